@@ -1,0 +1,95 @@
+"""Synthetic QCQP generators (host side, NumPy only).
+
+They mirror the problem families of the reference's examples and of
+BASELINE.json's configs; each returns a list of ``(P, q, r, relop)`` tuples
+with the objective first (relop ``None``) -- the raw-array form accepted by
+``qcqp_amd.QCQPForm.from_arrays`` -- plus a ``maximize`` flag.
+
+* ``boolean_least_squares``  -- examples/boolean_least_squares.py:6-15
+* ``maxcut``                 -- examples/maxcut.py:9-21
+* ``beamforming``            -- examples/secondary_user_beamforming.py:18-41
+* ``dense_indefinite``       -- SURVEY.md section 8(d) cfg5 generator
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+def boolean_least_squares(n, m_rows, seed=1, legacy_seed=False):
+    """minimize ||Ax-b||^2  s.t. x_i^2 == 1.
+
+    legacy_seed=True draws A, b exactly like the example script
+    (np.random.seed(seed); randn(m, n); randn(m, 1))."""
+    if legacy_seed:
+        st = np.random.get_state()
+        np.random.seed(seed)
+        A = np.random.randn(m_rows, n)
+        b = np.random.randn(m_rows, 1)
+        np.random.set_state(st)
+    else:
+        rs = np.random.RandomState(seed)
+        A = rs.randn(m_rows, n)
+        b = rs.randn(m_rows, 1)
+    P0 = A.T.dot(A)
+    P0 = (P0 + P0.T) / 2.
+    q0 = (-2. * A.T.dot(b)).ravel()
+    r0 = float(b.T.dot(b)[0, 0])
+    funcs = [(P0, q0, r0, None)]
+    for i in range(n):
+        P = sp.csr_matrix(([1.0], ([i], [i])), shape=(n, n))
+        funcs.append((P, np.zeros(n), -1.0, '=='))
+    return funcs, False, dict(A=A, b=b)
+
+
+def maxcut(n, p=0.5, seed=1):
+    """maximize 0.25 (sum(W) - x^T W x)  s.t. x_i^2 == 1   (minimise form returned)."""
+    rs = np.random.RandomState(seed)
+    U = np.triu((rs.uniform(size=(n, n)) < p).astype(float), 1)
+    W = U + U.T
+    P0 = 0.25 * W
+    r0 = -0.25 * float(W.sum())
+    funcs = [(P0, np.zeros(n), r0, None)]
+    for i in range(n):
+        P = sp.csr_matrix(([1.0], ([i], [i])), shape=(n, n))
+        funcs.append((P, np.zeros(n), -1.0, '=='))
+    return funcs, True, dict(W=W)
+
+
+def beamforming(nant, m_h, l, tau=20., eta=2., seed=1):
+    """minimize ||x||^2 s.t. |h_i^H x|^2 >= tau, |g_i^H x|^2 <= eta, real expansion (n = 2 nant)."""
+    rs = np.random.RandomState(seed)
+    HR = rs.randn(m_h, nant)
+    HI = rs.randn(m_h, nant)
+    A = np.hstack((HR, HI))
+    B = np.hstack((-HI, HR))
+    GR = rs.randn(l, nant)
+    GI = rs.randn(l, nant)
+    Cm = np.hstack((GR, GI))
+    D = np.hstack((-GI, GR))
+    n = 2 * nant
+    funcs = [(np.eye(n), np.zeros(n), 0.0, None)]
+    for i in range(m_h):
+        P = -(np.outer(A[i], A[i]) + np.outer(B[i], B[i]))
+        funcs.append((P, np.zeros(n), tau, '<='))
+    for i in range(l):
+        P = np.outer(Cm[i], Cm[i]) + np.outer(D[i], D[i])
+        funcs.append((P, np.zeros(n), -eta, '<='))
+    return funcs, False, dict(A=A, B=B, C=Cm, D=D)
+
+
+def dense_indefinite(n, m, seed=7, easy=True):
+    """Random indefinite dense QCQP: P_k = (G+G^T)/2, G = randn/sqrt(n); last constraint is the
+    ball ||x||^2 <= n.  easy=True scales r_k with n so that feasibility is reachable."""
+    rs = np.random.RandomState(seed)
+
+    def sym():
+        G = rs.randn(n, n) / np.sqrt(n)
+        return (G + G.T) / 2.
+
+    funcs = [(sym(), rs.randn(n), 0.0, None)]
+    for k in range(m - 1):
+        r = -1. - abs(rs.randn())
+        if easy:
+            r *= n / 8.
+        funcs.append((sym(), rs.randn(n), r, '<='))
+    funcs.append((np.eye(n), np.zeros(n), -float(n), '<='))
+    return funcs, False, {}
