@@ -1,0 +1,136 @@
+/*
+ * qcqp_mi.h -- C ABI of the MI355X-native Suggest-and-Improve engine (libqcqp_mi.so).
+ *
+ * This is the drop-in boundary for the hot path of cvxgrp/qcqp.  The reference has no FFI
+ * or plugin registry; its seam is the plain-Python call sites
+ *     QCQP.suggest            qcqp/qcqp.py:378-401   (RANDOM :381-382, SDR tail :394-401)
+ *     QCQP._improve           qcqp/qcqp.py:403-417   (improve_coord_descent :181-192,
+ *                                                      improve_admm :254-285)
+ * operating on a QCQPForm (qcqp/utilities.py:122-146) of QuadraticFunction objects
+ * (qcqp/utilities.py:41-62).  Each entry point below names the reference code it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative QCQPMI_E* code and
+ *     never throws; qcqpmi_last_error() returns the message for the last failure.
+ *   - the caller owns every host buffer (C-contiguous, fp64 / int64) and may free it on return.
+ *   - the context owns all device memory and one HIP stream; a context is not thread-safe,
+ *     distinct contexts are independent.
+ *   - candidate points are handed over as an n x R "column per candidate" array:
+ *     candidate r occupies X[r*n .. r*n + n).
+ *   - "population" = the device-resident batch of candidates (restarts of improve(), samples of
+ *     suggest()); the timed hot path works on the resident population, host copies are explicit.
+ *   - relop codes: 0 = none (objective), 1 = '<=', 2 = '=='.
+ *   - all arithmetic is fp64.
+ */
+#ifndef QCQP_MI_H
+#define QCQP_MI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QCQPMI_ABI_VERSION 1
+
+enum {
+    QCQPMI_OK = 0,
+    QCQPMI_EINVAL = -1,       /* bad argument */
+    QCQPMI_EHIP = -2,         /* HIP runtime failure (no device, OOM, launch error) */
+    QCQPMI_ESTATE = -3,       /* call order (e.g. run before finalize / without population) */
+    QCQPMI_EUNSUPPORTED = -4, /* problem structure not handled by the HIP engine yet */
+    QCQPMI_EREFERENCE = -5,   /* the reference would raise on this input (see last_error) */
+    QCQPMI_ECOMM = -6         /* RCCL failure */
+};
+
+enum { QCQPMI_FMT_DENSE = 0, QCQPMI_FMT_CSR = 1 };
+
+typedef struct qcqpmi_ctx qcqpmi_ctx;
+
+/* ---- library / device ------------------------------------------------------------------ */
+int qcqpmi_abi_version(void);
+int qcqpmi_device_count(void); /* number of visible HIP devices, 0 if none, never fails */
+const char *qcqpmi_last_error(const qcqpmi_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* ---- context = one QCQPForm on one GPU  (utilities.py:122-130) ------------------------- */
+int qcqpmi_ctx_create(qcqpmi_ctx **out, int64_t n, int64_t m, int device);
+void qcqpmi_ctx_destroy(qcqpmi_ctx *ctx);
+
+/* QuadraticFunction(P, q, r, relop)  (utilities.py:41-46).  k = 0 is the objective f0,
+ * k = 1..m the constraints fs[k-1].  P must be symmetric (get_qcqp_form symmetrises,
+ * utilities.py:333,345).  DENSE: vals = n*n row-major, idx = ptr = NULL, nnz ignored.
+ * CSR: ptr[n+1], idx[nnz], vals[nnz]. */
+int qcqpmi_set_quad(qcqpmi_ctx *ctx, int64_t k, int format, const double *vals,
+                    const int64_t *idx, const int64_t *ptr, int64_t nnz, const double *q,
+                    double r, int relop);
+/* Build the device layouts (MFMA-packed P0, per-coordinate constraint lists). */
+int qcqpmi_finalize(qcqpmi_ctx *ctx);
+/* 1 if every constraint touches exactly one coordinate (Boolean / box families) */
+int qcqpmi_is_separable(const qcqpmi_ctx *ctx);
+
+/* ---- population ------------------------------------------------------------------------- */
+int qcqpmi_pop_upload(qcqpmi_ctx *ctx, const double *X, int64_t R);
+int qcqpmi_pop_download(qcqpmi_ctx *ctx, double *X, int64_t R);
+int64_t qcqpmi_pop_size(const qcqpmi_ctx *ctx);
+/* suggest(RANDOM) batched: x_r = randn(n)  (qcqp.py:381-382).  Counter-based stream keyed on
+ * (seed, first_index + r, element): independent of the sharding over GPUs. */
+int qcqpmi_pop_randn(qcqpmi_ctx *ctx, int64_t R, uint64_t seed, uint64_t first_index);
+/* suggest(SDR) tail batched: x_s = mu + F xi_s, xi_s ~ N(0, I)  (qcqp.py:396), where
+ * F (n x n row-major) is any factor with F F^T = Sigma (the host computes it once: Cholesky, or
+ * the SVD factor NumPy's multivariate_normal uses).  Xi (n x S, column per sample) may be given
+ * for reproducibility tests; NULL = device Philox normals keyed on (seed, first_index + s). */
+int qcqpmi_pop_sdr_sample(qcqpmi_ctx *ctx, const double *mu, const double *F, int64_t S,
+                          uint64_t seed, uint64_t first_index, const double *Xi);
+
+/* ---- evaluation: QuadraticFunction.eval / violation, QCQPForm.violations
+ *      (utilities.py:49-62, 133-134; callers qcqp.py:399-401, 415-417) -------------------- */
+/* on the resident population; f0/maxviol have R entries; F (optional) is (m+1) x R row-major */
+int qcqpmi_pop_eval(qcqpmi_ctx *ctx, double *f0, double *maxviol, double *F);
+/* host convenience: upload X, evaluate */
+int qcqpmi_eval_batch(qcqpmi_ctx *ctx, const double *X, int64_t S, double *f0, double *maxviol,
+                      double *F);
+
+/* ---- improve(COORD_DESCENT) on the resident population
+ *      (improve_coord_descent qcqp.py:181-192; phase 1 :101-148; phase 2 :152-178;
+ *       onevar_qcqp utilities.py:241-288; get_feasible_intervals utilities.py:198-232).
+ * Outputs (each R entries, any may be NULL):
+ *   sweeps1/sweeps2   sweeps started in phase 1 / phase 2
+ *   visits2           coordinate visits of phase 2 (loop bodies of qcqp.py:162)
+ *   accepted2         accepted coordinate updates of phase 2
+ *   ran_phase2        1 if the restart passed the max-violation gate (qcqp.py:189)
+ *   f0/maxviol        objective / max violation of the final point (qcqp.py:415-417)       */
+int qcqpmi_cd_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double viol_tol, double tol,
+                  uint64_t seed, uint64_t first_index, int64_t *sweeps1, int64_t *sweeps2,
+                  int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
+                  double *maxviol);
+
+/* ---- QCQPForm.better ordering over the population (utilities.py:135-146):
+ * lexicographic minimum of (int(maxviol/tol), f0), ties -> lowest index.  Evaluates the
+ * population if needed.  best_x (n doubles) may be NULL. */
+int qcqpmi_select_best(qcqpmi_ctx *ctx, double tol, int64_t *best_index, double *best_f0,
+                       double *best_maxviol, double *best_x);
+
+/* ---- timing of the hot kernels (HIP events on the context's stream) ---------------------
+ * which: 0 = eval, 1 = cd phase 1, 2 = cd phase 2, 3 = sdr sampling.  Returns the duration of
+ * the most recent launch of that kernel in milliseconds. */
+int qcqpmi_last_kernel_ms(qcqpmi_ctx *ctx, int which, double *ms);
+int qcqpmi_sync(qcqpmi_ctx *ctx);
+
+/* ---- multi-GPU: one process per GPU, restarts sharded by global index, ONE collective at the
+ * end to pick the global best (RCCL over xGMI; librccl is loaded lazily). --------------- */
+int qcqpmi_comm_unique_id(uint8_t id_out[128]);
+int qcqpmi_comm_init(qcqpmi_ctx *ctx, int rank, int world, const uint8_t id[128]);
+/* all ranks call; local best (from qcqpmi_select_best semantics) -> global best on every rank.
+ * index_offset = global index of this rank's candidate 0. */
+int qcqpmi_comm_select_best(qcqpmi_ctx *ctx, double tol, int64_t index_offset,
+                            int64_t *best_global_index, double *best_f0, double *best_maxviol,
+                            double *best_x);
+int qcqpmi_comm_barrier(qcqpmi_ctx *ctx);
+/* in-place all-reduce of up to 4 host doubles; op 0 = max, 1 = sum (bench.py: max-over-ranks
+ * step time, sum-over-ranks work counters) */
+int qcqpmi_comm_allreduce(qcqpmi_ctx *ctx, double *values, int64_t count, int op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

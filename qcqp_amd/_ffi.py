@@ -1,0 +1,64 @@
+"""Thin binding of the C ABI declared in include/qcqp_mi.h.
+
+The north star asks for cffi; cffi is not installed in the image, so the binding uses the
+standard library's ctypes in the same ABI-mode style (dlopen + declared prototypes).  There is
+no Python/NumPy fallback: if the shared library is missing this module raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, 'libqcqp_mi.so')
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int64)
+c_bp = C.POINTER(C.c_uint8)
+
+# (name, restype, argtypes) -- every symbol of include/qcqp_mi.h
+PROTOTYPES = [
+    ('qcqpmi_abi_version', C.c_int, []),
+    ('qcqpmi_device_count', C.c_int, []),
+    ('qcqpmi_last_error', C.c_char_p, [C.c_void_p]),
+    ('qcqpmi_ctx_create', C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_int]),
+    ('qcqpmi_ctx_destroy', None, [C.c_void_p]),
+    ('qcqpmi_set_quad', C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_dp, c_ip, c_ip, C.c_int64, c_dp,
+                                  C.c_double, C.c_int]),
+    ('qcqpmi_finalize', C.c_int, [C.c_void_p]),
+    ('qcqpmi_is_separable', C.c_int, [C.c_void_p]),
+    ('qcqpmi_pop_upload', C.c_int, [C.c_void_p, c_dp, C.c_int64]),
+    ('qcqpmi_pop_download', C.c_int, [C.c_void_p, c_dp, C.c_int64]),
+    ('qcqpmi_pop_size', C.c_int64, [C.c_void_p]),
+    ('qcqpmi_pop_randn', C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]),
+    ('qcqpmi_pop_sdr_sample', C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int64, C.c_uint64, C.c_uint64, c_dp]),
+    ('qcqpmi_pop_eval', C.c_int, [C.c_void_p, c_dp, c_dp, c_dp]),
+    ('qcqpmi_eval_batch', C.c_int, [C.c_void_p, c_dp, C.c_int64, c_dp, c_dp, c_dp]),
+    ('qcqpmi_cd_run', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_uint64,
+                                C.c_uint64, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp]),
+    ('qcqpmi_select_best', C.c_int, [C.c_void_p, C.c_double, c_ip, c_dp, c_dp, c_dp]),
+    ('qcqpmi_last_kernel_ms', C.c_int, [C.c_void_p, C.c_int, c_dp]),
+    ('qcqpmi_sync', C.c_int, [C.c_void_p]),
+    ('qcqpmi_comm_unique_id', C.c_int, [c_bp]),
+    ('qcqpmi_comm_init', C.c_int, [C.c_void_p, C.c_int, C.c_int, c_bp]),
+    ('qcqpmi_comm_select_best', C.c_int, [C.c_void_p, C.c_double, C.c_int64, c_ip, c_dp, c_dp, c_dp]),
+    ('qcqpmi_comm_barrier', C.c_int, [C.c_void_p]),
+    ('qcqpmi_comm_allreduce', C.c_int, [C.c_void_p, c_dp, C.c_int64, C.c_int]),
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libqcqp_mi.so (built in-tree by qcqp_amd._build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise ImportError(
+                'libqcqp_mi.so is not built (%s missing). Run `python -m qcqp_amd._build` or '
+                '__graft_entry__.build(); the engine has no CPU fallback.' % LIBPATH)
+        L = C.CDLL(LIBPATH)
+        for name, res, args in PROTOTYPES:
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

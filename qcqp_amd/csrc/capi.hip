@@ -1,0 +1,743 @@
+// C ABI of libqcqp_mi.so (declared in include/qcqp_mi.h): context, problem upload, population
+// management, launches of the kernels in kernels.hip, HIP-event timing, lazy RCCL.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qcqp_mi.h"
+#include "kernels.hip"
+
+using namespace qcqpmi;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HostQuad {
+    bool set = false;
+    std::vector<int> ci, cj;  // COO
+    std::vector<double> cv;
+    std::vector<double> q;
+    double r = 0.0;
+    int relop = 0;
+};
+
+struct Timer {
+    hipEvent_t beg = nullptr, end = nullptr;
+    bool valid = false;
+};
+
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi *rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *nm : names) {
+            api.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (api.h) break;
+        }
+        if (api.h) {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+            api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
+            api.Broadcast = (decltype(api.Broadcast))dlsym(api.h, "ncclBroadcast");
+            api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+        }
+    }
+    return (api.h && api.GetUniqueId && api.CommInitRank && api.AllGather && api.Broadcast &&
+            api.AllReduce) ? &api : nullptr;
+}
+
+}  // namespace
+
+struct qcqpmi_ctx {
+    int device = 0;
+    int64_t n = 0, n16 = 0, m = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<HostQuad> quads;  // m+1
+    bool finalized = false;
+    bool sep = false;
+    int maxc = 0;
+    DevProblem dp{};
+    std::vector<void *> prob_allocs;
+    // population
+    int64_t R = 0, Rpad = 0, Rcap = 0;
+    double *X = nullptr, *Xi = nullptr;
+    double *d_f0 = nullptr, *d_mv = nullptr, *d_F = nullptr;
+    int64_t *d_visits = nullptr, *d_acc = nullptr, *d_sweeps = nullptr, *d_sweeps1 = nullptr;
+    int *d_status = nullptr;
+    uint8_t *d_flag = nullptr;
+    int64_t *d_best_idx = nullptr;
+    double *d_best_key = nullptr;
+    double *d_stage = nullptr;  // host-layout staging (n x Rcap)
+    int64_t F_cap = 0;
+    bool evaluated = false;
+    // SDR factor
+    double *d_Fpack = nullptr, *d_Frow = nullptr, *d_mu = nullptr;
+    Timer timers[4];
+    // comm
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    double *d_comm = nullptr;
+};
+
+namespace {
+
+int fail(qcqpmi_ctx *c, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(c, QCQPMI_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+template <typename T>
+int dev_alloc(qcqpmi_ctx *c, T **p, size_t count, bool zero = true) {
+    void *v = nullptr;
+    HIPCHK(c, hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(T)));
+    if (zero) HIPCHK(c, hipMemsetAsync(v, 0, std::max<size_t>(count, 1) * sizeof(T), c->stream));
+    *p = (T *)v;
+    return 0;
+}
+
+template <typename T>
+int prob_upload(qcqpmi_ctx *c, const T **dst, const std::vector<T> &src) {
+    T *p = nullptr;
+    int rc = dev_alloc(c, &p, src.size(), false);
+    if (rc) return rc;
+    c->prob_allocs.push_back(p);
+    if (!src.empty())
+        HIPCHK(c, hipMemcpyAsync(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *dst = p;
+    return 0;
+}
+
+void free_population(qcqpmi_ctx *c) {
+    void *ptrs[] = {c->X, c->Xi, c->d_f0, c->d_mv, c->d_F, c->d_visits, c->d_acc, c->d_sweeps,
+                    c->d_sweeps1, c->d_status, c->d_flag, c->d_stage};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    c->X = c->Xi = c->d_f0 = c->d_mv = c->d_F = c->d_stage = nullptr;
+    c->d_visits = c->d_acc = c->d_sweeps = c->d_sweeps1 = nullptr;
+    c->d_status = nullptr; c->d_flag = nullptr;
+    c->Rcap = 0; c->F_cap = 0;
+}
+
+int pop_reserve(qcqpmi_ctx *c, int64_t R) {
+    if (R <= 0) return fail(c, QCQPMI_EINVAL, "population size must be positive");
+    int64_t Rpad = (R + 15) / 16 * 16;
+    if (Rpad > c->Rcap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        free_population(c);
+        int rc = 0;
+        size_t xe = (size_t)Rpad * (size_t)c->n16;
+        if ((rc = dev_alloc(c, &c->X, xe))) return rc;
+        if ((rc = dev_alloc(c, &c->d_stage, (size_t)Rpad * (size_t)c->n))) return rc;
+        if ((rc = dev_alloc(c, &c->d_f0, Rpad))) return rc;
+        if ((rc = dev_alloc(c, &c->d_mv, Rpad))) return rc;
+        if ((rc = dev_alloc(c, &c->d_visits, Rpad))) return rc;
+        if ((rc = dev_alloc(c, &c->d_acc, Rpad))) return rc;
+        if ((rc = dev_alloc(c, &c->d_sweeps, Rpad))) return rc;
+        if ((rc = dev_alloc(c, &c->d_sweeps1, Rpad))) return rc;
+        if ((rc = dev_alloc(c, &c->d_status, Rpad))) return rc;
+        if ((rc = dev_alloc(c, &c->d_flag, Rpad))) return rc;
+        c->Rcap = Rpad;
+    }
+    c->R = R;
+    c->Rpad = Rpad;
+    c->evaluated = false;
+    return 0;
+}
+
+void tic(qcqpmi_ctx *c, int which) { (void)hipEventRecord(c->timers[which].beg, c->stream); }
+void toc(qcqpmi_ctx *c, int which) {
+    (void)hipEventRecord(c->timers[which].end, c->stream);
+    c->timers[which].valid = true;
+}
+
+int launch_eval(qcqpmi_ctx *c, bool want_F) {
+    if (want_F) {
+        int64_t need = (c->m + 1) * c->Rpad;
+        if (need > c->F_cap) {
+            if (c->d_F) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_F); c->d_F = nullptr; }
+            int rc = dev_alloc(c, &c->d_F, need);
+            if (rc) return rc;
+            c->F_cap = need;
+        }
+    }
+    EvalArgs a;
+    a.P = c->dp; a.X = c->X; a.R = c->R; a.f0 = c->d_f0; a.maxviol = c->d_mv;
+    a.F = want_F ? c->d_F : nullptr; a.Rpad = c->Rpad;
+    tic(c, 0);
+    hipLaunchKernelGGL(eval_kernel, dim3((unsigned)(c->Rpad / 16)), dim3(256), 0, c->stream, a);
+    toc(c, 0);
+    HIPCHK(c, hipGetLastError());
+    c->evaluated = true;
+    return 0;
+}
+
+template <int MAXC>
+int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
+    dim3 grid((unsigned)(c->Rpad / 16)), block(256);
+    if (phase1) {
+        tic(c, 1);
+        hipLaunchKernelGGL(cd_phase1_sep_kernel<MAXC>, grid, block, 0, c->stream, a1);
+        toc(c, 1);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+    size_t common = (size_t)(4 * 256 + 256 + 2 * (MAXC + 1) * 256 + 16 + 128 + 16) * sizeof(double);
+    size_t with_x = common + (size_t)c->n16 * 16 * sizeof(double);
+    used_lds = with_x <= 160 * 1024;
+    tic(c, 2);
+    if (used_lds) {
+        auto k = cd_phase2_kernel<MAXC, true>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)with_x));
+        hipLaunchKernelGGL(k, grid, block, with_x, c->stream, a1);
+    } else {
+        auto k = cd_phase2_kernel<MAXC, false>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)common));
+        hipLaunchKernelGGL(k, grid, block, common, c->stream, a1);
+    }
+    toc(c, 2);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int check_ready(qcqpmi_ctx *c, bool need_pop) {
+    if (!c) return QCQPMI_EINVAL;
+    if (!c->finalized) return fail(c, QCQPMI_ESTATE, "qcqpmi_finalize has not been called");
+    if (need_pop && c->R <= 0) return fail(c, QCQPMI_ESTATE, "no resident population (upload / randn / sdr_sample first)");
+    return 0;
+}
+
+}  // namespace
+
+// ============================================================================================
+
+extern "C" {
+
+int qcqpmi_abi_version(void) { return QCQPMI_ABI_VERSION; }
+
+int qcqpmi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *qcqpmi_last_error(const qcqpmi_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int qcqpmi_ctx_create(qcqpmi_ctx **out, int64_t n, int64_t m, int device) {
+    if (!out || n <= 0 || m < 0) return fail(nullptr, QCQPMI_EINVAL, "ctx_create: bad arguments");
+    int ndev = qcqpmi_device_count();
+    if (ndev <= 0)
+        return fail(nullptr, QCQPMI_EHIP, "no HIP device visible: the qcqp_amd engine requires an MI355X (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, QCQPMI_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    qcqpmi_ctx *c = new qcqpmi_ctx();
+    c->device = device; c->n = n; c->m = m; c->n16 = (n + 15) / 16 * 16;
+    c->quads.resize((size_t)m + 1);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) {
+        e = hipEventCreate(&c->timers[i].beg);
+        if (e == hipSuccess) e = hipEventCreate(&c->timers[i].end);
+    }
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, QCQPMI_EHIP, "ctx_create: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->comm);
+    free_population(c);
+    for (void *p : c->prob_allocs) (void)hipFree(p);
+    void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int qcqpmi_set_quad(qcqpmi_ctx *c, int64_t k, int format, const double *vals, const int64_t *idx,
+                    const int64_t *ptr, int64_t nnz, const double *q, double r, int relop) {
+    if (!c) return QCQPMI_EINVAL;
+    if (c->finalized) return fail(c, QCQPMI_ESTATE, "set_quad after finalize");
+    if (k < 0 || k > c->m || !q) return fail(c, QCQPMI_EINVAL, "set_quad: bad k or q");
+    if ((k == 0) != (relop == 0) || relop < 0 || relop > 2)
+        return fail(c, QCQPMI_EINVAL, "set_quad: relop %d invalid for function %lld", relop, (long long)k);
+    HostQuad &h = c->quads[(size_t)k];
+    h = HostQuad();
+    const int64_t n = c->n;
+    if (format == QCQPMI_FMT_DENSE) {
+        if (!vals) return fail(c, QCQPMI_EINVAL, "set_quad: dense vals missing");
+        for (int64_t i = 0; i < n; i++)
+            for (int64_t j = 0; j < n; j++) {
+                double v = vals[i * n + j];
+                if (v != 0.0) { h.ci.push_back((int)i); h.cj.push_back((int)j); h.cv.push_back(v); }
+            }
+    } else if (format == QCQPMI_FMT_CSR) {
+        if (!ptr || (nnz > 0 && (!idx || !vals))) return fail(c, QCQPMI_EINVAL, "set_quad: CSR arrays missing");
+        for (int64_t i = 0; i < n; i++)
+            for (int64_t e = ptr[i]; e < ptr[i + 1]; e++) {
+                if (idx[e] < 0 || idx[e] >= n || e >= nnz) return fail(c, QCQPMI_EINVAL, "set_quad: CSR index out of range");
+                if (vals[e] != 0.0) { h.ci.push_back((int)i); h.cj.push_back((int)idx[e]); h.cv.push_back(vals[e]); }
+            }
+    } else {
+        return fail(c, QCQPMI_EINVAL, "set_quad: unknown format %d", format);
+    }
+    h.q.assign(q, q + n);
+    h.r = r; h.relop = relop; h.set = true;
+    return 0;
+}
+
+int qcqpmi_finalize(qcqpmi_ctx *c) {
+    if (!c) return QCQPMI_EINVAL;
+    if (c->finalized) return 0;
+    for (size_t k = 0; k < c->quads.size(); k++)
+        if (!c->quads[k].set) return fail(c, QCQPMI_ESTATE, "finalize: function %zu was never set", k);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n = c->n, n16 = c->n16, m = c->m;
+    DevProblem &dp = c->dp;
+    dp.n = n; dp.n16 = n16; dp.NB = n16 / 16; dp.KS = n16 / 4; dp.m = m;
+    // ---- objective: dense padded + MFMA-packed
+    {
+        const HostQuad &h = c->quads[0];
+        std::vector<double> P((size_t)n16 * n16, 0.0), q((size_t)n16, 0.0);
+        for (size_t e = 0; e < h.cv.size(); e++) P[(size_t)h.ci[e] * n16 + h.cj[e]] += h.cv[e];
+        for (int64_t j = 0; j < n; j++) q[j] = h.q[j];
+        int rc;
+        if ((rc = prob_upload(c, &dp.P0, P))) return rc;
+        if ((rc = prob_upload(c, &dp.q0, q))) return rc;
+        double *ap = nullptr;
+        if ((rc = dev_alloc(c, &ap, (size_t)n16 * n16, false))) return rc;
+        c->prob_allocs.push_back(ap);
+        int64_t total = n16 * n16;
+        hipLaunchKernelGGL(pack_A_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                           dp.P0, ap, n16, dp.KS);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // P, q vectors go out of scope
+        dp.Apack = ap;
+        dp.r0 = h.r;
+    }
+    // ---- constraints: separable iff one diagonal entry / one linear entry on the same coordinate
+    bool sep = true;
+    std::vector<int> coord_of((size_t)m, -1);
+    for (int64_t k = 1; k <= m && sep; k++) {
+        const HostQuad &h = c->quads[(size_t)k];
+        int coord = -1;
+        for (size_t e = 0; e < h.cv.size(); e++) {
+            if (h.ci[e] != h.cj[e]) { sep = false; break; }
+            if (coord >= 0 && coord != h.ci[e]) { sep = false; break; }
+            coord = h.ci[e];
+        }
+        for (int64_t j = 0; j < n && sep; j++)
+            if (h.q[j] != 0.0) { if (coord >= 0 && coord != (int)j) sep = false; coord = (int)j; }
+        if (coord < 0) sep = false;  // constant constraint
+        coord_of[(size_t)k - 1] = coord;
+    }
+    c->sep = sep;
+    dp.sep = sep ? 1 : 0;
+    int rc;
+    if (sep) {
+        std::vector<int> cptr((size_t)n16 + 1, 0);
+        for (int64_t k = 0; k < m; k++) cptr[(size_t)coord_of[k] + 1]++;
+        int maxc = 0;
+        for (int64_t i = 0; i < n16; i++) { maxc = std::max(maxc, cptr[i + 1]); cptr[i + 1] += cptr[i]; }
+        std::vector<double> cp((size_t)m), cq((size_t)m), cr((size_t)m);
+        std::vector<int> crel((size_t)m), cidx((size_t)m), fill(cptr.begin(), cptr.end() - 1);
+        for (int64_t k = 0; k < m; k++) {  // constraint order preserved inside a coordinate's list
+            const HostQuad &h = c->quads[(size_t)k + 1];
+            int i = coord_of[k], e = fill[i]++;
+            double p = 0.0;
+            for (size_t t = 0; t < h.cv.size(); t++) p += h.cv[t];
+            cp[e] = p; cq[e] = h.q[i]; cr[e] = h.r; crel[e] = h.relop; cidx[e] = (int)k + 1;
+        }
+        c->maxc = maxc; dp.maxc = maxc;
+        if ((rc = prob_upload(c, &dp.cptr, cptr))) return rc;
+        if ((rc = prob_upload(c, &dp.cp, cp))) return rc;
+        if ((rc = prob_upload(c, &dp.cq, cq))) return rc;
+        if ((rc = prob_upload(c, &dp.cr, cr))) return rc;
+        if ((rc = prob_upload(c, &dp.crel, crel))) return rc;
+        if ((rc = prob_upload(c, &dp.cidx, cidx))) return rc;
+    } else {
+        std::vector<int64_t> gptr((size_t)m + 1, 0);
+        std::vector<int> gi, gj, grel((size_t)m);
+        std::vector<double> gv, gq((size_t)m * n16, 0.0), gr((size_t)m);
+        for (int64_t k = 0; k < m; k++) {
+            const HostQuad &h = c->quads[(size_t)k + 1];
+            gi.insert(gi.end(), h.ci.begin(), h.ci.end());
+            gj.insert(gj.end(), h.cj.begin(), h.cj.end());
+            gv.insert(gv.end(), h.cv.begin(), h.cv.end());
+            gptr[(size_t)k + 1] = (int64_t)gv.size();
+            for (int64_t j = 0; j < n; j++) gq[(size_t)k * n16 + j] = h.q[j];
+            gr[k] = h.r; grel[k] = h.relop;
+        }
+        if ((rc = prob_upload(c, &dp.gptr, gptr))) return rc;
+        if ((rc = prob_upload(c, &dp.gi, gi))) return rc;
+        if ((rc = prob_upload(c, &dp.gj, gj))) return rc;
+        if ((rc = prob_upload(c, &dp.gv, gv))) return rc;
+        if ((rc = prob_upload(c, &dp.gq, gq))) return rc;
+        if ((rc = prob_upload(c, &dp.gr, gr))) return rc;
+        if ((rc = prob_upload(c, &dp.grel, grel))) return rc;
+    }
+    if ((rc = dev_alloc(c, &c->d_best_idx, 2))) return rc;
+    if ((rc = dev_alloc(c, &c->d_best_key, 2))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // host copies are no longer needed
+    for (auto &h : c->quads) { std::vector<int>().swap(h.ci); std::vector<int>().swap(h.cj); std::vector<double>().swap(h.cv); }
+    c->finalized = true;
+    return 0;
+}
+
+int qcqpmi_is_separable(const qcqpmi_ctx *c) { return (c && c->finalized && c->sep) ? 1 : 0; }
+
+// -------------------------------------------------------------------------------- population
+
+int qcqpmi_pop_upload(qcqpmi_ctx *c, const double *X, int64_t R) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!X) return fail(c, QCQPMI_EINVAL, "pop_upload: X is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = pop_reserve(c, R))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_stage, X, (size_t)R * c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int64_t total = c->Rpad * c->n16;
+    hipLaunchKernelGGL(to_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_stage, c->X, c->n, c->n16, R, c->Rpad);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int qcqpmi_pop_download(qcqpmi_ctx *c, double *X, int64_t R) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!X || R <= 0 || R > c->R) return fail(c, QCQPMI_EINVAL, "pop_download: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t total = R * c->n;
+    hipLaunchKernelGGL(from_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       c->X, c->d_stage, c->n, c->n16, R);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(X, c->d_stage, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int64_t qcqpmi_pop_size(const qcqpmi_ctx *c) { return c ? c->R : 0; }
+
+int qcqpmi_pop_randn(qcqpmi_ctx *c, int64_t R, uint64_t seed, uint64_t first_index) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = pop_reserve(c, R))) return rc;
+    int64_t total = c->Rpad * c->n16;
+    hipLaunchKernelGGL(randn_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       c->X, c->n, c->n16, R, c->Rpad, seed, first_index);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int qcqpmi_pop_sdr_sample(qcqpmi_ctx *c, const double *mu, const double *F, int64_t S, uint64_t seed,
+                          uint64_t first_index, const double *Xi) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!mu || !F) return fail(c, QCQPMI_EINVAL, "pop_sdr_sample: mu / F missing");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n = c->n, n16 = c->n16;
+    if (!c->d_Fpack) {
+        if ((rc = dev_alloc(c, &c->d_Fpack, (size_t)n16 * n16))) return rc;
+        if ((rc = dev_alloc(c, &c->d_Frow, (size_t)n16 * n16))) return rc;
+        if ((rc = dev_alloc(c, &c->d_mu, (size_t)n16))) return rc;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_Frow, 0, (size_t)n16 * n16 * sizeof(double), c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->d_Frow, (size_t)n16 * sizeof(double), F, (size_t)n * sizeof(double),
+                               (size_t)n * sizeof(double), (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_mu, mu, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int64_t total = n16 * n16;
+    hipLaunchKernelGGL(pack_A_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_Frow, c->d_Fpack, n16, c->dp.KS);
+    if ((rc = pop_reserve(c, S))) return rc;
+    // the standard normals: caller-provided (host layout) or device Philox
+    if (c->Xi) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->Xi); c->Xi = nullptr; }
+    if ((rc = dev_alloc(c, &c->Xi, (size_t)c->Rpad * n16))) return rc;
+    int64_t tot2 = c->Rpad * n16;
+    if (Xi) {
+        HIPCHK(c, hipMemcpyAsync(c->d_stage, Xi, (size_t)S * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(to_tiles_kernel, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_stage, c->Xi, n, n16, S, c->Rpad);
+    } else {
+        hipLaunchKernelGGL(randn_tiles_kernel, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, c->stream,
+                           c->Xi, n, n16, S, c->Rpad, seed, first_index);
+    }
+    tic(c, 3);
+    hipLaunchKernelGGL(affine_tiles_kernel, dim3((unsigned)(c->Rpad / 16)), dim3(256), 0, c->stream,
+                       c->d_Fpack, c->d_mu, c->Xi, c->X, n, n16, c->dp.NB, c->dp.KS);
+    toc(c, 3);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------- evaluation
+
+int qcqpmi_pop_eval(qcqpmi_ctx *c, double *f0, double *maxviol, double *F) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = launch_eval(c, F != nullptr))) return rc;
+    if (f0) HIPCHK(c, hipMemcpyAsync(f0, c->d_f0, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (maxviol) HIPCHK(c, hipMemcpyAsync(maxviol, c->d_mv, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (F)
+        HIPCHK(c, hipMemcpy2DAsync(F, (size_t)c->R * sizeof(double), c->d_F, (size_t)c->Rpad * sizeof(double),
+                                   (size_t)c->R * sizeof(double), (size_t)(c->m + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int qcqpmi_eval_batch(qcqpmi_ctx *c, const double *X, int64_t S, double *f0, double *maxviol, double *F) {
+    int rc = qcqpmi_pop_upload(c, X, S);
+    if (rc) return rc;
+    return qcqpmi_pop_eval(c, f0, maxviol, F);
+}
+
+// ------------------------------------------------------------------------- coordinate descent
+
+int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol, double tol,
+                  uint64_t seed, uint64_t first_index, int64_t *sweeps1, int64_t *sweeps2,
+                  int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
+                  double *maxviol) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!c->sep)
+        return fail(c, QCQPMI_EUNSUPPORTED,
+                    "COORD_DESCENT on the HIP engine currently needs separable constraints (each constraint touching one coordinate); this problem couples coordinates inside a constraint");
+    if (c->maxc > 4)
+        return fail(c, QCQPMI_EUNSUPPORTED, "more than 4 constraints on one coordinate (%d)", c->maxc);
+    if (num_iters < 0 || !(tol > 0.0)) return fail(c, QCQPMI_EINVAL, "cd_run: bad num_iters / tol");
+    HIPCHK(c, hipSetDevice(c->device));
+    CdArgs a;
+    a.P = c->dp; a.X = c->X; a.R = c->R; a.f0cur = c->d_f0; a.slack = c->d_mv;
+    a.num_iters = num_iters; a.viol_tol = viol_tol; a.tol = tol; a.seed = seed; a.first_index = first_index;
+    a.visits = c->d_visits; a.accepted = c->d_acc; a.sweeps = c->d_sweeps; a.status = c->d_status;
+    a.flag = c->d_flag;
+    bool used_lds = false;
+    std::vector<int> st((size_t)c->R);
+    HIPCHK(c, hipMemsetAsync(c->d_sweeps1, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+    if (phase1) {
+        CdArgs a1 = a;
+        a1.sweeps = c->d_sweeps1;
+        rc = (c->maxc <= 1) ? launch_cd<1>(c, a1, true, used_lds) : launch_cd<4>(c, a1, true, used_lds);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int64_t r = 0; r < c->R; r++)
+            if (st[(size_t)r]) {
+                if (st[(size_t)r] == -3)
+                    return fail(c, QCQPMI_EREFERENCE, "phase 1: a variable appears in no constraint (reference: ValueError: max() arg is an empty sequence, qcqp.py:117); restart %lld", (long long)r);
+                return fail(c, QCQPMI_EREFERENCE, "phase 1: unbounded feasible interval with zero objective (reference: OverflowError in np.random.uniform, utilities.py:267); restart %lld", (long long)r);
+            }
+    }
+    // gate of improve_coord_descent (qcqp.py:189): phase 2 only if max violation < viol_tol.
+    // The evaluation also provides the phase-2 slack (qcqp.py:157) and the running objective.
+    if ((rc = launch_eval(c, false))) return rc;
+    {
+        std::vector<double> mv((size_t)c->R);
+        std::vector<uint8_t> flag((size_t)c->Rpad, 0);
+        HIPCHK(c, hipMemcpyAsync(mv.data(), c->d_mv, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int64_t r = 0; r < c->R; r++) flag[(size_t)r] = (mv[(size_t)r] < viol_tol) ? 1 : 0;
+        HIPCHK(c, hipMemcpyAsync(c->d_flag, flag.data(), (size_t)c->Rpad, hipMemcpyHostToDevice, c->stream));
+        if (ran_phase2) memcpy(ran_phase2, flag.data(), (size_t)c->R);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    rc = (c->maxc <= 1) ? launch_cd<1>(c, a, false, used_lds) : launch_cd<4>(c, a, false, used_lds);
+    if (rc) return rc;
+    if ((rc = launch_eval(c, false))) return rc;
+    if (sweeps1) HIPCHK(c, hipMemcpyAsync(sweeps1, c->d_sweeps1, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (sweeps2) HIPCHK(c, hipMemcpyAsync(sweeps2, c->d_sweeps, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (visits2) HIPCHK(c, hipMemcpyAsync(visits2, c->d_visits, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (accepted2) HIPCHK(c, hipMemcpyAsync(accepted2, c->d_acc, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (f0) HIPCHK(c, hipMemcpyAsync(f0, c->d_f0, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (maxviol) HIPCHK(c, hipMemcpyAsync(maxviol, c->d_mv, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int64_t r = 0; r < c->R; r++)
+        if (st[(size_t)r])
+            return fail(c, QCQPMI_EREFERENCE, "phase 2: the reference raises on restart %lld (code %d: unbounded interval with zero objective / NameError in OneVarQuadraticFunction.eval)", (long long)r, st[(size_t)r]);
+    return 0;
+}
+
+// -------------------------------------------------------------------------------- best of pop
+
+int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *best_f0,
+                       double *best_maxviol, double *best_x) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->evaluated && (rc = launch_eval(c, false))) return rc;
+    hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_f0, c->d_mv, c->R, tol,
+                       c->d_best_idx, c->d_best_key);
+    HIPCHK(c, hipGetLastError());
+    int64_t idx[2];
+    double key[2];
+    HIPCHK(c, hipMemcpyAsync(idx, c->d_best_idx, sizeof(idx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(key, c->d_best_key, sizeof(key), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (best_index) *best_index = idx[0];
+    if (best_f0) *best_f0 = key[0];
+    if (best_maxviol) *best_maxviol = key[1];
+    if (best_x && idx[0] >= 0) {
+        int64_t r = idx[0];
+        const double *src = c->X + (r >> 4) * c->n16 * 16 + (r & 15);
+        HIPCHK(c, hipMemcpy2DAsync(best_x, sizeof(double), src, 16 * sizeof(double), sizeof(double), (size_t)c->n,
+                                   hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int qcqpmi_last_kernel_ms(qcqpmi_ctx *c, int which, double *ms) {
+    if (!c || which < 0 || which > 3 || !ms) return QCQPMI_EINVAL;
+    if (!c->timers[which].valid) return fail(c, QCQPMI_ESTATE, "kernel %d has not been launched", which);
+    HIPCHK(c, hipEventSynchronize(c->timers[which].end));
+    float f = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&f, c->timers[which].beg, c->timers[which].end));
+    *ms = (double)f;
+    return 0;
+}
+
+int qcqpmi_sync(qcqpmi_ctx *c) {
+    if (!c) return QCQPMI_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- RCCL
+
+#define NCCLCHK(c, expr)                                                                        \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return fail(c, QCQPMI_ECOMM, "%s failed: %s", #expr,                                \
+                        rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "rccl error");    \
+    } while (0)
+
+int qcqpmi_comm_unique_id(uint8_t id_out[128]) {
+    if (!rccl()) return fail(nullptr, QCQPMI_ECOMM, "librccl.so could not be loaded");
+    ncclUniqueId id;
+    if (rccl()->GetUniqueId(&id) != ncclSuccess) return fail(nullptr, QCQPMI_ECOMM, "ncclGetUniqueId failed");
+    memcpy(id_out, id.internal, 128);
+    return 0;
+}
+
+int qcqpmi_comm_init(qcqpmi_ctx *c, int rank, int world, const uint8_t id_in[128]) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return QCQPMI_EINVAL;
+    if (!rccl()) return fail(c, QCQPMI_ECOMM, "librccl.so could not be loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(id.internal, id_in, 128);
+    NCCLCHK(c, rccl()->CommInitRank(&c->comm, world, id, rank));
+    c->rank = rank; c->world = world;
+    if (!c->d_comm) {
+        int rc = dev_alloc(c, &c->d_comm, (size_t)4 * world + 4 + (size_t)c->n);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int qcqpmi_comm_barrier(qcqpmi_ctx *c) {
+    double v = 0.0;
+    return qcqpmi_comm_allreduce(c, &v, 1, 0);
+}
+
+int qcqpmi_comm_allreduce(qcqpmi_ctx *c, double *values, int64_t count, int op) {
+    if (!c || !values || count < 1 || count > 4 || op < 0 || op > 1) return QCQPMI_EINVAL;
+    if (!c->comm) return fail(c, QCQPMI_ESTATE, "comm_init has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_comm, values, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, rccl()->AllReduce(c->d_comm, c->d_comm, (size_t)count, ncclDouble, op == 0 ? ncclMax : ncclSum,
+                                 c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(values, c->d_comm, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int qcqpmi_comm_select_best(qcqpmi_ctx *c, double tol, int64_t index_offset, int64_t *best_global_index,
+                            double *best_f0, double *best_maxviol, double *best_x) {
+    if (!c) return QCQPMI_EINVAL;
+    if (!c->comm) return fail(c, QCQPMI_ESTATE, "comm_init has not been called");
+    int64_t li = -1;
+    double lf = 0.0, lv = 0.0;
+    int rc = qcqpmi_select_best(c, tol, &li, &lf, &lv, nullptr);
+    if (rc) return rc;
+    // key record: (bucket, f0, maxviol, global index) as 4 doubles (indices < 2^53 are exact)
+    double rec[4] = {std::floor(lv / tol), lf, lv, (double)(index_offset + li)};
+    if (!(lv == lv) || !(lf == lf) || li < 0) rec[0] = 9.0e18;
+    const int W = c->world;
+    double *d_send = c->d_comm, *d_recv = c->d_comm + 4, *d_x = c->d_comm + 4 + 4 * (size_t)W;
+    HIPCHK(c, hipMemcpyAsync(d_send, rec, sizeof(rec), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, rccl()->AllGather(d_send, d_recv, 4, ncclDouble, c->comm, c->stream));
+    std::vector<double> all((size_t)4 * W);
+    HIPCHK(c, hipMemcpyAsync(all.data(), d_recv, all.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int win = 0;
+    for (int w = 1; w < W; w++) {
+        const double *a = &all[(size_t)4 * w], *b = &all[(size_t)4 * win];
+        if (a[0] < b[0] || (a[0] == b[0] && (a[1] < b[1] || (a[1] == b[1] && a[3] < b[3])))) win = w;
+    }
+    if (c->rank == win && li >= 0) {
+        const double *src = c->X + (li >> 4) * c->n16 * 16 + (li & 15);
+        HIPCHK(c, hipMemcpy2DAsync(d_x, sizeof(double), src, 16 * sizeof(double), sizeof(double), (size_t)c->n,
+                                   hipMemcpyDeviceToDevice, c->stream));
+    }
+    NCCLCHK(c, rccl()->Broadcast(d_x, d_x, (size_t)c->n, ncclDouble, win, c->comm, c->stream));
+    if (best_x) HIPCHK(c, hipMemcpyAsync(best_x, d_x, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (best_global_index) *best_global_index = (int64_t)all[(size_t)4 * win + 3];
+    if (best_f0) *best_f0 = all[(size_t)4 * win + 1];
+    if (best_maxviol) *best_maxviol = all[(size_t)4 * win + 2];
+    return 0;
+}
+
+}  // extern "C"

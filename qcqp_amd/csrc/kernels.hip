@@ -1,0 +1,485 @@
+// Hand-written gfx950 kernels of the Suggest-and-Improve engine.  fp64 throughout.
+//
+//   pack_A            P0 (row-major) -> MFMA A-fragment order
+//   to_tiles/from_tiles  host column-per-candidate layout <-> tile-major population
+//   randn_tiles       RANDOM suggest, batched (qcqp.py:381-382)
+//   affine_tiles      X = mu 1^T + F Xi   (SDR sampling, qcqp.py:396; F = factor of Sigma)
+//   eval_kernel       f0(x), max violation for a tile of 16 candidates (utilities.py:49-62,133-134)
+//   cd_phase1_sep     coordinate descent phase 1, separable constraints (qcqp.py:101-148)
+//   cd_phase2_kernel  coordinate descent phase 2 as blocked Gauss-Seidel on v_mfma_f64_16x16x4_f64
+//                     (qcqp.py:152-178)
+//   select_best       lexicographic (violation bucket, objective) argmin (utilities.py:135-146)
+//
+// Work decomposition: one workgroup owns one TILE of 16 candidates (see kernels.h); the 16x16
+// fp64 MFMA tile is (16 coordinates of a block) x (16 candidates).
+#include "kernels.h"
+#include "onevar.h"
+
+namespace qcqpmi {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ----------------------------------------------------------------------------- layout kernels
+
+__global__ void pack_A_kernel(const double *__restrict__ P, double *__restrict__ Apack,
+                              int64_t n16, int64_t KS) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = n16 * n16;
+    if (idx >= total) return;
+    int l = (int)(idx & 63);
+    int64_t t = idx >> 6;
+    int64_t kk = t % KS, b = t / KS;
+    Apack[idx] = P[(16 * b + (l & 15)) * n16 + 4 * kk + (l >> 4)];
+}
+
+// host layout: X[r*n + j]; tile layout: Xt[(r/16) * n16*16 + j*16 + (r%16)]
+__global__ void to_tiles_kernel(const double *__restrict__ X, double *__restrict__ Xt, int64_t n,
+                                int64_t n16, int64_t R, int64_t Rpad) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Rpad * n16) return;
+    int64_t tile = idx / (n16 * 16), rem = idx % (n16 * 16);
+    int64_t j = rem >> 4, r = tile * 16 + (rem & 15);
+    Xt[idx] = (r < R && j < n) ? X[r * n + j] : 0.0;
+}
+
+__global__ void from_tiles_kernel(const double *__restrict__ Xt, double *__restrict__ X,
+                                  int64_t n, int64_t n16, int64_t R) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * n) return;
+    int64_t r = idx / n, j = idx % n;
+    X[idx] = Xt[(r >> 4) * n16 * 16 + j * 16 + (r & 15)];
+}
+
+__global__ void randn_tiles_kernel(double *__restrict__ Xt, int64_t n, int64_t n16, int64_t R,
+                                   int64_t Rpad, uint64_t seed, uint64_t first_index) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Rpad * n16) return;
+    int64_t tile = idx / (n16 * 16), rem = idx % (n16 * 16);
+    int64_t j = rem >> 4, r = tile * 16 + (rem & 15);
+    Xt[idx] = (r < R && j < n) ? keyed_normal(seed, first_index + (uint64_t)r, (uint64_t)j) : 0.0;
+}
+
+// ------------------------------------------------------------------------ MFMA building block
+
+// acc(16 rows of block b) x (16 candidates) += Apack[b][kk0..kk1) * Xt rows.  XT may point to LDS
+// or global memory; rows are 16 doubles.
+template <typename XPtr>
+__device__ inline v4d block_rows_times_X(const double *__restrict__ Ab, XPtr Xs, int kk0, int kk1,
+                                         int lane, v4d acc) {
+    const int xoff = (lane >> 4) * 16 + (lane & 15);
+    int kk = kk0;
+    for (; kk + 8 <= kk1; kk += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            a[u] = Ab[(int64_t)(kk + u) * 64 + lane];
+            b[u] = Xs[(kk + u) * 64 + xoff];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; kk < kk1; kk++) {
+        double a = Ab[(int64_t)kk * 64 + lane];
+        double b = Xs[kk * 64 + xoff];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// X = mu 1^T + F * Xi   with F packed like P0 (Apack layout) and Xi tile-major.
+// One workgroup per tile; wave w computes row blocks b = w, w+4, ...
+__global__ __launch_bounds__(256) void affine_tiles_kernel(const double *__restrict__ Fpack,
+                                                           const double *__restrict__ mu,
+                                                           const double *__restrict__ Xi,
+                                                           double *__restrict__ Xt, int64_t n,
+                                                           int64_t n16, int64_t NB, int64_t KS) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *Xs = Xi + (int64_t)blockIdx.x * n16 * 16;
+    double *Xo = Xt + (int64_t)blockIdx.x * n16 * 16;
+    for (int64_t b = wave; b < NB; b += 4) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        acc = block_rows_times_X(Fpack + b * KS * 64, Xs, 0, (int)KS, lane, acc);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            int64_t i = 16 * b + (lane >> 4) + 4 * v;
+            Xo[i * 16 + (lane & 15)] = (i < n) ? mu[i] + acc[v] : 0.0;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------- evaluation
+
+__device__ inline double viol_of(double f, int relop) {
+    if (relop == RELOP_EQ) return fabs(f);
+    return f > 0.0 ? f : 0.0;
+}
+
+// One workgroup (4 waves) per tile of 16 candidates.
+//   objective: y = P0 x by MFMA (wave w owns row blocks w, w+4, ...), f0 = sum_i x_i (y_i + q_i) + r
+//   constraints: separable -> element-wise; general -> COO quadratic forms
+__global__ __launch_bounds__(256) void eval_kernel(EvalArgs a) {
+    __shared__ double red[256];
+    __shared__ double redv[256];
+    const DevProblem &P = a.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tile = blockIdx.x;
+    const double *Xs = a.X + tile * P.n16 * 16;
+    const int r = lane & 15;
+
+    double facc = 0.0;
+    for (int64_t b = wave; b < P.NB; b += 4) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        acc = block_rows_times_X(P.Apack + b * P.KS * 64, Xs, 0, (int)P.KS, lane, acc);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            int64_t i = 16 * b + (lane >> 4) + 4 * v;
+            facc += Xs[i * 16 + r] * (acc[v] + P.q0[i]);
+        }
+    }
+    // deterministic reduction over the 16 (wave, lane-group) partials of each candidate
+    red[tid] = facc;
+    __syncthreads();
+    if (tid < 16) {
+        double s = 0.0;
+        for (int g = 0; g < 16; g++) s += red[g * 16 + tid];
+        int64_t gr = tile * 16 + tid;
+        double f = s + P.r0;
+        a.f0[gr] = f;
+        if (a.F) a.F[gr] = f;
+    }
+    __syncthreads();
+
+    // constraints
+    double vmax = -QM_INF;
+    const int c = tid >> 4;  // 16 slots x 16 candidates
+    const int64_t gr = tile * 16 + (tid & 15);
+    if (P.sep) {
+        for (int64_t i = c; i < P.n; i += 16) {
+            double xi = Xs[i * 16 + (tid & 15)];
+            for (int e = P.cptr[i]; e < P.cptr[i + 1]; e++) {
+                double f = (P.cp[e] * xi + P.cq[e]) * xi + P.cr[e];
+                double v = viol_of(f, P.crel[e]);
+                vmax = v > vmax ? v : vmax;
+                if (a.F) a.F[(int64_t)P.cidx[e] * a.Rpad + gr] = f;
+            }
+        }
+    } else {
+        for (int64_t k = c; k < P.m; k += 16) {
+            double s = 0.0;
+            for (int64_t e = P.gptr[k]; e < P.gptr[k + 1]; e++)
+                s += P.gv[e] * Xs[(int64_t)P.gi[e] * 16 + (tid & 15)] *
+                     Xs[(int64_t)P.gj[e] * 16 + (tid & 15)];
+            const double *qk = P.gq + k * P.n16;
+            double l = 0.0;
+            for (int64_t j = 0; j < P.n; j++) l += qk[j] * Xs[j * 16 + (tid & 15)];
+            double f = s + l + P.gr[k];
+            double v = viol_of(f, P.grel[k]);
+            vmax = v > vmax ? v : vmax;
+            if (a.F) a.F[(k + 1) * a.Rpad + gr] = f;
+        }
+    }
+    redv[tid] = vmax;
+    __syncthreads();
+    if (tid < 16) {
+        double v = -QM_INF;
+        for (int g = 0; g < 16; g++) { double w = redv[g * 16 + tid]; v = w > v ? w : v; }
+        a.maxviol[tile * 16 + tid] = v;
+    }
+}
+
+// -------------------------------------------------------------------- coordinate descent phase 1
+
+// Separable constraints: a coordinate's local violation and its update depend on x_i alone
+// (objective is identically zero in phase 1, qcqp.py:114), so a sweep is element-wise; the
+// sweep loop, the per-restart max-violation reduction and the termination tests stay in-kernel.
+template <int MAXC>
+__global__ __launch_bounds__(256) void cd_phase1_sep_kernel(CdArgs a) {
+    __shared__ double vred[256];
+    __shared__ int ured[256];
+    __shared__ double viol_last[16];
+    __shared__ int fin[16];
+    __shared__ int nlive;
+    const DevProblem &P = a.P;
+    const int tid = threadIdx.x;
+    const int r = tid & 15, slot = tid >> 4;
+    const int64_t tile = blockIdx.x;
+    double *Xs = a.X + tile * P.n16 * 16;
+    const int64_t gr = tile * 16 + r;
+    const bool live = gr < a.R;
+    if (tid < 16) { viol_last[tid] = QM_INF; fin[tid] = (tile * 16 + tid < a.R) ? 0 : 1; }
+    int64_t my_visits = 0, my_acc = 0;
+    int my_status = 0;
+    int64_t sweeps_done = 0;
+    __syncthreads();
+    for (int64_t t = 0; t < a.num_iters; t++) {
+        // loop-top test of the reference (qcqp.py:111) is folded into fin[]
+        if (tid == 0) { int c = 0; for (int k = 0; k < 16; k++) c += fin[k] ? 0 : 1; nlive = c; }
+        __syncthreads();
+        if (nlive == 0) break;
+        const bool run = live && !fin[r];
+        double vmax = -QM_INF;
+        int upd = 0;
+        if (run) {
+            if (slot == 0) sweeps_done++;
+            for (int64_t i = slot; i < P.n; i += 16) {
+                const int e0 = P.cptr[i], mf = P.cptr[i + 1] - e0;
+                double xi = Xs[i * 16 + r];
+                if (mf == 0) { my_status = -3; continue; }  // python: max([]) -> ValueError
+                double cp[MAXC], cq[MAXC], cr[MAXC];
+                int crel[MAXC];
+#pragma unroll
+                for (int k = 0; k < MAXC; k++) {
+                    bool ok = k < mf;
+                    cp[k] = ok ? P.cp[e0 + k] : 0.0; cq[k] = ok ? P.cq[e0 + k] : 0.0;
+                    cr[k] = ok ? P.cr[e0 + k] : 0.0; crel[k] = ok ? P.crel[e0 + k] : RELOP_LE;
+                }
+                double viol = -QM_INF;
+#pragma unroll
+                for (int k = 0; k < MAXC; k++)
+                    if (k < mf) {
+                        double v = viol_of(xi * (cp[k] * xi + cq[k]) + cr[k], crel[k]);
+                        viol = v > viol ? v : viol;
+                    }
+                double new_xi = xi, new_viol = viol;
+                double ss = -a.tol, es = viol - a.viol_tol;
+                uint32_t it = 0;
+                my_visits++;
+                while (es - ss > a.tol) {
+                    double s = (ss + es) / 2.0;
+                    FeasSet<MAXC> C;
+                    feasible_set<MAXC>(cp, cq, cr, crel, mf, s, C);
+                    DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t, it++};
+                    double xn;
+                    int got = onevar_minimise<MAXC>(0.0, 0.0, 0.0, C, dk, &xn);
+                    if (got < 0) { my_status = got; break; }
+                    if (!got) ss = s;
+                    else { new_xi = xn; new_viol = s; es = s; }
+                }
+                if (new_viol < viol) { xi = new_xi; Xs[i * 16 + r] = xi; upd = 1; my_acc++; }
+                // violation of the constraints on x_i after the update (feeds qcqp.py:142)
+#pragma unroll
+                for (int k = 0; k < MAXC; k++)
+                    if (k < mf) {
+                        double v = viol_of((cp[k] * xi + cq[k]) * xi + cr[k], crel[k]);
+                        vmax = v > vmax ? v : vmax;
+                    }
+            }
+        }
+        vred[tid] = vmax; ured[tid] = upd;
+        __syncthreads();
+        if (tid < 16 && !fin[tid]) {
+            double v = -QM_INF;
+            int u = 0;
+            for (int g = 0; g < 16; g++) { double w = vred[g * 16 + tid]; v = w > v ? w : v; u |= ured[g * 16 + tid]; }
+            viol_last[tid] = v;
+            // done when feasible enough (qcqp.py:111); a sweep without any update is a fixed
+            // point of the (deterministic-in-feasibility) map, so later sweeps cannot change x.
+            if (v < a.viol_tol || !u) fin[tid] = 1;
+        }
+        __syncthreads();
+    }
+    // per-restart outputs
+    vred[tid] = (double)my_visits; ured[tid] = (int)my_acc;
+    __shared__ int sred[256];
+    sred[tid] = my_status;
+    __syncthreads();
+    if (tid < 16 && tile * 16 + tid < a.R) {
+        int64_t vis = 0, acc = 0;
+        int st = 0;
+        for (int g = 0; g < 16; g++) { vis += (int64_t)vred[g * 16 + tid]; acc += ured[g * 16 + tid]; if (sred[g * 16 + tid]) st = sred[g * 16 + tid]; }
+        int64_t g = tile * 16 + tid;
+        a.visits[g] = vis; a.accepted[g] = acc; a.status[g] = st;
+        a.flag[g] = (viol_last[tid] < a.viol_tol) ? 1 : 0;
+    }
+    if (slot == 0 && live) a.sweeps[gr] = sweeps_done;
+}
+
+// -------------------------------------------------------------------- coordinate descent phase 2
+
+// Blocked Gauss-Seidel.  For a block of 16 coordinates I_b the products G = P0[I_b,:] X are one
+// 16 x n16 by n16 x 16 fp64 MFMA contraction (K split over the 4 waves); the 16 coordinates are
+// then visited in order by lanes 0..15 of wave 0 (lane = restart), each new x_i being folded into
+// the remaining rows of the block through the 16x16 diagonal block of P0.  The one-variable
+// feasible sets of separable constraints do not depend on the other coordinates, so they are
+// computed for the whole block by all 256 threads before the sequential part.
+template <int MAXC, bool XLDS>
+__global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
+    extern __shared__ double smem[];
+    const DevProblem &P = a.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tile = blockIdx.x;
+    double *Xg = a.X + tile * P.n16 * 16;
+    // dynamic LDS carve-up
+    double *sp = smem;
+    double *Xl = sp; if (XLDS) sp += P.n16 * 16;
+    double *part = sp; sp += 4 * 256;
+    double *Dblk = sp; sp += 256;
+    double *ivlo = sp; sp += (MAXC + 1) * 256;
+    double *ivhi = sp; sp += (MAXC + 1) * 256;
+    double *slk = sp; sp += 16;
+    int *ivn = (int *)sp; sp += 128;
+    int *done = (int *)sp;
+
+    double *Xs = XLDS ? Xl : Xg;
+    if (XLDS) {
+        for (int64_t idx = tid; idx < P.n16 * 16; idx += 256) Xl[idx] = Xg[idx];
+    }
+    if (tid < 16) {
+        int64_t g = tile * 16 + tid;
+        slk[tid] = (g < a.R) ? a.slack[g] : 0.0;
+    }
+    if (tid == 0) *done = 0;
+    // per-restart chain state (wave 0, lanes 0..15)
+    const int64_t gr = tile * 16 + (lane & 15);
+    double fcur = 0.0;
+    int64_t upd_counter = 0, visits = 0, accepted = 0, sweeps = 0;
+    bool conv = true;
+    int status = 0;
+    if (wave == 0 && lane < 16 && gr < a.R) {
+        conv = a.flag[gr] ? false : true;
+        fcur = a.f0cur[gr];
+    }
+    __syncthreads();
+
+    const int kper = (int)(P.KS / 4);  // KS = n16/4 is a multiple of 4
+    bool all_done = false;
+    for (int64_t t = 0; t < a.num_iters && !all_done; t++) {
+        if (wave == 0 && lane < 16 && !conv) sweeps++;
+        for (int64_t b = 0; b < P.NB; b++) {
+            // ---- G partials on the matrix cores
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            acc = block_rows_times_X(P.Apack + b * P.KS * 64, Xs, wave * kper, (wave + 1) * kper,
+                                     lane, acc);
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                part[wave * 256 + ((lane >> 4) + 4 * v) * 16 + (lane & 15)] = acc[v];
+            // ---- per (coordinate c, restart r): feasible set at the restart's slack
+            {
+                const int c = tid >> 4, r = tid & 15;
+                const int64_t i = 16 * b + c;
+                Dblk[tid] = P.P0[i * P.n16 + 16 * b + r];
+                FeasSet<MAXC> C;
+                C.n = 0;
+                if (i < P.n) {
+                    const int e0 = P.cptr[i], mf = P.cptr[i + 1] - e0;
+                    double cp[MAXC], cq[MAXC], cr[MAXC];
+                    int crel[MAXC];
+#pragma unroll
+                    for (int k = 0; k < MAXC; k++) {
+                        bool ok = k < mf;
+                        cp[k] = ok ? P.cp[e0 + k] : 0.0; cq[k] = ok ? P.cq[e0 + k] : 0.0;
+                        cr[k] = ok ? P.cr[e0 + k] : 0.0; crel[k] = ok ? P.crel[e0 + k] : RELOP_LE;
+                    }
+                    feasible_set<MAXC>(cp, cq, cr, crel, mf, slk[r], C);
+                }
+                ivn[tid] = C.n;
+#pragma unroll
+                for (int j = 0; j <= MAXC; j++) { ivlo[j * 256 + tid] = C.lo[j]; ivhi[j * 256 + tid] = C.hi[j]; }
+            }
+            __syncthreads();
+            // ---- sequential part: lane = restart
+            if (wave == 0) {
+                if (lane < 16) {
+                    const int r = lane;
+                    double xb[16], gb[16];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) {
+                        xb[c] = Xs[(16 * b + c) * 16 + r];
+                        gb[c] = part[c * 16 + r] + part[256 + c * 16 + r] + part[512 + c * 16 + r] +
+                                part[768 + c * 16 + r];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 16; c++) {
+                        const int64_t i = 16 * b + c;
+                        if (i < P.n && !conv) {
+                            const double t2 = Dblk[c * 16 + c];
+                            const double xi = xb[c];
+                            const double t1 = 2.0 * (gb[c] - t2 * xi) + P.q0[i];
+                            const double t0 = fcur - xi * (t2 * xi + t1);
+                            FeasSet<MAXC> C;
+                            C.n = ivn[c * 16 + r];
+#pragma unroll
+                            for (int j = 0; j <= MAXC; j++) { C.lo[j] = ivlo[j * 256 + c * 16 + r]; C.hi[j] = ivhi[j * 256 + c * 16 + r]; }
+                            DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i,
+                                       (uint32_t)t | 0x80000000u, 0u};
+                            double xn = xi;
+                            int got = onevar_minimise<MAXC>(t2, t1, t0, C, dk, &xn);
+                            visits++;
+                            if (got < 0) { status = got; conv = true; }
+                            else if (got && fabs(xn - xi) > a.tol) {
+                                const double delta = xn - xi;
+                                xb[c] = xn;
+                                fcur = t0 + xn * (t2 * xn + t1);
+                                upd_counter = 0;
+                                accepted++;
+#pragma unroll
+                                for (int c2 = c + 1; c2 < 16; c2++) gb[c2] += Dblk[c2 * 16 + c] * delta;
+                            } else {
+                                upd_counter++;
+                                if (upd_counter == P.n) conv = true;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 16; c++) Xs[(16 * b + c) * 16 + r] = xb[c];
+                }
+                // all restarts of the tile converged?
+                unsigned long long live = __ballot(lane < 16 && !conv);
+                if (lane == 0) *done = (live == 0ull) ? 1 : 0;
+            }
+            __syncthreads();
+            if (*done) { all_done = true; break; }
+        }
+    }
+    __syncthreads();
+    if (XLDS) {
+        for (int64_t idx = tid; idx < P.n16 * 16; idx += 256) Xg[idx] = Xl[idx];
+    }
+    if (wave == 0 && lane < 16 && gr < a.R) {
+        a.visits[gr] = visits; a.accepted[gr] = accepted; a.sweeps[gr] = sweeps;
+        a.status[gr] = status;
+    }
+}
+
+// ------------------------------------------------------------------------------- best selection
+
+// key = (int(maxviol / tol), f0, index): lexicographic minimum, ties -> lowest index.
+__global__ __launch_bounds__(1024) void select_best_kernel(const double *__restrict__ f0,
+                                                           const double *__restrict__ maxviol,
+                                                           int64_t R, double tol,
+                                                           int64_t *__restrict__ out_idx,
+                                                           double *__restrict__ out_key) {
+    __shared__ long long sb[1024];
+    __shared__ double sf[1024];
+    __shared__ long long si[1024];
+    long long bb = 0x7fffffffffffffffll, bi = -1;
+    double bf = QM_INF;
+    for (int64_t r = threadIdx.x; r < R; r += 1024) {
+        double v = maxviol[r], f = f0[r];
+        long long bucket = (v == v && f == f) ? (long long)(v / tol) : 0x7ffffffffffffffell;
+        bool better = bucket < bb || (bucket == bb && f < bf);
+        if (bi < 0 || better) { bb = bucket; bf = f; bi = r; }
+    }
+    sb[threadIdx.x] = bb; sf[threadIdx.x] = bf; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            int o = threadIdx.x + s;
+            bool take = si[o] >= 0 &&
+                        (si[threadIdx.x] < 0 || sb[o] < sb[threadIdx.x] ||
+                         (sb[o] == sb[threadIdx.x] &&
+                          (sf[o] < sf[threadIdx.x] || (sf[o] == sf[threadIdx.x] && si[o] < si[threadIdx.x]))));
+            if (take) { sb[threadIdx.x] = sb[o]; sf[threadIdx.x] = sf[o]; si[threadIdx.x] = si[o]; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_idx[0] = si[0];
+        out_idx[1] = sb[0];
+        out_key[0] = sf[0];
+        out_key[1] = si[0] >= 0 ? maxviol[si[0]] : QM_NAN;
+    }
+}
+
+}  // namespace qcqpmi

@@ -1,0 +1,189 @@
+"""Engine: one QCQPForm resident on one MI355X, driven through the C ABI (include/qcqp_mi.h)."""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _ffi
+from .form import RELOP_CODE
+
+
+class EngineError(Exception):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(_ffi.c_dp) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(_ffi.c_ip) if a is not None else None
+
+
+def _bp(a):
+    return a.ctypes.data_as(_ffi.c_bp) if a is not None else None
+
+
+def device_count():
+    return _ffi.lib().qcqpmi_device_count()
+
+
+class Engine(object):
+    KERNEL_EVAL, KERNEL_CD1, KERNEL_CD2, KERNEL_SDR = 0, 1, 2, 3
+
+    def __init__(self, form, device=0):
+        self.L = _ffi.lib()
+        self.n, self.m = int(form.n), int(form.m)
+        h = C.c_void_p()
+        rc = self.L.qcqpmi_ctx_create(C.byref(h), self.n, self.m, int(device))
+        if rc:
+            raise EngineError(self.L.qcqpmi_last_error(None).decode())
+        self.h = h
+        for k, f in enumerate([form.f0] + list(form.fs)):
+            self._set_quad(k, f)
+        self._chk(self.L.qcqpmi_finalize(self.h))
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc):
+        if rc:
+            raise EngineError(self.L.qcqpmi_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.qcqpmi_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _set_quad(self, k, f):
+        q = np.ascontiguousarray(f.qarray, dtype=np.float64)
+        if sp.issparse(f.P):
+            P = sp.csr_matrix(f.P)
+            P.sum_duplicates()
+            P.sort_indices()
+            ptr = np.ascontiguousarray(P.indptr, dtype=np.int64)
+            idx = np.ascontiguousarray(P.indices, dtype=np.int64)
+            val = np.ascontiguousarray(P.data, dtype=np.float64)
+            rc = self.L.qcqpmi_set_quad(self.h, k, 1, _dp(val), _ip(idx), _ip(ptr), len(val), _dp(q),
+                                        float(f.r), RELOP_CODE[f.relop])
+        else:
+            P = np.ascontiguousarray(f.P, dtype=np.float64)
+            rc = self.L.qcqpmi_set_quad(self.h, k, 0, _dp(P), None, None, 0, _dp(q), float(f.r),
+                                        RELOP_CODE[f.relop])
+        self._chk(rc)
+
+    @property
+    def separable(self):
+        return bool(self.L.qcqpmi_is_separable(self.h))
+
+    # ---------------------------------------------------------------- population
+    @property
+    def pop_size(self):
+        return int(self.L.qcqpmi_pop_size(self.h))
+
+    def upload(self, X):
+        """X: (n, R) array, one candidate per column."""
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = X.reshape(-1, 1)
+        assert X.shape[0] == self.n
+        Xc = np.ascontiguousarray(X.T)
+        self._chk(self.L.qcqpmi_pop_upload(self.h, _dp(Xc), Xc.shape[0]))
+
+    def download(self, R=None):
+        R = self.pop_size if R is None else R
+        out = np.empty((R, self.n))
+        self._chk(self.L.qcqpmi_pop_download(self.h, _dp(out), R))
+        return np.ascontiguousarray(out.T)
+
+    def randn(self, R, seed=0, first_index=0):
+        self._chk(self.L.qcqpmi_pop_randn(self.h, int(R), int(seed), int(first_index)))
+
+    def sdr_sample(self, mu, F, S, seed=0, first_index=0, Xi=None):
+        mu = np.ascontiguousarray(mu, dtype=np.float64).ravel()
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        assert F.shape == (self.n, self.n) and mu.size == self.n
+        Xc = None
+        if Xi is not None:
+            Xi = np.asarray(Xi, dtype=np.float64)
+            assert Xi.shape == (self.n, S)
+            Xc = np.ascontiguousarray(Xi.T)
+        self._chk(self.L.qcqpmi_pop_sdr_sample(self.h, _dp(mu), _dp(F), int(S), int(seed),
+                                               int(first_index), _dp(Xc)))
+
+    # ---------------------------------------------------------------- evaluation
+    def eval(self, want_F=False):
+        R = self.pop_size
+        f0 = np.empty(R)
+        mv = np.empty(R)
+        F = np.empty((self.m + 1, R)) if want_F else None
+        self._chk(self.L.qcqpmi_pop_eval(self.h, _dp(f0), _dp(mv), _dp(F)))
+        return (f0, mv, F) if want_F else (f0, mv)
+
+    def eval_batch(self, X, want_F=False):
+        self.upload(X)
+        return self.eval(want_F)
+
+    # -------------------------------------------------------- coordinate descent
+    def cd_run(self, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=0, first_index=0):
+        R = self.pop_size
+        out = dict(sweeps1=np.zeros(R, dtype=np.int64), sweeps2=np.zeros(R, dtype=np.int64),
+                   visits2=np.zeros(R, dtype=np.int64), accepted2=np.zeros(R, dtype=np.int64),
+                   ran_phase2=np.zeros(R, dtype=np.uint8), f0=np.empty(R), maxviol=np.empty(R))
+        self._chk(self.L.qcqpmi_cd_run(self.h, int(bool(phase1)), int(num_iters), float(viol_tol),
+                                       float(tol), int(seed), int(first_index), _ip(out['sweeps1']),
+                                       _ip(out['sweeps2']), _ip(out['visits2']), _ip(out['accepted2']),
+                                       _bp(out['ran_phase2']), _dp(out['f0']), _dp(out['maxviol'])))
+        return out
+
+    # ------------------------------------------------------------------ selection
+    def select_best(self, tol=1e-4, want_x=True):
+        idx = np.zeros(1, dtype=np.int64)
+        f = np.zeros(1)
+        v = np.zeros(1)
+        x = np.empty(self.n) if want_x else None
+        self._chk(self.L.qcqpmi_select_best(self.h, float(tol), _ip(idx), _dp(f), _dp(v), _dp(x)))
+        return int(idx[0]), float(f[0]), float(v[0]), x
+
+    # --------------------------------------------------------------------- timing
+    def kernel_ms(self, which):
+        ms = np.zeros(1)
+        self._chk(self.L.qcqpmi_last_kernel_ms(self.h, int(which), _dp(ms)))
+        return float(ms[0])
+
+    def sync(self):
+        self._chk(self.L.qcqpmi_sync(self.h))
+
+    # ----------------------------------------------------------------------- comm
+    @staticmethod
+    def comm_unique_id():
+        L = _ffi.lib()
+        buf = np.zeros(128, dtype=np.uint8)
+        if L.qcqpmi_comm_unique_id(_bp(buf)):
+            raise EngineError(L.qcqpmi_last_error(None).decode())
+        return buf
+
+    def comm_init(self, rank, world, uid):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        self._chk(self.L.qcqpmi_comm_init(self.h, int(rank), int(world), _bp(uid)))
+
+    def comm_barrier(self):
+        self._chk(self.L.qcqpmi_comm_barrier(self.h))
+
+    def comm_allreduce(self, values, op='max'):
+        v = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)))
+        self._chk(self.L.qcqpmi_comm_allreduce(self.h, _dp(v), v.size, 0 if op == 'max' else 1))
+        return v
+
+    def comm_select_best(self, tol=1e-4, index_offset=0):
+        idx = np.zeros(1, dtype=np.int64)
+        f = np.zeros(1)
+        v = np.zeros(1)
+        x = np.empty(self.n)
+        self._chk(self.L.qcqpmi_comm_select_best(self.h, float(tol), int(index_offset), _ip(idx), _dp(f),
+                                                 _dp(v), _dp(x)))
+        return int(idx[0]), float(f[0]), float(v[0]), x

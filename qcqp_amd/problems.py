@@ -40,10 +40,13 @@ def boolean_least_squares(n, m_rows, seed=1, legacy_seed=False):
     return funcs, False, dict(A=A, b=b)
 
 
-def maxcut(n, p=0.5, seed=1):
-    """maximize 0.25 (sum(W) - x^T W x)  s.t. x_i^2 == 1   (minimise form returned)."""
+def maxcut(n, p=0.5, seed=1, weighted=False):
+    """maximize 0.25 (sum(W) - x^T W x)  s.t. x_i^2 == 1   (minimise form returned).
+    weighted=True draws edge weights from U(0.5, 1.5): no exact ties between cuts."""
     rs = np.random.RandomState(seed)
     U = np.triu((rs.uniform(size=(n, n)) < p).astype(float), 1)
+    if weighted:
+        U = U * np.triu(rs.uniform(0.5, 1.5, size=(n, n)), 1)
     W = U + U.T
     P0 = 0.25 * W
     r0 = -0.25 * float(W.sum())

@@ -1,0 +1,141 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle and the golden
+vectors captured from the reference.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import funcs_from_npz, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng_mod():
+    from qcqp_amd import engine
+    assert engine.device_count() >= 1, 'no HIP device visible'
+    return engine
+
+
+def make(eng_mod, funcs):
+    from qcqp_amd.form import QCQPForm
+    return eng_mod.Engine(QCQPForm.from_arrays(funcs))
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b)) / (1.0 + np.abs(np.asarray(b))))
+
+
+@pytest.mark.parametrize('name', ['bls10', 'bls32', 'maxcut12', 'dense16', 'beam10'])
+def test_eval_matches_golden(eng_mod, orc, name):
+    z = load_golden('g1_' + name)
+    e = make(eng_mod, funcs_from_npz(z))
+    f0, mv, F = e.eval_batch(z['X'], want_F=True)
+    assert rel(F, z['F']) < 1e-12          # tolerance: fp64, summation order differs from SciPy CSR
+    assert rel(mv, z['maxviol']) < 1e-12
+    assert rel(f0, z['F'][0]) < 1e-12
+
+
+def test_eval_large_vs_oracle(eng_mod, orc):
+    from qcqp_amd import problems
+    funcs, _, _ = problems.boolean_least_squares(200, 64, seed=5)
+    e = make(eng_mod, funcs)
+    prob = orc.Problem(funcs)
+    X = np.random.RandomState(0).randn(200, 37)
+    f0, mv = e.eval_batch(X)
+    g0, gv = prob.eval_batch(X)
+    assert rel(f0, g0) < 1e-12 and rel(mv, gv) < 1e-13
+
+
+@pytest.mark.parametrize('name', ['bls10', 'bls32', 'bls64', 'maxcut12'])
+def test_cd_phase2_matches_reference_golden(eng_mod, name):
+    """Phase 2 is deterministic: the device trajectory must land on the reference's point."""
+    z = load_golden('g6_cd_' + name)
+    e = make(eng_mod, funcs_from_npz(z))
+    e.upload(z['X0'])
+    out = e.cd_run(phase1=False)
+    X = e.download()
+    assert rel(X, z['p2_x']) < 1e-9
+    assert rel(out['f0'], z['p2_fv'][:, 0]) < 1e-9
+    assert rel(out['maxviol'], z['p2_fv'][:, 1]) < 1e-9
+
+
+@pytest.mark.parametrize('name,n,m_rows', [('bls', 96, 40), ('bls', 250, 100), ('maxcut', 130, 0)])
+def test_cd_full_driver_vs_oracle_keyed(eng_mod, orc, name, n, m_rows):
+    """Phase 1 draws from the keyed Philox stream: oracle (ORC_RNG_KEYED) and GPU consume the same
+    draws, so whole improve_coord_descent trajectories are comparable."""
+    from qcqp_amd import problems
+    funcs = (problems.boolean_least_squares(n, m_rows, seed=2)[0] if name == 'bls'
+             else problems.maxcut(n, 0.5, seed=3, weighted=True)[0])
+    e = make(eng_mod, funcs)
+    prob = orc.Problem(funcs)
+    R, seed, first = 21, 1234, 7
+    X0 = np.random.RandomState(1).randn(n, R)
+    e.upload(X0)
+    out = e.cd_run(phase1=True, num_iters=50, seed=seed, first_index=first)
+    X = e.download()
+    for r in range(R):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(first + r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=50, rng=rng)
+        assert rel(X[:, r], x) < 1e-9, r
+        assert out['sweeps1'][r] == s1[0]
+        assert out['visits2'][r] == s2[1] and out['accepted2'][r] == s2[2]
+        assert abs(out['f0'][r] - prob.eval(0, x)) <= 1e-9 * (1 + abs(out['f0'][r]))
+
+
+def test_randn_matches_oracle_stream(eng_mod, orc):
+    from qcqp_amd import problems
+    funcs, _, _ = problems.boolean_least_squares(33, 10, seed=1)
+    e = make(eng_mod, funcs)
+    e.randn(19, seed=99, first_index=1000)
+    X = e.download()
+    ref = orc.keyed_normal_matrix(99, 33, 19, first_index=1000)
+    assert np.max(np.abs(X - ref)) < 1e-13   # device libm vs glibc: last-ulp differences allowed
+    assert abs(X.mean()) < 0.2 and 0.8 < X.std() < 1.2
+
+
+def test_sdr_sample_affine(eng_mod, orc):
+    z = load_golden('g9_sdr_bls10')
+    funcs = funcs_from_npz(z)
+    e = make(eng_mod, funcs)
+    n = 10
+    mu, Sigma = orc.sdr_mu_sigma(z['X'], compat=False)
+    F = np.linalg.cholesky(Sigma)
+    Xi = np.random.RandomState(3).randn(n, 40)
+    e.sdr_sample(mu, F, 40, Xi=Xi)
+    X = e.download()
+    assert rel(X, mu[:, None] + F.dot(Xi)) < 1e-13
+    f0, mv = e.eval()
+    g0, gv = orc.Problem(funcs).eval_batch(X)
+    assert rel(f0, g0) < 1e-12 and rel(mv, gv) < 1e-12
+    # device normals: same stream as the oracle's keyed normals
+    e.sdr_sample(mu, F, 24, seed=5, first_index=3)
+    Xd = e.download()
+    Xi2 = orc.keyed_normal_matrix(5, n, 24, first_index=3)
+    assert rel(Xd, mu[:, None] + F.dot(Xi2)) < 1e-12
+
+
+def test_select_best_ordering(eng_mod, orc):
+    z = load_golden('g1_bls10')
+    funcs = funcs_from_npz(z)
+    e = make(eng_mod, funcs)
+    e.upload(z['X'])
+    idx, f, v, x = e.select_best(1e-4)
+    prob = orc.Problem(funcs)
+    best = 0
+    for s in range(1, z['X'].shape[1]):   # fold with QCQPForm.better, ties keep the earlier index
+        if prob.better(z['X'][:, s], z['X'][:, best]) == 1:
+            v1 = int(prob.max_violation(z['X'][:, s]) / 1e-4), prob.eval(0, z['X'][:, s])
+            v2 = int(prob.max_violation(z['X'][:, best]) / 1e-4), prob.eval(0, z['X'][:, best])
+            if v1 != v2:
+                best = s
+    assert idx == best
+    assert np.array_equal(x, z['X'][:, idx])
+
+
+def test_unsupported_structure_fails_loudly(eng_mod):
+    z = load_golden('g1_dense16')
+    e = make(eng_mod, funcs_from_npz(z))
+    assert not e.separable
+    e.upload(z['X'])
+    with pytest.raises(eng_mod.EngineError):
+        e.cd_run()
