@@ -115,6 +115,9 @@ int qcqpmi_select_best(qcqpmi_ctx *ctx, double tol, int64_t *best_index, double 
  * the most recent launch of that kernel in milliseconds. */
 int qcqpmi_last_kernel_ms(qcqpmi_ctx *ctx, int which, double *ms);
 int qcqpmi_sync(qcqpmi_ctx *ctx);
+/* debug: enable in-kernel cycle counters of the phase-2 kernel / read their sums over tiles
+ * (slots: 0 mfma, 1 feasible sets, 2 barrier, 3 sequential part, 4 barrier, 5 #blocks) */
+int qcqpmi_debug_profile(qcqpmi_ctx *ctx, int enable, int64_t *sums8);
 
 /* ---- multi-GPU: one process per GPU, restarts sharded by global index, ONE collective at the
  * end to pick the global best (RCCL over xGMI; librccl is loaded lazily). --------------- */

@@ -81,6 +81,8 @@ struct qcqpmi_ctx {
     bool finalized = false;
     bool sep = false;
     int maxc = 0;
+    int K = 0;
+    int objclass = 0;  // 1: every P0[i,i] > 0, 2: every P0[i,i] == 0, 0: mixed
     DevProblem dp{};
     std::vector<void *> prob_allocs;
     // population
@@ -102,6 +104,8 @@ struct qcqpmi_ctx {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     double *d_comm = nullptr;
+    long long *d_prof = nullptr;
+    bool profile = false;
 };
 
 namespace {
@@ -218,20 +222,41 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
         HIPCHK(c, hipGetLastError());
         return 0;
     }
-    size_t common = (size_t)(4 * 256 + 256 + 2 * (MAXC + 1) * 256 + 16 + 128 + 16) * sizeof(double);
+    // dynamic LDS: [X tile] + partial tiles + G + diagonal block + slack + feasible-set table
+    const bool use_cls = c->K <= 16;
+    const size_t slots = use_cls ? (size_t)c->K * 16 : 0;
+    size_t common = (size_t)(4 * 256 + 256 + 256 + 3 * 16 + 512) * sizeof(double) +              // part, G, Dblk, slk/q0b/rcpb, midb/thrb
+                    (size_t)(2 * (MAXC + 1) * 256 + 256) * sizeof(double) +                      // block table
+                    ((size_t)(2 * (MAXC + 1)) * slots + ((slots + 1) / 2) * 2) * sizeof(double) + // class table
+                    64;
     size_t with_x = common + (size_t)c->n16 * 16 * sizeof(double);
     used_lds = with_x <= 160 * 1024;
-    tic(c, 2);
-    if (used_lds) {
-        auto k = cd_phase2_kernel<MAXC, true>;
-        HIPCHK(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)with_x));
-        hipLaunchKernelGGL(k, grid, block, with_x, c->stream, a1);
-    } else {
-        auto k = cd_phase2_kernel<MAXC, false>;
-        HIPCHK(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)common));
-        hipLaunchKernelGGL(k, grid, block, common, c->stream, a1);
-    }
-    toc(c, 2);
+    const size_t lds = used_lds ? with_x : common;
+    const DevProblem &dp = c->dp;
+    const int fast = (MAXC == 1) ? c->objclass : 0;
+    const bool uni = use_cls && c->K == 1;
+#define QM_LAUNCH2(XL, CL, FA, UN)                                                                     \
+    do {                                                                                            \
+        auto k = cd_phase2_kernel<MAXC, XL, CL, FA, UN>;                                                \
+        HIPCHK(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        tic(c, 2);                                                                                  \
+        hipLaunchKernelGGL(k, grid, block, lds, c->stream, a1, dp.Apack, dp.P0, dp.q0, dp.rcp2d, dp.cls);      \
+        toc(c, 2);                                                                                  \
+    } while (0)
+#define QM_LAUNCH(XL, CL)                                                 \
+    do {                                                                  \
+        if (fast == 1 && uni && CL) QM_LAUNCH2(XL, CL, 1, CL);            \
+        else if (fast == 2 && uni && CL) QM_LAUNCH2(XL, CL, 2, CL);       \
+        else if (fast == 1) QM_LAUNCH2(XL, CL, 1, false);                 \
+        else if (fast == 2) QM_LAUNCH2(XL, CL, 2, false);                 \
+        else QM_LAUNCH2(XL, CL, 0, false);                                \
+    } while (0)
+    if (used_lds && use_cls) QM_LAUNCH(true, true);
+    else if (used_lds) QM_LAUNCH(true, false);
+    else if (use_cls) QM_LAUNCH(false, true);
+    else QM_LAUNCH(false, false);
+#undef QM_LAUNCH
+#undef QM_LAUNCH2
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -349,6 +374,21 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
         int rc;
         if ((rc = prob_upload(c, &dp.P0, P))) return rc;
         if ((rc = prob_upload(c, &dp.q0, q))) return rc;
+        std::vector<double> rcp2d((size_t)n16, 0.0);
+        for (int64_t i = 0; i < n; i++) {
+            const double d = P[(size_t)i * n16 + i];
+            if (d != 0.0) rcp2d[i] = 1.0 / (2.0 * d);
+        }
+        if ((rc = prob_upload(c, &dp.rcp2d, rcp2d))) return rc;
+        {
+            bool allpos = true, allzero = true;
+            for (int64_t i = 0; i < n; i++) {
+                const double d = P[(size_t)i * n16 + i];
+                allpos = allpos && d > 0.0;
+                allzero = allzero && d == 0.0;
+            }
+            c->objclass = allpos ? 1 : (allzero ? 2 : 0);
+        }
         double *ap = nullptr;
         if ((rc = dev_alloc(c, &ap, (size_t)n16 * n16, false))) return rc;
         c->prob_allocs.push_back(ap);
@@ -394,6 +434,34 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
             cp[e] = p; cq[e] = h.q[i]; cr[e] = h.r; crel[e] = h.relop; cidx[e] = (int)k + 1;
         }
         c->maxc = maxc; dp.maxc = maxc;
+        // constraint classes: coordinates whose (p, q, r, relop) lists are bit-identical
+        {
+            std::vector<int> cls((size_t)n16, 0), krep;
+            for (int64_t i = 0; i < n16; i++) {
+                int found = -1;
+                const int len = cptr[i + 1] - cptr[i];
+                for (size_t k = 0; k < krep.size() && found < 0; k++) {
+                    const int j = krep[k];
+                    if (cptr[j + 1] - cptr[j] != len) continue;
+                    bool same = true;
+                    for (int e = 0; e < len && same; e++) {
+                        const int a = cptr[i] + e, b = cptr[j] + e;
+                        same = memcmp(&cp[a], &cp[b], 8) == 0 && memcmp(&cq[a], &cq[b], 8) == 0 &&
+                               memcmp(&cr[a], &cr[b], 8) == 0 && crel[a] == crel[b];
+                    }
+                    if (same) found = (int)k;
+                }
+                if (found < 0) {
+                    krep.push_back((int)i);
+                    found = (int)krep.size() - 1;
+                }
+                cls[i] = found;
+            }
+            dp.K = (int)krep.size();
+            c->K = dp.K;
+            if ((rc = prob_upload(c, &dp.krep, krep))) return rc;
+            if ((rc = prob_upload(c, &dp.cls, cls))) return rc;
+        }
         if ((rc = prob_upload(c, &dp.cptr, cptr))) return rc;
         if ((rc = prob_upload(c, &dp.cp, cp))) return rc;
         if ((rc = prob_upload(c, &dp.cq, cq))) return rc;
@@ -560,6 +628,12 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
     a.num_iters = num_iters; a.viol_tol = viol_tol; a.tol = tol; a.seed = seed; a.first_index = first_index;
     a.visits = c->d_visits; a.accepted = c->d_acc; a.sweeps = c->d_sweeps; a.status = c->d_status;
     a.flag = c->d_flag;
+    a.prof = nullptr;
+    if (c->profile) {
+        if (c->d_prof) { (void)hipFree(c->d_prof); c->d_prof = nullptr; }
+        if ((rc = dev_alloc(c, &c->d_prof, (size_t)(c->Rpad / 16) * 8))) return rc;
+        a.prof = c->d_prof;
+    }
     bool used_lds = false;
     std::vector<int> st((size_t)c->R);
     HIPCHK(c, hipMemsetAsync(c->d_sweeps1, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
@@ -643,6 +717,18 @@ int qcqpmi_last_kernel_ms(qcqpmi_ctx *c, int which, double *ms) {
     float f = 0.f;
     HIPCHK(c, hipEventElapsedTime(&f, c->timers[which].beg, c->timers[which].end));
     *ms = (double)f;
+    return 0;
+}
+
+int qcqpmi_debug_profile(qcqpmi_ctx *c, int enable, int64_t *sums8) {
+    if (!c) return QCQPMI_EINVAL;
+    c->profile = enable != 0;
+    if (sums8 && c->d_prof && c->Rpad > 0) {
+        std::vector<long long> h((size_t)(c->Rpad / 16) * 8);
+        HIPCHK(c, hipMemcpy(h.data(), c->d_prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; k++) sums8[k] = 0;
+        for (size_t t = 0; t < h.size(); t++) sums8[t & 7] += h[t];
+    }
     return 0;
 }
 

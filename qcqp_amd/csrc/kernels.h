@@ -28,6 +28,11 @@ struct DevProblem {
     const double *cp, *cq, *cr;  // per entry: p = P_k[i,i], q = q_k[i], r = r_k
     const int *crel;      // per entry relop
     const int *cidx;      // per entry: constraint index k (1-based)
+    // constraint classes: coordinates with bit-identical constraint lists share a class
+    int K;                // number of classes
+    const int *krep;      // [K] a representative coordinate of each class
+    const int *cls;       // [n16] class of each coordinate
+    const double *rcp2d;  // [n16] 1 / (2 P0[i,i]) where P0[i,i] > 0, else 0
     // general constraints (COO of P_k, dense q_k) -- used by eval when !sep
     const int64_t *gptr;  // [m + 1] entry ranges
     const int *gi, *gj;   // entry row / col
@@ -61,6 +66,7 @@ struct CdArgs {
     int64_t *sweeps;        // [Rpad] sweeps started
     int *status;            // [Rpad] 0 ok, <0 where the reference would raise
     uint8_t *flag;          // [Rpad] in: run this restart (phase 2) / out: phase-1 feasible
+    long long *prof;        // optional [tiles][8] cycle counters of wave 0 (debug), or nullptr
 };
 
 }  // namespace qcqpmi

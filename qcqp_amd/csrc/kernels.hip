@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void cd_phase1_sep_kernel(CdArgs a) {
 // the remaining rows of the block through the 16x16 diagonal block of P0.  The one-variable
 // feasible sets of separable constraints do not depend on the other coordinates, so they are
 // computed for the whole block by all 256 threads before the sequential part.
+#if 0  // first version, superseded by cd_phase2.h (kept until the new kernel is parity-green)
 template <int MAXC, bool XLDS>
 __global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
     extern __shared__ double smem[];
@@ -344,6 +345,10 @@ __global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
 
     const int kper = (int)(P.KS / 4);  // KS = n16/4 is a multiple of 4
     bool all_done = false;
+    long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;
+#define PROF_TICK(slot)                                                    \
+    if (a.prof) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); pc[slot] += now_ - tp; tp = now_; }
+    if (a.prof) tp = (long long)__builtin_amdgcn_s_memtime();
     for (int64_t t = 0; t < a.num_iters && !all_done; t++) {
         if (wave == 0 && lane < 16 && !conv) sweeps++;
         for (int64_t b = 0; b < P.NB; b++) {
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
 #pragma unroll
             for (int v = 0; v < 4; v++)
                 part[wave * 256 + ((lane >> 4) + 4 * v) * 16 + (lane & 15)] = acc[v];
+            PROF_TICK(0)
             // ---- per (coordinate c, restart r): feasible set at the restart's slack
             {
                 const int c = tid >> 4, r = tid & 15;
@@ -377,7 +383,9 @@ __global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
 #pragma unroll
                 for (int j = 0; j <= MAXC; j++) { ivlo[j * 256 + tid] = C.lo[j]; ivhi[j * 256 + tid] = C.hi[j]; }
             }
+            PROF_TICK(1)
             __syncthreads();
+            PROF_TICK(2)
             // ---- sequential part: lane = restart
             if (wave == 0) {
                 if (lane < 16) {
@@ -428,7 +436,10 @@ __global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
                 unsigned long long live = __ballot(lane < 16 && !conv);
                 if (lane == 0) *done = (live == 0ull) ? 1 : 0;
             }
+            PROF_TICK(3)
             __syncthreads();
+            PROF_TICK(4)
+            pc[5]++;
             if (*done) { all_done = true; break; }
         }
     }
@@ -440,7 +451,16 @@ __global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
         a.visits[gr] = visits; a.accepted[gr] = accepted; a.sweeps[gr] = sweeps;
         a.status[gr] = status;
     }
+    if (a.prof && tid == 0)
+        for (int k = 0; k < 8; k++) a.prof[tile * 8 + k] = pc[k];
+#undef PROF_TICK
 }
+
+#endif
+
+}  // namespace qcqpmi
+#include "cd_phase2.h"
+namespace qcqpmi {
 
 // ------------------------------------------------------------------------------- best selection
 
