@@ -106,6 +106,8 @@ struct qcqpmi_ctx {
     double *d_comm = nullptr;
     long long *d_prof = nullptr;
     bool profile = false;
+    int dbg = 0;
+    bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
 };
 
 namespace {
@@ -222,6 +224,30 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
         HIPCHK(c, hipGetLastError());
         return 0;
     }
+    const DevProblem &dp = c->dp;
+    // role-split pipelined kernel for the single-class Boolean / box families
+    if (MAXC == 1 && c->K == 1 && (c->objclass == 1 || c->objclass == 2) && !c->force_generic) {
+        const size_t rs_common = (size_t)(3 * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8) * sizeof(double);
+        const size_t rs_with_x = rs_common + (size_t)c->n16 * 16 * sizeof(double);
+        used_lds = rs_with_x <= 160 * 1024;
+        const size_t rs_lds = used_lds ? rs_with_x : rs_common;
+        dim3 block512(256);
+#define QM_RS(XL, FA)                                                                               \
+    do {                                                                                            \
+        auto k = cd_phase2_rs_kernel<XL, FA>;                                                       \
+        HIPCHK(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds)); \
+        tic(c, 2);                                                                                  \
+        hipLaunchKernelGGL(k, grid, block512, rs_lds, c->stream, a1, dp.Apack, dp.Apack2, dp.P0, dp.q0, dp.rcp2d); \
+        toc(c, 2);                                                                                  \
+    } while (0)
+        if (used_lds && c->objclass == 1) QM_RS(true, 1);
+        else if (used_lds) QM_RS(true, 2);
+        else if (c->objclass == 1) QM_RS(false, 1);
+        else QM_RS(false, 2);
+#undef QM_RS
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     // dynamic LDS: [X tile] + partial tiles + G + diagonal block + slack + feasible-set table
     const bool use_cls = c->K <= 16;
     const size_t slots = use_cls ? (size_t)c->K * 16 : 0;
@@ -232,7 +258,6 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
     size_t with_x = common + (size_t)c->n16 * 16 * sizeof(double);
     used_lds = with_x <= 160 * 1024;
     const size_t lds = used_lds ? with_x : common;
-    const DevProblem &dp = c->dp;
     const int fast = (MAXC == 1) ? c->objclass : 0;
     const bool uni = use_cls && c->K == 1;
 #define QM_LAUNCH2(XL, CL, FA, UN)                                                                     \
@@ -396,8 +421,15 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
         hipLaunchKernelGGL(pack_A_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                            dp.P0, ap, n16, dp.KS);
         HIPCHK(c, hipGetLastError());
+        double *ap2 = nullptr;
+        if ((rc = dev_alloc(c, &ap2, (size_t)n16 * n16, false))) return rc;
+        c->prob_allocs.push_back(ap2);
+        hipLaunchKernelGGL(pack_A2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                           dp.P0, ap2, n16, dp.KS);
+        HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));  // P, q vectors go out of scope
         dp.Apack = ap;
+        dp.Apack2 = ap2;
         dp.r0 = h.r;
     }
     // ---- constraints: separable iff one diagonal entry / one linear entry on the same coordinate
@@ -629,9 +661,10 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
     a.visits = c->d_visits; a.accepted = c->d_acc; a.sweeps = c->d_sweeps; a.status = c->d_status;
     a.flag = c->d_flag;
     a.prof = nullptr;
+    a.dbg = c->dbg;
     if (c->profile) {
         if (c->d_prof) { (void)hipFree(c->d_prof); c->d_prof = nullptr; }
-        if ((rc = dev_alloc(c, &c->d_prof, (size_t)(c->Rpad / 16) * 8))) return rc;
+        if ((rc = dev_alloc(c, &c->d_prof, (size_t)(c->Rpad / 16) * 16))) return rc;
         a.prof = c->d_prof;
     }
     bool used_lds = false;
@@ -722,12 +755,14 @@ int qcqpmi_last_kernel_ms(qcqpmi_ctx *c, int which, double *ms) {
 
 int qcqpmi_debug_profile(qcqpmi_ctx *c, int enable, int64_t *sums8) {
     if (!c) return QCQPMI_EINVAL;
-    c->profile = enable != 0;
+    c->profile = (enable & 1) != 0;
+    c->force_generic = (enable & 2) != 0;
+    c->dbg = enable >> 4;
     if (sums8 && c->d_prof && c->Rpad > 0) {
-        std::vector<long long> h((size_t)(c->Rpad / 16) * 8);
+        std::vector<long long> h((size_t)(c->Rpad / 16) * 16);
         HIPCHK(c, hipMemcpy(h.data(), c->d_prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        for (int k = 0; k < 8; k++) sums8[k] = 0;
-        for (size_t t = 0; t < h.size(); t++) sums8[t & 7] += h[t];
+        for (int k = 0; k < 16; k++) sums8[k] = 0;
+        for (size_t t = 0; t < h.size(); t++) sums8[t & 15] += h[t];
     }
     return 0;
 }

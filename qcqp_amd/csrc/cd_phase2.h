@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a, const double *
         a.status[gr] = S.status;
     }
     if (a.prof && tid == 0)
-        for (int k = 0; k < 8; k++) a.prof[tile * 8 + k] = pc[k];
+        for (int k = 0; k < 8; k++) a.prof[tile * 16 + k] = pc[k];
 #undef PROF_TICK
 }
 

@@ -1,0 +1,437 @@
+// Coordinate descent phase 2 (qcqp.py:152-178), role-split pipelined kernel for the common
+// Boolean / box families: every coordinate carries the same single constraint (one constraint
+// class, K == 1, MAXC == 1) and the diagonal of P0 is all positive (FAST == 1, convex scalar
+// objective) or all zero (FAST == 2, linear scalar objective, e.g. MAXCUT).
+//
+// One workgroup = 4 waves (one per SIMD, 512 VGPRs each) owns a tile of 16 restarts and walks the
+// blocks of 16 coordinates:
+//
+//   wave 0      ("chain")  visits the 16 coordinates of block b in order, lane = restart
+//                          (Gauss-Seidel: each accepted move is folded into the rest of the block
+//                          through the 16x16 diagonal block of P0);
+//   waves 1..3  ("mfma")   meanwhile compute, for the NEXT block b', the partial products
+//                          G' = P0[I_b', k] X[k]  over all k outside block b on
+//                          v_mfma_f64_16x16x4_f64 (K split 3 ways) -- rows of X outside block b do
+//                          not change while the chain works on block b.  The A fragments do not
+//                          depend on X at all: they are fetched into registers a whole iteration
+//                          ahead (16-byte loads from a pair-packed copy of P0), double-buffered;
+//   then wave 0 adds the 4 missing k-steps (the freshly updated rows I_b) with 4 MFMAs, sums the
+//   3 partial tiles in a fixed order and starts the next chain.
+//
+// fp64 MFMA competes with fp64 VALU for a SIMD's double-precision pipe (measured: +54 % chain
+// time with an MFMA wave beside it), so the chain keeps its SIMD for itself; one wave per SIMD
+// already saturates the fp64 matrix pipe (64-cycle issue = 64-cycle dependent latency).
+//
+// Per block the critical path is   chain (16 dependent steps)  +  fix-up  +  2 barriers;
+// the MFMA work (2 n16^2 flops per restart-sweep, the roofline term) hides behind the chain.
+//
+// Arithmetic of the fast path: vertex xv = x_i - (G_i + q_i/2) / P_ii  (exact algebra for the
+// reference's -t1/(2 t2)), projection on the interval on xv's side of the gap midpoint.  Every
+// decision that is close to a tie, touches +-inf or has a vanishing objective raises `redo`: the
+// block is then recomputed by the generic loop, which follows the reference's arithmetic
+// literally (onevar_minimise in onevar.h).
+#pragma once
+#include "cd_phase2.h"
+
+namespace qcqpmi {
+
+typedef double v2d_ __attribute__((ext_vector_type(2)));
+
+// acc += Apack[b][kk] * X rows for kk in [kk0, kk1) streaming the A fragments from L2
+// (fallback for k-steps that do not fit the register prefetch, n > 16 * 3 * PFU).
+template <typename XPtr>
+__device__ inline v4d_ mfma_range(const double *__restrict__ Ab, XPtr Xs, int kk0, int kk1, int lane,
+                                  v4d_ acc) {
+    const double *ap = Ab + (int64_t)kk0 * 64 + lane;
+    XPtr xp = Xs + kk0 * 64 + (lane >> 4) * 16 + (lane & 15);
+    for (int k = kk0; k < kk1; k++) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], xp[0], acc, 0, 0, 0);
+        ap += 64;
+        xp += 64;
+    }
+    return acc;
+}
+
+constexpr int RS_NMW = 3;    // mfma waves
+constexpr int RS_PFU = 22;   // units (blocks of 16 coordinates) whose A fragments live in registers
+
+// ------------------------------------------------------------------------------ mfma role
+// Work is dealt in UNITS of 4 k-steps (= one block of 16 coordinates).  For the product of block
+// `bn` the units are all blocks except `bx`, the one the chain is rewriting (bx < 0: no
+// exclusion): unit j -> block  j < bx ? j : j + 1.  Wave mw owns the units [u0, u1).
+
+// fragments of the owned units of product (bn | hole bx) -> registers (pair-packed P0 copy:
+// the fragments of k-steps 2 kk2, 2 kk2 + 1 of block bn sit at ((bn KS/2 + kk2) 64 + lane) 2)
+__device__ inline const v2d_ *rs_unit_ptr(const double *__restrict__ Apack2, int NB, int KS, int mw,
+                                          int lane, int bn, int bx, int U) {
+    const int total = (bx >= 0) ? NB - 1 : NB;
+    const int u0 = total * mw / RS_NMW, u1 = total * (mw + 1) / RS_NMW;
+    const int hb = (bx >= 0) ? bx : NB;
+    int j = u0 + U;
+    j = j < u1 ? j : u1 - 1;            // units past the owned range re-load the last one (harmless):
+    j = j < 0 ? 0 : j;                  // every load is unconditional so that s_waitcnt can count them
+    int bb = j < hb ? j : j + 1;
+    bb = bb < NB ? bb : NB - 1;
+    return reinterpret_cast<const v2d_ *>(Apack2) + ((int64_t)bn * (KS / 2) + 2 * bb) * 64 + lane;
+}
+
+__device__ inline void rs_prefetch(v2d_ (&ar)[2 * RS_PFU], const double *__restrict__ Apack2, int NB,
+                                   int KS, int mw, int lane, int bn, int bx) {
+#pragma unroll
+    for (int U = 0; U < RS_PFU; U++) {
+        const v2d_ *ap = rs_unit_ptr(Apack2, NB, KS, mw, lane, bn, bx, U);
+        ar[2 * U] = ap[0];
+        ar[2 * U + 1] = ap[64];
+    }
+}
+
+// Product of block bn (hole bx) from the fragments in `ar`; each fragment register is refilled,
+// right after the MFMA that consumed it, with the fragment of the NEXT product (block bn2, hole
+// bx2) -- the load lands hundreds of cycles later, long after the MFMA has read its operand.
+// All X rows (B operands) of the wave are read from LDS up front: an MFMA fed by an LDS read
+// issued just before it runs at ~90 cycles instead of 64 (in-order issue: the read cannot be
+// issued while the wave waits for the matrix pipe).
+template <typename XPtr>
+__device__ inline v4d_ rs_compute(v2d_ (&ar)[2 * RS_PFU], const double *__restrict__ Apack,
+                                  const double *__restrict__ Apack2, XPtr Xs, int NB, int KS, int mw,
+                                  int lane, int bn, int bx, int bn2, int bx2, int dbg) {
+    const int total = (bx >= 0) ? NB - 1 : NB;
+    const int u0 = total * mw / RS_NMW, u1 = total * (mw + 1) / RS_NMW;
+    const int hb = (bx >= 0) ? bx : NB;
+    const int nu = u1 - u0;
+    const int xoff = (lane >> 4) * 16 + (lane & 15);
+    double bq[4 * RS_PFU];
+#pragma unroll
+    for (int U = 0; U < RS_PFU; U++) {
+        int j = u0 + U;
+        j = j < u1 ? j : u1 - 1;
+        j = j < 0 ? 0 : j;
+        int bb = j < hb ? j : j + 1;
+        bb = bb < NB ? bb : NB - 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[4 * U + q] = Xs[(4 * bb + q) * 64 + xoff];
+    }
+    v4d_ acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc, acc2 = acc, acc3 = acc;
+#pragma unroll
+    for (int U = 0; U < RS_PFU; U++) {
+        if (U < nu) {   // wave-uniform
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U][0], bq[4 * U], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U][1], bq[4 * U + 1], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U + 1][0], bq[4 * U + 2], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U + 1][1], bq[4 * U + 3], acc3, 0, 0, 0);
+        }
+        {   // unconditional: s_waitcnt can then count exactly how many loads are younger
+            const v2d_ *ap = rs_unit_ptr(Apack2, NB, KS, mw, lane, bn2, bx2, U);
+            ar[2 * U] = ap[0];
+            ar[2 * U + 1] = ap[64];
+        }
+    }
+    acc = (acc + acc1) + (acc2 + acc3);
+    if (nu > RS_PFU) {   // large n: the rest streams from L2
+        const double *Ab = Apack + (int64_t)bn * KS * 64;
+        for (int j = u0 + RS_PFU; j < u1; j++) {
+            const int bb = j < hb ? j : j + 1;
+            acc = mfma_range(Ab, Xs, 4 * bb, 4 * bb + 4, lane, acc);
+        }
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------ kernel
+
+template <bool XLDS, int FAST>
+__global__ __launch_bounds__(256) void cd_phase2_rs_kernel(CdArgs a, const double *__restrict__ Apack,
+                                                           const double *__restrict__ Apack2,
+                                                           const double *__restrict__ P0,
+                                                           const double *__restrict__ q0,
+                                                           const double *__restrict__ rcp2d) {
+    constexpr int MAXC = 1;
+    extern __shared__ double smem[];
+    const DevProblem &P = a.P;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too
+    const int64_t tile = blockIdx.x;
+    const int64_t n16 = P.n16;
+    const int NB = (int)P.NB, KS = (int)P.KS;
+    double *Xg = a.X + tile * n16 * 16;
+    // ---- dynamic LDS carve-up
+    double *sp = smem;
+    double *Xl = sp; if (XLDS) sp += n16 * 16;
+    double *part = sp; sp += RS_NMW * 256;   // partial G tiles of the mfma waves, [c][r] layout
+    double *Gsc = sp; sp += 256;             // complete G (+ q/2) of the current block, [c][r]
+    double *Dblk2 = sp; sp += 2 * 256;       // diagonal block of P0, double-buffered by block parity
+    double *hqb2 = sp; sp += 2 * 16;         // q0 / 2
+    double *rtb2 = sp; sp += 2 * 16;         // 1 / P0[i,i]  (0 if P0[i,i] == 0)
+    double *slk = sp; sp += 16;
+    SetTable<MAXC> TC;                       // the single class: slot = restart
+    TC.slots = 16;
+    TC.lo = sp; sp += 2 * 16;
+    TC.hi = sp; sp += 2 * 16;
+    TC.n = (int *)sp; sp += 8;
+    TC.slow = (int *)sp; sp += 8;
+    int *done = (int *)sp;
+
+    double *Xs = XLDS ? Xl : Xg;
+    if (XLDS)
+        for (int64_t idx = tid; idx < n16 * 16; idx += 256) Xl[idx] = Xg[idx];
+    if (tid < 16) {
+        const int64_t g = tile * 16 + tid;
+        slk[tid] = (g < a.R) ? a.slack[g] : 0.0;
+    }
+    if (tid == 0) *done = 0;
+    __syncthreads();
+    if (tid < 16) {
+        FeasSet<MAXC> C;
+        compute_set<MAXC>(P, P.krep[0], slk[tid], C);
+        store_set<MAXC>(TC, tid, C);
+    }
+    __syncthreads();
+
+    const int64_t gmax = a.num_iters * (int64_t)NB;
+
+    if (wave != 0) {
+        // =========================================================================== mfma role
+        const int mw = wave - 1;
+        const int st = tid - 64;   // 0..191: staging slot of this thread
+        v2d_ arP[2 * RS_PFU];
+        long long qc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
+#define QTICK(slot) if (a.prof && wave == 1) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); qc[slot] += now_ - tq; tq = now_; }
+        // staging of the small operands of a block: diagonal block of P0 (256 entries over 192
+        // threads) and q/2, 1/P_ii of its 16 coordinates (threads 0..15).  Loads are issued early,
+        // the LDS stores come after the matrix work.
+        double st_d0 = 0.0, st_d1 = 0.0, st_q = 0.0, st_r = 0.0;
+        auto stage_load = [&](int bn) {
+            st_d0 = P0[(16 * (int64_t)bn + (st >> 4)) * n16 + 16 * bn + (st & 15)];
+            if (st < 64) st_d1 = P0[(16 * (int64_t)bn + 12 + (st >> 4)) * n16 + 16 * bn + (st & 15)];
+            if (st < 16) { st_q = q0[16 * (int64_t)bn + st]; st_r = rcp2d[16 * (int64_t)bn + st]; }
+        };
+        auto stage_store = [&](int buf) {
+            double *Dblk = Dblk2 + buf * 256;
+            Dblk[st] = st_d0;
+            if (st < 64) Dblk[192 + st] = st_d1;
+            if (st < 16) { hqb2[buf * 16 + st] = 0.5 * st_q; rtb2[buf * 16 + st] = st_r + st_r; }
+        };
+        auto store_part = [&](const v4d_ &acc) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) part[mw * 256 + ((lane >> 4) + 4 * v) * 16 + (lane & 15)] = acc[v];
+        };
+        // prologue: full G of block 0 (no exclusion), then the fragments of iteration 0's product
+        rs_prefetch(arP, Apack2, NB, KS, mw, lane, 0, -1);
+        stage_load(0);
+        {
+            v4d_ acc = rs_compute(arP, Apack, Apack2, Xs, NB, KS, mw, lane, 0, -1, 1 % NB, 0, 0);
+            store_part(acc);
+            stage_store(0);
+        }
+        if (a.prof) tq = (long long)__builtin_amdgcn_s_memtime();
+        // iteration g computes the product for block b(g+1) with hole b(g) from set S_, and
+        // prefetches the fragments of iteration g+1 (block b(g+2), hole b(g+1)) into set T_.
+#define RS_MFMA_ITER(S_, T_)                                                          \
+        {                                                                             \
+            const int b = (int)(g % NB);                                              \
+            QTICK(0)                                                                  \
+            __syncthreads();                                                          \
+            if (*done || g >= gmax) break;                                            \
+            stage_load((b + 1) % NB);                                                 \
+            QTICK(1)                                                                  \
+            __syncthreads();                                                          \
+            QTICK(2)                                                                  \
+            v4d_ acc = {0.0, 0.0, 0.0, 0.0};                                          \
+            if (!(a.dbg & 1)) acc = rs_compute(arP, Apack, Apack2, Xs, NB, KS, mw, lane, (b + 1) % NB, b, (b + 2) % NB, (b + 1) % NB, a.dbg); \
+            QTICK(3)                                                                  \
+            store_part(acc);                                                          \
+            stage_store((int)((g + 1) & 1));                                          \
+            g++;                                                                      \
+        }
+        for (int64_t g = 0;;) {
+            RS_MFMA_ITER(arP, arP)
+        }
+#undef RS_MFMA_ITER
+        if (a.prof && tid == 64)
+            for (int k = 0; k < 8; k++) a.prof[tile * 16 + 8 + k] = qc[k];
+#undef QTICK
+    } else {
+        // ========================================================================== chain role
+        __builtin_amdgcn_s_setprio(3);
+        const int r = lane & 15;
+        const int64_t gr = tile * 16 + r;
+        // feasible set of this lane's restart: registers for the whole kernel
+        StepTab U;
+        U.l0 = TC.lo[r]; U.h0 = TC.hi[r]; U.l1 = TC.lo[16 + r]; U.h1 = TC.hi[16 + r];
+        U.n = TC.n[r]; U.slow = TC.slow[r];
+        {
+            const bool two = U.n >= 2;
+            U.mid = two ? 0.5 * (U.h0 + U.l1) : QM_INF;
+            U.thr = two ? 1e-7 * (U.l1 - U.h0) : 0.0;
+        }
+        ChainState S;
+        S.fcur = 0.0; S.upd_counter = 0; S.visits = 0; S.accepted = 0; S.sweeps = 0;
+        S.conv = true; S.status = 0;
+        if (lane < 16 && gr < a.R) {
+            S.conv = a.flag[gr] ? false : true;
+            S.fcur = a.f0cur[gr];
+        }
+        double afix[4] = {0.0, 0.0, 0.0, 0.0};   // A fragments of the next fix-up
+        long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;
+#define PROF_TICK(slot) if (a.prof) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); pc[slot] += now_ - tp; tp = now_; }
+        if (a.prof) tp = (long long)__builtin_amdgcn_s_memtime();
+        for (int64_t g = 0;; g++) {
+            const int b = (int)(g % NB);
+            const int64_t t = g / NB;
+            const int bprev = (g > 0) ? (int)((g - 1) % NB) : -1;
+            const int cur = (int)(g & 1);
+            const double *Dblk = Dblk2 + cur * 256, *hqb = hqb2 + cur * 16, *rtb = rtb2 + cur * 16;
+            PROF_TICK(0)
+            __syncthreads();                  // (1) part/Dblk/hq/rt of block b and X rows of bprev are ready
+            PROF_TICK(1)
+            if (*done || g >= gmax) break;
+            double xb[16], gb[16];
+            {
+                // ---- fix-up: the 4 k-steps of the block the chain has just updated (A fragments
+                // were fetched during that chain), then the partials, in a fixed order
+                v4d_ acc = {0.0, 0.0, 0.0, 0.0};
+                if (bprev >= 0) {
+                    const int xo = (4 * bprev) * 64 + (lane >> 4) * 16 + (lane & 15);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afix[u], Xs[xo + u * 64], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int c = (lane >> 4) + 4 * v;
+                    double s = acc[v];
+#pragma unroll
+                    for (int w = 0; w < RS_NMW; w++) s += part[w * 256 + c * 16 + (lane & 15)];
+                    Gsc[c * 16 + (lane & 15)] = s + hqb[c];
+                }
+                // same wave: LDS operations complete in order, no barrier needed before reading Gsc
+                if (lane < 16) {
+#pragma unroll
+                    for (int c = 0; c < 16; c++) {
+                        gb[c] = Gsc[c * 16 + r];
+                        xb[c] = Xs[(16 * b + c) * 16 + r];
+                    }
+                }
+                if (lane < 16 && b == 0 && !S.conv) S.sweeps++;
+            }
+            PROF_TICK(2)
+            __syncthreads();                  // (2) block b is in registers: part may be rewritten
+            PROF_TICK(3)
+            {   // A fragments for the fix-up of the NEXT block: k-steps of this block
+                const int bn = (b + 1) % NB;
+                const double *ap = Apack + ((int64_t)bn * KS + 4 * b) * 64 + lane;
+#pragma unroll
+                for (int u = 0; u < 4; u++) afix[u] = ap[u * 64];
+            }
+            if (lane < 16 && !(a.dbg & 8)) {
+                const int cmax = (P.n - 16 * (int64_t)b) < 16 ? (int)(P.n - 16 * (int64_t)b) : 16;  // uniform
+                const bool act = !S.conv;
+                int upd = (int)S.upd_counter, accn = 0;
+                bool redo = false;
+                double fcur = S.fcur;
+                double xn_[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) xn_[c] = xb[c];
+                // row c of the diagonal block (wave-uniform LDS broadcast reads), fetched one step ahead
+                double drow[16], t2 = Dblk[0], rt = rtb[0];
+#pragma unroll
+                for (int c2 = 1; c2 < 16; c2++) drow[c2] = Dblk[c2];
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    if (c >= cmax) continue;   // wave-uniform
+                    double dnext[16], t2n = 0.0, rtn = 0.0;
+                    if (c + 1 < 16) {
+                        t2n = Dblk[(c + 1) * 16 + (c + 1)];
+                        rtn = rtb[c + 1];
+#pragma unroll
+                        for (int c2 = c + 2; c2 < 16; c2++) dnext[c2] = Dblk[(c + 1) * 16 + c2];
+                    }
+                    const double xi = xb[c];
+                    const double g2 = gb[c];                      // G_i + q_i / 2  (includes P_ii x_i)
+                    double pick;
+                    bool nr;
+                    if (FAST == 1) {
+                        const double xv = __builtin_fma(-g2, rt, xi);          // vertex of the scalar objective
+                        const double p0 = fmin(fmax(xv, U.l0), U.h0);
+                        const double p1 = fmin(fmax(xv, U.l1), U.h1);
+                        pick = (xv > U.mid) ? p1 : p0;
+                        nr = fabs(xv - U.mid) <= U.thr;
+                    } else {
+                        // linear scalar objective: slope t1 = 2 (G_i + q_i/2), extreme end point against it
+                        const double L = U.l0;
+                        const double H = (U.n >= 2) ? U.h1 : U.h0;
+                        pick = (g2 > 0.0) ? L : H;
+                        nr = 2.0 * fabs(g2) * (fabs(L) + fabs(H)) <= 1e-9 * fabs(fcur) + 1e-300;
+                    }
+                    redo = redo || nr || !(pick == pick);
+                    const double dlt = pick - xi;
+                    const bool moved = act && U.n > 0 && fabs(dlt) > a.tol;
+                    const double delta = moved ? dlt : 0.0;
+                    xn_[c] = moved ? pick : xi;
+                    // f(pick) - f(xi) = delta (t2 delta + t1),  t1 = 2 (g2 - t2 xi)
+                    fcur += delta * __builtin_fma(t2, delta, 2.0 * (g2 - t2 * xi));
+                    accn += moved ? 1 : 0;
+                    upd = moved ? 0 : upd + 1;
+#pragma unroll
+                    for (int c2 = c + 1; c2 < 16; c2++) gb[c2] = __builtin_fma(drow[c2], delta, gb[c2]);
+#pragma unroll
+                    for (int c2 = c + 2; c2 < 16; c2++) drow[c2] = dnext[c2];
+                    t2 = t2n;
+                    rt = rtn;
+                }
+                redo = act && U.n > 0 && (redo || U.slow != 0);
+                if (__builtin_amdgcn_ballot_w64(redo) == 0ull) {
+                    if (act) {
+                        // n consecutive rejections = convergence (qcqp.py:172-176).  Visits past that
+                        // point inside this block changed nothing (deterministic map) and are not counted.
+                        S.fcur = fcur; S.accepted += accn;
+                        const int over = upd - (int)P.n;
+                        S.visits += cmax - (over > 0 ? over : 0);
+                        S.upd_counter = upd;
+                        if (over >= 0) S.conv = true;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 16; c++) Xs[(16 * b + c) * 16 + r] = xn_[c];
+                } else {
+                    // ---- generic loop (rare): the reference's arithmetic, state in LDS (Gsc, X rows)
+                    pc[6]++;
+                    for (int c = 0; c < cmax; c++) {
+                        const int64_t i = 16 * (int64_t)b + c;
+                        FeasSet<MAXC> C;
+                        C.n = U.n; C.lo[0] = U.l0; C.hi[0] = U.h0; C.lo[1] = U.l1; C.hi[1] = U.h1;
+                        const double t2g = Dblk[c * 16 + c];
+                        const double xi = Xs[i * 16 + r];
+                        const double hq = hqb[c];
+                        const double t1 = 2.0 * ((Gsc[c * 16 + r] - hq) - t2g * xi) + (hq + hq);
+                        const double t0 = S.fcur - xi * (t2g * xi + t1);
+                        DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t | 0x80000000u, 0u};
+                        double xn = xi;
+                        int got = S.conv ? 0 : onevar_minimise<MAXC>(t2g, t1, t0, C, dk, &xn);
+                        bool moved;
+                        double delta;
+                        chain_commit<MAXC>(S, got, xn, xi, t2g, t1, t0, a.tol, P.n, moved, delta);
+                        if (moved) {
+                            Xs[i * 16 + r] = xn;
+                            for (int c2 = c + 1; c2 < 16; c2++) Gsc[c2 * 16 + r] += Dblk[c * 16 + c2] * delta;
+                        }
+                    }
+                }
+            }
+            const unsigned long long live = __builtin_amdgcn_ballot_w64(lane < 16 && !S.conv);
+            if (lane == 0) *done = (live == 0ull) ? 1 : 0;
+            pc[5]++;
+        }
+        if (lane < 16 && gr < a.R) {
+            a.visits[gr] = S.visits; a.accepted[gr] = S.accepted; a.sweeps[gr] = S.sweeps;
+            a.status[gr] = S.status;
+        }
+        if (a.prof && tid == 0)
+            for (int k = 0; k < 8; k++) a.prof[tile * 16 + k] = pc[k];
+#undef PROF_TICK
+    }
+    __syncthreads();
+    if (XLDS)
+        for (int64_t idx = tid; idx < n16 * 16; idx += 256) Xg[idx] = Xl[idx];
+}
+
+}  // namespace qcqpmi

@@ -18,6 +18,7 @@ namespace qcqpmi {
 struct DevProblem {
     int64_t n, n16, NB, KS, m;
     const double *Apack;  // [NB][KS][64]
+    const double *Apack2; // [NB][KS/2][64][2]: the same fragments, two consecutive k-steps per lane (16-byte loads)
     const double *P0;     // [n16][n16] row-major, zero padded
     const double *q0;     // [n16]
     double r0;
@@ -67,6 +68,7 @@ struct CdArgs {
     int *status;            // [Rpad] 0 ok, <0 where the reference would raise
     uint8_t *flag;          // [Rpad] in: run this restart (phase 2) / out: phase-1 feasible
     long long *prof;        // optional [tiles][8] cycle counters of wave 0 (debug), or nullptr
+    int dbg;                // debug switches for timing experiments (results invalid when != 0)
 };
 
 }  // namespace qcqpmi

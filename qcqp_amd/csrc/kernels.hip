@@ -32,6 +32,19 @@ __global__ void pack_A_kernel(const double *__restrict__ P, double *__restrict__
     Apack[idx] = P[(16 * b + (l & 15)) * n16 + 4 * kk + (l >> 4)];
 }
 
+// pair-packed variant: Apack2[((b*KS/2 + kk2)*64 + l)*2 + t] = fragment element of k-step 2 kk2 + t
+__global__ void pack_A2_kernel(const double *__restrict__ P, double *__restrict__ Apack2,
+                               int64_t n16, int64_t KS) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = n16 * n16;
+    if (idx >= total) return;
+    int t = (int)(idx & 1);
+    int l = (int)((idx >> 1) & 63);
+    int64_t u = idx >> 7;
+    int64_t kk2 = u % (KS / 2), b = u / (KS / 2);
+    Apack2[idx] = P[(16 * b + (l & 15)) * n16 + 4 * (2 * kk2 + t) + (l >> 4)];
+}
+
 // host layout: X[r*n + j]; tile layout: Xt[(r/16) * n16*16 + j*16 + (r%16)]
 __global__ void to_tiles_kernel(const double *__restrict__ X, double *__restrict__ Xt, int64_t n,
                                 int64_t n16, int64_t R, int64_t Rpad) {
@@ -460,6 +473,7 @@ __global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
 
 }  // namespace qcqpmi
 #include "cd_phase2.h"
+#include "cd_phase2_rs.h"
 namespace qcqpmi {
 
 // ------------------------------------------------------------------------------- best selection

@@ -45,11 +45,14 @@ def test_eval_large_vs_oracle(eng_mod, orc):
     assert rel(f0, g0) < 1e-12 and rel(mv, gv) < 1e-13
 
 
+@pytest.mark.parametrize('generic', [False, True])
 @pytest.mark.parametrize('name', ['bls10', 'bls32', 'bls64', 'maxcut12'])
-def test_cd_phase2_matches_reference_golden(eng_mod, name):
-    """Phase 2 is deterministic: the device trajectory must land on the reference's point."""
+def test_cd_phase2_matches_reference_golden(eng_mod, name, generic):
+    """Phase 2 is deterministic: the device trajectory must land on the reference's point.
+    generic=True forces the general 4-wave kernel where the pipelined 8-wave one would apply."""
     z = load_golden('g6_cd_' + name)
     e = make(eng_mod, funcs_from_npz(z))
+    e.L.qcqpmi_debug_profile(e.h, 2 if generic else 0, None)
     e.upload(z['X0'])
     out = e.cd_run(phase1=False)
     X = e.download()
@@ -58,14 +61,16 @@ def test_cd_phase2_matches_reference_golden(eng_mod, name):
     assert rel(out['maxviol'], z['p2_fv'][:, 1]) < 1e-9
 
 
+@pytest.mark.parametrize('generic', [False, True])
 @pytest.mark.parametrize('name,n,m_rows', [('bls', 96, 40), ('bls', 250, 100), ('maxcut', 130, 0)])
-def test_cd_full_driver_vs_oracle_keyed(eng_mod, orc, name, n, m_rows):
+def test_cd_full_driver_vs_oracle_keyed(eng_mod, orc, name, n, m_rows, generic):
     """Phase 1 draws from the keyed Philox stream: oracle (ORC_RNG_KEYED) and GPU consume the same
     draws, so whole improve_coord_descent trajectories are comparable."""
     from qcqp_amd import problems
     funcs = (problems.boolean_least_squares(n, m_rows, seed=2)[0] if name == 'bls'
              else problems.maxcut(n, 0.5, seed=3, weighted=True)[0])
     e = make(eng_mod, funcs)
+    e.L.qcqpmi_debug_profile(e.h, 2 if generic else 0, None)
     prob = orc.Problem(funcs)
     R, seed, first = 21, 1234, 7
     X0 = np.random.RandomState(1).randn(n, R)
