@@ -1,0 +1,230 @@
+"""Drop-in facade: the reference's ``QCQP(prob).suggest()/improve()`` (qcqp/qcqp.py:367-432) on top of
+the HIP engine.  Same method constants, same ``(f, v)`` return pairs, same sign convention for
+maximisation, same kwargs and defaults; the inner loops run on the GPU for a whole POPULATION of
+candidate points at once.
+
+What is new (all optional, defaults reproduce the reference's one-point behaviour):
+  suggest(..., num_samples=R, seed=s)   draw R candidates instead of one (resident on the GPU)
+  improve(..., seed=s)                  seed of the counter-based stream used by phase 1 of
+                                        coordinate descent (the reference uses the global NumPy RNG)
+  qcqp.population_f / population_v      objective / max violation of every candidate
+  qcqp.population()                     the candidates themselves, one per column
+
+cvxpy is not needed (and not installed here): problems are given as ``qcqp_amd.Problem`` built from
+raw ``(P, q, r, relop)`` arrays -- the data ``get_qcqp_form`` (utilities.py:318-347) would extract.
+"""
+import numpy as np
+
+from . import settings as s
+from .engine import Engine
+from .form import QCQPForm
+
+
+class Variable(object):
+    """Minimal stand-in for a cvxpy variable: ``size`` (rows, cols), ``value``, ``id``."""
+    _next_id = 0
+
+    def __init__(self, rows, cols=1):
+        self.size = (int(rows), int(cols))
+        self.value = None
+        self.id = Variable._next_id
+        Variable._next_id += 1
+
+
+class _Objective(object):
+    def __init__(self, name):
+        self.NAME = name
+
+
+class Problem(object):
+    """A QCQP given by raw arrays.  ``funcs`` = [(P, q, r, relop), ...], objective first with
+    relop None, written for the problem AS STATED (maximise problems give the function to be
+    maximised; it is negated internally exactly like utilities.py:335-336)."""
+
+    def __init__(self, funcs, maximize=False, var_sizes=None):
+        funcs = list(funcs)
+        n = int(np.asarray(funcs[0][1]).size)
+        if maximize:
+            P0, q0, r0, _ = funcs[0]
+            funcs[0] = (-P0, -np.asarray(q0, dtype=np.float64), -float(r0), None)
+        self.qcqp_form = QCQPForm.from_arrays(funcs)
+        self.objective = _Objective('maximize' if maximize else 'minimize')
+        sizes = var_sizes or [(n, 1)]
+        assert sum(a * b for a, b in sizes) == n
+        self._vars = [Variable(a, b) for a, b in sizes]
+
+    @classmethod
+    def from_minimize_form(cls, funcs, maximize=False, var_sizes=None):
+        """``funcs`` already in minimise form (what QCQPForm holds), e.g. qcqp_amd.problems.*"""
+        p = cls(funcs, False, var_sizes)
+        p.objective = _Objective('maximize' if maximize else 'minimize')
+        return p
+
+    def variables(self):
+        return self._vars
+
+
+def assign_vars(xs, vals):
+    """utilities.py:298-308"""
+    if vals is None:
+        for x in xs:
+            x.value = np.full(x.size, np.nan)
+    else:
+        ind = 0
+        for x in xs:
+            size = x.size[0] * x.size[1]
+            x.value = np.reshape(vals[ind:ind + size], x.size, order='F')
+            ind += size
+
+
+def flatten_vars(xs, n):
+    """utilities.py:310-316 -- with the index advanced (the reference forgets ``ind += size`` and
+    returns garbage past the first variable)."""
+    ret = np.empty(n)
+    ind = 0
+    for x in xs:
+        size = x.size[0] * x.size[1]
+        ret[ind:ind + size] = np.ravel(x.value, order='F')
+        ind += size
+    return ret
+
+
+class QCQP(object):
+    def __init__(self, prob, device=0):
+        if isinstance(prob, QCQPForm):
+            form = prob
+            prob = Problem.__new__(Problem)
+            prob.qcqp_form = form
+            prob.objective = _Objective('minimize')
+            prob._vars = [Variable(form.n, 1)]
+        if not hasattr(prob, 'qcqp_form'):
+            raise Exception("QCQP needs a qcqp_amd.Problem (raw (P, q, r, relop) arrays); extracting "
+                            "coefficients from a cvxpy problem is not implemented in this engine.")
+        self.prob = prob
+        self.qcqp_form = prob.qcqp_form
+        self.n = self.qcqp_form.n
+        self.spectral_sol = None
+        self.spectral_bound = None
+        self.sdr_sol = None
+        self.sdr_bound = None
+        self.maximize_flag = (prob.objective.NAME == "maximize")
+        self.engine = Engine(self.qcqp_form, device=device)
+        self._resident = False      # the engine's population matches the variables' best point
+        self.population_f = None
+        self.population_v = None
+        self.last_stats = None
+
+    # ------------------------------------------------------------------ helpers
+    def _sign(self, f):
+        return -f if self.maximize_flag else f
+
+    def _publish(self, f0, mv):
+        """Record the population's values, write the best candidate into the variables and return
+        the reference's (f, v) pair for it."""
+        self.population_f = self._sign(np.asarray(f0))
+        self.population_v = np.asarray(mv)
+        idx, fb, vb, xb = self.engine.select_best(1e-4)
+        assign_vars(self.prob.variables(), xb)
+        self._assigned = np.array(xb, copy=True)
+        self._resident = True
+        self.best_index = idx
+        return (self._sign(fb), vb)
+
+    def population(self):
+        return self.engine.download()
+
+    # ------------------------------------------------------------------ suggest
+    def suggest(self, method=s.RANDOM, eps=1e-8, *args, **kwargs):
+        if method not in s.suggest_methods:
+            raise Exception("Unknown suggest method: %s\n", method)
+        R = int(kwargs.pop('num_samples', kwargs.pop('num_restarts', 1)))
+        seed = kwargs.pop('seed', None)
+        compat = kwargs.pop('compat', True)
+        if method == s.RANDOM:
+            if R == 1 and seed is None:
+                x = np.random.randn(self.n)          # qcqp.py:382, same global-RNG draw
+                self.engine.upload(x)
+            else:
+                self.engine.randn(R, seed=0 if seed is None else seed)
+        elif method == s.SPECTRAL:
+            if self.spectral_sol is None:
+                raise Exception("SPECTRAL suggest needs the spectral relaxation solution: no SDP solver "
+                                "is available; set qcqp.spectral_sol / qcqp.spectral_bound first.")
+            self.engine.upload(np.asarray(self.spectral_sol, dtype=np.float64).ravel())
+        elif method == s.SDR:
+            if 'X' in kwargs:
+                self.sdr_sol = np.asarray(kwargs.pop('X'), dtype=np.float64)
+                self.sdr_bound = kwargs.pop('bound', None)
+                if hasattr(self, 'mu'):
+                    del self.mu
+            if self.sdr_sol is None:
+                raise Exception("SDR suggest needs the lifted SDP solution: no SDP solver is available; "
+                                "pass suggest(SDR, X=...) or set qcqp.sdr_sol / qcqp.sdr_bound first.")
+            if not hasattr(self, 'mu'):
+                X = np.asarray(self.sdr_sol, dtype=np.float64)
+                self.mu = np.asarray(X[:-1, -1]).flatten()
+                if compat:   # qcqp.py:395 as written: 1-D mu => element-wise square, row-broadcast
+                    self.Sigma = X[:-1, :-1] - self.mu * self.mu.T + eps * np.eye(self.n)
+                else:        # the intended X - mu mu^T + eps I
+                    self.Sigma = X[:-1, :-1] - np.outer(self.mu, self.mu) + eps * np.eye(self.n)
+                self._sdr_factor = None
+            if R == 1 and seed is None:
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    x = np.random.multivariate_normal(self.mu, self.Sigma)   # qcqp.py:396
+                self.engine.upload(x)
+            else:
+                if self._sdr_factor is None:
+                    # the factor NumPy's multivariate_normal uses: x = mu + (xi * sqrt(s)) @ v
+                    (u, sv, v) = np.linalg.svd(self.Sigma)
+                    self._sdr_factor = np.ascontiguousarray((np.sqrt(sv)[:, None] * v).T)
+                self.engine.sdr_sample(self.mu, self._sdr_factor, R, seed=0 if seed is None else seed)
+        f0, mv = self.engine.eval()
+        return self._publish(f0, mv)
+
+    # ------------------------------------------------------------------ improve
+    def _improve(self, method, *args, **kwargs):
+        x0 = flatten_vars(self.prob.variables(), self.n)
+        if not self._resident or not np.array_equal(x0, self._assigned):
+            # the user (or another tool) wrote the variables: restart from that single point
+            self.engine.upload(x0)
+        if method == s.COORD_DESCENT:
+            num_iters = kwargs.get('num_iters', 1000)
+            viol_tol = kwargs.get('viol_tol', 1e-2)
+            tol = kwargs.get('tol', 1e-4)
+            phase1 = kwargs.get('phase1', True)
+            seed = kwargs.get('seed', None)
+            if seed is None:
+                seed = int(np.random.randint(0, 2 ** 31 - 1))
+            out = self.engine.cd_run(phase1=phase1, num_iters=num_iters, viol_tol=viol_tol, tol=tol,
+                                     seed=seed)
+            self.last_stats = out
+            return self._publish(out['f0'], out['maxviol'])
+        elif method == s.ADMM:
+            raise Exception("improve(ADMM) is not available in the HIP engine yet.")
+        elif method == s.DCCP:
+            try:
+                import dccp  # noqa: F401
+            except ImportError:
+                raise Exception("DCCP package is not installed.")
+            raise Exception("improve(DCCP) delegates to an external solver and is out of scope of the HIP engine.")
+        elif method == s.IPOPT:
+            try:
+                import pyipopt  # noqa: F401
+            except ImportError:
+                raise Exception("PyIpopt package is not installed.")
+            raise Exception("improve(IPOPT) delegates to an external solver and is out of scope of the HIP engine.")
+
+    def improve(self, method, *args, **kwargs):
+        if not isinstance(method, list):
+            methods = [method]
+        else:
+            methods = method
+        if not all([method in s.improve_methods for method in methods]):
+            raise Exception("Unknown improve method(s): ", methods)
+        if any([x is None or x.value is None for x in self.prob.variables()]):
+            self.suggest()
+        for method in methods:
+            f, v = self._improve(method, *args, **kwargs)
+        return (f, v)

@@ -90,7 +90,7 @@ struct qcqpmi_ctx {
     double *X = nullptr, *Xi = nullptr;
     double *d_f0 = nullptr, *d_mv = nullptr, *d_F = nullptr;
     int64_t *d_visits = nullptr, *d_acc = nullptr, *d_sweeps = nullptr, *d_sweeps1 = nullptr;
-    int *d_status = nullptr;
+    int *d_status = nullptr, *d_status1 = nullptr;
     uint8_t *d_flag = nullptr;
     int64_t *d_best_idx = nullptr;
     double *d_best_key = nullptr;
@@ -153,11 +153,11 @@ int prob_upload(qcqpmi_ctx *c, const T **dst, const std::vector<T> &src) {
 
 void free_population(qcqpmi_ctx *c) {
     void *ptrs[] = {c->X, c->Xi, c->d_f0, c->d_mv, c->d_F, c->d_visits, c->d_acc, c->d_sweeps,
-                    c->d_sweeps1, c->d_status, c->d_flag, c->d_stage};
+                    c->d_sweeps1, c->d_status, c->d_status1, c->d_flag, c->d_stage};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->X = c->Xi = c->d_f0 = c->d_mv = c->d_F = c->d_stage = nullptr;
     c->d_visits = c->d_acc = c->d_sweeps = c->d_sweeps1 = nullptr;
-    c->d_status = nullptr; c->d_flag = nullptr;
+    c->d_status = nullptr; c->d_status1 = nullptr; c->d_flag = nullptr;
     c->Rcap = 0; c->F_cap = 0;
 }
 
@@ -178,6 +178,7 @@ int pop_reserve(qcqpmi_ctx *c, int64_t R) {
         if ((rc = dev_alloc(c, &c->d_sweeps, Rpad))) return rc;
         if ((rc = dev_alloc(c, &c->d_sweeps1, Rpad))) return rc;
         if ((rc = dev_alloc(c, &c->d_status, Rpad))) return rc;
+        if ((rc = dev_alloc(c, &c->d_status1, Rpad))) return rc;
         if ((rc = dev_alloc(c, &c->d_flag, Rpad))) return rc;
         c->Rcap = Rpad;
     }
@@ -668,38 +669,28 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
         a.prof = c->d_prof;
     }
     bool used_lds = false;
-    std::vector<int> st((size_t)c->R);
+    // Everything below is enqueued on the context's stream without a host round trip: phase 1,
+    // evaluation, the improve_coord_descent gate, phase 2, final evaluation, result copies.
     HIPCHK(c, hipMemsetAsync(c->d_sweeps1, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_status1, 0, (size_t)c->Rpad * sizeof(int), c->stream));
     if (phase1) {
         CdArgs a1 = a;
         a1.sweeps = c->d_sweeps1;
+        a1.status = c->d_status1;
         rc = (c->maxc <= 1) ? launch_cd<1>(c, a1, true, used_lds) : launch_cd<4>(c, a1, true, used_lds);
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int64_t r = 0; r < c->R; r++)
-            if (st[(size_t)r]) {
-                if (st[(size_t)r] == -3)
-                    return fail(c, QCQPMI_EREFERENCE, "phase 1: a variable appears in no constraint (reference: ValueError: max() arg is an empty sequence, qcqp.py:117); restart %lld", (long long)r);
-                return fail(c, QCQPMI_EREFERENCE, "phase 1: unbounded feasible interval with zero objective (reference: OverflowError in np.random.uniform, utilities.py:267); restart %lld", (long long)r);
-            }
     }
     // gate of improve_coord_descent (qcqp.py:189): phase 2 only if max violation < viol_tol.
     // The evaluation also provides the phase-2 slack (qcqp.py:157) and the running objective.
     if ((rc = launch_eval(c, false))) return rc;
-    {
-        std::vector<double> mv((size_t)c->R);
-        std::vector<uint8_t> flag((size_t)c->Rpad, 0);
-        HIPCHK(c, hipMemcpyAsync(mv.data(), c->d_mv, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int64_t r = 0; r < c->R; r++) flag[(size_t)r] = (mv[(size_t)r] < viol_tol) ? 1 : 0;
-        HIPCHK(c, hipMemcpyAsync(c->d_flag, flag.data(), (size_t)c->Rpad, hipMemcpyHostToDevice, c->stream));
-        if (ran_phase2) memcpy(ran_phase2, flag.data(), (size_t)c->R);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
+    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((c->Rpad + 255) / 256)), dim3(256), 0, c->stream, c->d_mv,
+                       c->d_status1, c->d_flag, c->R, c->Rpad, viol_tol);
+    HIPCHK(c, hipGetLastError());
+    if (ran_phase2) HIPCHK(c, hipMemcpyAsync(ran_phase2, c->d_flag, (size_t)c->R, hipMemcpyDeviceToHost, c->stream));
     rc = (c->maxc <= 1) ? launch_cd<1>(c, a, false, used_lds) : launch_cd<4>(c, a, false, used_lds);
     if (rc) return rc;
     if ((rc = launch_eval(c, false))) return rc;
+    std::vector<int> st((size_t)c->R), st1((size_t)c->R);
     if (sweeps1) HIPCHK(c, hipMemcpyAsync(sweeps1, c->d_sweeps1, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     if (sweeps2) HIPCHK(c, hipMemcpyAsync(sweeps2, c->d_sweeps, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     if (visits2) HIPCHK(c, hipMemcpyAsync(visits2, c->d_visits, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
@@ -707,10 +698,16 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
     if (f0) HIPCHK(c, hipMemcpyAsync(f0, c->d_f0, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (maxviol) HIPCHK(c, hipMemcpyAsync(maxviol, c->d_mv, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st1.data(), c->d_status1, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int64_t r = 0; r < c->R; r++)
+    for (int64_t r = 0; r < c->R; r++) {
+        if (st1[(size_t)r] == -3)
+            return fail(c, QCQPMI_EREFERENCE, "phase 1: a variable appears in no constraint (reference: ValueError: max() arg is an empty sequence, qcqp.py:117); restart %lld", (long long)r);
+        if (st1[(size_t)r])
+            return fail(c, QCQPMI_EREFERENCE, "phase 1: unbounded feasible interval with zero objective (reference: OverflowError in np.random.uniform, utilities.py:267); restart %lld", (long long)r);
         if (st[(size_t)r])
             return fail(c, QCQPMI_EREFERENCE, "phase 2: the reference raises on restart %lld (code %d: unbounded interval with zero objective / NameError in OneVarQuadraticFunction.eval)", (long long)r, st[(size_t)r]);
+    }
     return 0;
 }
 

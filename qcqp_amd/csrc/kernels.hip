@@ -476,6 +476,15 @@ __global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
 #include "cd_phase2_rs.h"
 namespace qcqpmi {
 
+// gate of improve_coord_descent (qcqp.py:189): phase 2 runs only for restarts whose max violation
+// is below viol_tol (and whose phase 1 did not hit a case where the reference raises)
+__global__ void gate_kernel(const double *__restrict__ maxviol, const int *__restrict__ status1,
+                            uint8_t *__restrict__ flag, int64_t R, int64_t Rpad, double viol_tol) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= Rpad) return;
+    flag[r] = (r < R && status1[r] == 0 && maxviol[r] < viol_tol) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------- best selection
 
 // key = (int(maxviol / tol), f0, index): lexicographic minimum, ties -> lowest index.

@@ -1,0 +1,95 @@
+"""GPU tests of the drop-in facade (qcqp_amd.QCQP) against the API-level golden vectors."""
+import numpy as np
+import pytest
+
+from conftest import funcs_from_npz, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def handler(funcs, maximize=False):
+    from qcqp_amd import QCQP, Problem
+    return QCQP(Problem.from_minimize_form(funcs, maximize=maximize))
+
+
+def test_constants_and_star_import():
+    ns = {}
+    exec('from qcqp_amd import *', ns)
+    for name in ['QCQP', 'RANDOM', 'SPECTRAL', 'SDR', 'COORD_DESCENT', 'ADMM', 'DCCP', 'IPOPT']:
+        assert name in ns
+
+
+def test_suggest_random_and_phase2_match_reference_api_flow():
+    """G10: np.random.seed(42); suggest(RANDOM) gives the reference's point and (f, v); phase 2 run
+    from the reference's coordinate-descent result is a fixed point with the reference's (f, v)."""
+    from qcqp_amd import RANDOM, COORD_DESCENT
+    z = load_golden('g10_api_bls10')
+    q = handler(funcs_from_npz(z))
+    np.random.seed(int(z['seed']))
+    f, v = q.suggest(RANDOM)
+    x = np.ravel(q.prob.variables()[0].value, order='F')
+    assert np.array_equal(x, z['x_rand'])
+    assert abs(f - z['fv'][0, 0]) <= 1e-12 * (1 + abs(f)) and abs(v - z['fv'][0, 1]) <= 1e-13
+    q.prob.variables()[0].value = z['x_cd'].reshape(-1, 1)
+    f, v = q.improve(COORD_DESCENT, phase1=False)
+    assert abs(f - z['fv'][1, 0]) <= 1e-9 * (1 + abs(f))
+    assert abs(v - z['fv'][1, 1]) <= 1e-12
+    assert np.max(np.abs(np.ravel(q.prob.variables()[0].value) - z['x_cd'])) < 1e-9
+
+
+@pytest.mark.parametrize('name', ['bls10', 'maxcut12'])
+def test_suggest_sdr_matches_reference_draws(name):
+    """G9: injected lifted solution, np.random.seed(7): same draws, same (f, v) incl. the sign flip
+    of maximisation problems."""
+    from qcqp_amd import SDR
+    z = load_golden('g9_sdr_' + name)
+    q = handler(funcs_from_npz(z), maximize=bool(z['maximize']))
+    np.random.seed(int(z['seed']))
+    for t in range(z['xs'].shape[1]):
+        f, v = q.suggest(SDR, X=z['X']) if t == 0 else q.suggest(SDR)
+        x = np.ravel(q.prob.variables()[0].value, order='F')
+        assert np.max(np.abs(x - z['xs'][:, t])) < 1e-12
+        assert abs(f - z['fv'][t, 0]) <= 1e-11 * (1 + abs(f))
+        assert abs(v - z['fv'][t, 1]) <= 1e-11 * (1 + abs(v))
+    assert np.max(np.abs(q.Sigma - z['Sigma'])) < 1e-15
+
+
+def test_population_flow_best_of_restarts(orc):
+    """suggest(RANDOM, num_samples=R) + improve(COORD_DESCENT): best (f, v) equals the oracle's best
+    over the same keyed starts and draws."""
+    from qcqp_amd import RANDOM, COORD_DESCENT, problems, dist
+    funcs, _, _ = problems.boolean_least_squares(40, 24, seed=8)
+    q = handler(funcs)
+    R, seed = 48, 5
+    q.suggest(RANDOM, num_samples=R, seed=seed)
+    X0 = q.population()
+    f, v = q.improve(COORD_DESCENT, seed=seed)
+    prob = orc.Problem(funcs)
+    fs, vs = [], []
+    for r in range(R):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(r)
+        x, _, _ = prob.improve_cd(X0[:, r], rng=rng)
+        fs.append(prob.eval(0, x))
+        vs.append(prob.max_violation(x))
+    key = dist.select_best_host(fs, vs, 1e-4)
+    assert q.best_index == key[2]
+    assert abs(f - key[1]) <= 1e-9 * (1 + abs(f))
+    assert np.max(np.abs(q.population_f - np.array(fs)) / (1 + np.abs(np.array(fs)))) < 1e-9
+
+
+def test_errors_mirror_reference():
+    from qcqp_amd import ADMM, SDR, problems
+    funcs, _, _ = problems.boolean_least_squares(6, 8, seed=1)
+    q = handler(funcs)
+    with pytest.raises(Exception) as ei:
+        q.suggest('nope')
+    assert 'Unknown suggest method' in str(ei.value.args[0])
+    with pytest.raises(Exception) as ei:
+        q.improve('nope')
+    assert 'Unknown improve method(s)' in str(ei.value.args[0])
+    with pytest.raises(Exception):
+        q.suggest(SDR)          # no SDP solution available
+    with pytest.raises(Exception) as ei:
+        q.improve('dccp')
+    assert 'DCCP package is not installed.' in str(ei.value)

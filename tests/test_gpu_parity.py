@@ -144,3 +144,47 @@ def test_unsupported_structure_fails_loudly(eng_mod):
     e.upload(z['X'])
     with pytest.raises(eng_mod.EngineError):
         e.cd_run()
+
+
+# ----------------------------------------------------------------------------- full-size config
+def test_full_size_headline_config(eng_mod, orc):
+    """BASELINE.json configs[1]: Boolean least squares n=1024, m=256, 4096 restarts.
+    * three restarts are checked against the oracle trajectory (the oracle needs ~15 s each);
+    * size-independent properties on all 4096: sharding invariance (a slice of the restarts run
+      alone with the matching global index offset reproduces the big run bit for bit),
+      idempotence (phase 2 from a converged point moves nothing), every restart feasible within
+      the slack phase 1 leaves, and the reported objective equals a fresh evaluation."""
+    from qcqp_amd import problems
+    n, R, seed = 1024, 4096, 2024
+    funcs, _, _ = problems.boolean_least_squares(n, 256, seed=1)
+    e = make(eng_mod, funcs)
+    e.randn(R, seed=seed)
+    X0 = e.download()
+    out = e.cd_run(seed=seed)
+    X = e.download()
+    assert out['ran_phase2'].all()
+    assert out['maxviol'].max() < 1.1e-4
+    assert np.all(np.abs(np.abs(X) - 1.0) < 1e-4)
+    f0, mv = e.eval()
+    assert np.array_equal(f0, out['f0']) and np.array_equal(mv, out['maxviol'])
+    # oracle trajectories
+    prob = orc.Problem(funcs)
+    for r in (0, 1777, 4095):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], rng=rng)
+        assert rel(X[:, r], x) < 1e-9, r
+        assert out['visits2'][r] == s2[1] and out['accepted2'][r] == s2[2]
+        assert abs(out['f0'][r] - prob.eval(0, x)) <= 1e-6 * abs(out['f0'][r])   # north-star tolerance
+    # sharding invariance: restarts [2048, 2048+512) alone, as a second "rank" would run them
+    e.randn(512, seed=seed, first_index=2048)
+    out2 = e.cd_run(seed=seed, first_index=2048)
+    X2 = e.download()
+    assert np.array_equal(X2, X[:, 2048:2560])
+    assert np.array_equal(out2['f0'], out['f0'][2048:2560])
+    # idempotence of phase 2
+    e.upload(X[:, :256])
+    out3 = e.cd_run(phase1=False)
+    assert np.array_equal(e.download(), X[:, :256])
+    assert out3['accepted2'].sum() == 0 and np.all(out3['visits2'] == n)
+    # best-of-population rule
