@@ -24,6 +24,21 @@ sys.path.insert(0, REPO)
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (AMD datasheet); see DESIGN.md
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the phase-2 kernel from the committed PMC passes (profiles/, produced by
+    tools/profile_round.sh + tools/summarize_profile.py on the same workload); None if absent."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(REPO, 'profiles'))) if os.path.isdir(os.path.join(REPO, 'profiles')) else []:
+        if name.endswith('_summary.json'):
+            try:
+                d = json.load(open(os.path.join(REPO, 'profiles', name)))
+                if 'cd_phase2_hbm_bytes_per_launch' in d:
+                    best = (d['cd_phase2_hbm_bytes_per_launch'], name)
+            except Exception:
+                pass
+    return best
+
+
 def cpu_baseline(funcs, n, restarts, seed):
     """The oracle (plain-C restatement of the reference algorithm, 1 core) on a bounded sample of
     the same workload: `restarts` restarts of the same problem from the same keyed starts."""
@@ -99,6 +114,7 @@ def main():
 
     if rank == 0:
         achieved = (p2_flops / 1e12) / (p2_ms / 1e3) if p2_ms > 0 else 0.0
+        traffic = profiled_traffic()
         res = {
             'metric': 'restarts x coord-sweeps / sec (improve COORD_DESCENT, phase 1 + phase 2 to convergence)',
             'value': sweeps_all / dt,
@@ -117,9 +133,11 @@ def main():
                        'restarts_per_gpu': R, 'num_iters': 1000, 'viol_tol': 1e-2, 'tol': 1e-4,
                        'sharding': 'restarts by global index, replicas of P'},
             'best': {'objective': best[1], 'max_violation': best[2], 'global_restart_index': best[0]},
-            'roofline': {'bound': 'mfma', 'kernel': 'cd_phase2_kernel', 'achieved': achieved,
+            'roofline': {'bound': 'mfma', 'kernel': 'cd_phase2_rs_kernel', 'achieved': achieved,
                          'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / FP64_PEAK_TFLOPS,
+                         'traffic': traffic[0] if traffic else None,
+                         'traffic_source': ('profiles/' + traffic[1]) if traffic else None,
                          'algorithmic_flops_per_restart_sweep': 2.0 * n * n,
                          'kernel_ms_per_launch': p2_ms / max(args.steps, 1)},
         }

@@ -220,7 +220,7 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
     dim3 grid((unsigned)(c->Rpad / 16)), block(256);
     if (phase1) {
         tic(c, 1);
-        hipLaunchKernelGGL(cd_phase1_sep_kernel<MAXC>, grid, block, 0, c->stream, a1);
+        hipLaunchKernelGGL(cd_phase1_sep_kernel<MAXC>, grid, dim3(P1_THREADS), 0, c->stream, a1);
         toc(c, 1);
         HIPCHK(c, hipGetLastError());
         return 0;

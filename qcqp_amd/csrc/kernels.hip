@@ -206,10 +206,13 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a) {
 // Separable constraints: a coordinate's local violation and its update depend on x_i alone
 // (objective is identically zero in phase 1, qcqp.py:114), so a sweep is element-wise; the
 // sweep loop, the per-restart max-violation reduction and the termination tests stay in-kernel.
+// 1024 threads = 64 coordinate slots x 16 restarts: 4 waves per SIMD hide the latency of the
+// long scalar dependency chains (sqrt / divide / Philox) of the bisection.
+constexpr int P1_THREADS = 1024, P1_SLOTS = P1_THREADS / 16;
 template <int MAXC>
-__global__ __launch_bounds__(256) void cd_phase1_sep_kernel(CdArgs a) {
-    __shared__ double vred[256];
-    __shared__ int ured[256];
+__global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
+    __shared__ double vred[P1_THREADS];
+    __shared__ int ured[P1_THREADS];
     __shared__ double viol_last[16];
     __shared__ int fin[16];
     __shared__ int nlive;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void cd_phase1_sep_kernel(CdArgs a) {
         int upd = 0;
         if (run) {
             if (slot == 0) sweeps_done++;
-            for (int64_t i = slot; i < P.n; i += 16) {
+            for (int64_t i = slot; i < P.n; i += P1_SLOTS) {
                 const int e0 = P.cptr[i], mf = P.cptr[i + 1] - e0;
                 double xi = Xs[i * 16 + r];
                 if (mf == 0) { my_status = -3; continue; }  // python: max([]) -> ValueError
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void cd_phase1_sep_kernel(CdArgs a) {
         if (tid < 16 && !fin[tid]) {
             double v = -QM_INF;
             int u = 0;
-            for (int g = 0; g < 16; g++) { double w = vred[g * 16 + tid]; v = w > v ? w : v; u |= ured[g * 16 + tid]; }
+            for (int g = 0; g < P1_SLOTS; g++) { double w = vred[g * 16 + tid]; v = w > v ? w : v; u |= ured[g * 16 + tid]; }
             viol_last[tid] = v;
             // done when feasible enough (qcqp.py:111); a sweep without any update is a fixed
             // point of the (deterministic-in-feasibility) map, so later sweeps cannot change x.
@@ -294,13 +297,13 @@ __global__ __launch_bounds__(256) void cd_phase1_sep_kernel(CdArgs a) {
     }
     // per-restart outputs
     vred[tid] = (double)my_visits; ured[tid] = (int)my_acc;
-    __shared__ int sred[256];
+    __shared__ int sred[P1_THREADS];
     sred[tid] = my_status;
     __syncthreads();
     if (tid < 16 && tile * 16 + tid < a.R) {
         int64_t vis = 0, acc = 0;
         int st = 0;
-        for (int g = 0; g < 16; g++) { vis += (int64_t)vred[g * 16 + tid]; acc += ured[g * 16 + tid]; if (sred[g * 16 + tid]) st = sred[g * 16 + tid]; }
+        for (int g = 0; g < P1_SLOTS; g++) { vis += (int64_t)vred[g * 16 + tid]; acc += ured[g * 16 + tid]; if (sred[g * 16 + tid]) st = sred[g * 16 + tid]; }
         int64_t g = tile * 16 + tid;
         a.visits[g] = vis; a.accepted[g] = acc; a.status[g] = st;
         a.flag[g] = (viol_last[tid] < a.viol_tol) ? 1 : 0;

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = os.path.join(REPO, 'gpurun_out', 'prof_' + tag)
+dst = os.path.join(REPO, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+
+def find(sub, suffix):
+    hits = glob.glob(os.path.join(src, sub, '**', '*' + suffix), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    return name.split('(')[0].replace('void ', '').replace('qcqpmi::', '')[:60]
+
+
+out = {'tag': tag}
+# ---- kernel statistics
+ks = find('stats', 'kernel_stats.csv')
+lines = []
+if ks:
+    rows = list(csv.DictReader(open(ks)))
+    lines.append('| kernel | calls | total ms | avg us | min us | max us | % |')
+    lines.append('|---|---|---|---|---|---|---|')
+    for r in rows:
+        lines.append('| %s | %s | %.3f | %.1f | %.1f | %.1f | %.1f |' % (
+            short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3,
+            float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, float(r['Percentage'])))
+        if 'cd_phase2' in r['Name']:
+            out['cd_phase2_avg_ms'] = float(r['AverageNs']) / 1e6
+            out['cd_phase2_calls'] = int(r['Calls'])
+    open(os.path.join(dst, tag + '_kernel_stats.csv'), 'w').write(open(ks).read())
+
+
+def pmc(sub, counter):
+    f = find(sub, 'counter_collection.csv')
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    if not f:
+        return agg
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == counter:
+            a = agg[short(r['Kernel_Name'])]
+            a[0] += float(r['Counter_Value'])
+            a[1] += 1
+    return agg
+
+
+fetch, write = pmc('fetch', 'FETCH_SIZE'), pmc('write', 'WRITE_SIZE')
+hit, miss = pmc('l2', 'TCC_HIT_sum'), pmc('l2', 'TCC_MISS_sum')
+lines.append('')
+lines.append('| kernel | launches | FETCH_SIZE KB/launch (raw) | WRITE_SIZE KB/launch | HBM bytes/launch (2*FETCH + WRITE)*1024 | L2 hit rate |')
+lines.append('|---|---|---|---|---|---|')
+for k in sorted(set(fetch) | set(write)):
+    fe = fetch[k][0] / max(fetch[k][1], 1)
+    wr = write[k][0] / max(write[k][1], 1)
+    h, m = hit[k][0], miss[k][0]
+    hbm = (2.0 * fe + wr) * 1024.0
+    lines.append('| %s | %d | %.1f | %.1f | %.3e | %s |' % (k, fetch[k][1], fe, wr, hbm,
+                                                          ('%.3f' % (h / (h + m))) if h + m else 'n/a'))
+    if 'cd_phase2' in k:
+        out['cd_phase2_hbm_bytes_per_launch'] = hbm
+        out['cd_phase2_fetch_kb_raw'] = fe
+        out['cd_phase2_write_kb'] = wr
+        out['cd_phase2_l2_hit_rate'] = h / (h + m) if h + m else None
+bj = os.path.join(src, 'bench_under_profiler.json')
+if os.path.exists(bj) and os.path.getsize(bj):
+    out['bench_under_profiler'] = json.load(open(bj))
+hdr = ['# rocprofv3 summary %s' % tag, '',
+       'Command: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline` (tools/profile_round.sh).',
+       'Pass 1 `--kernel-trace --stats`; passes 2-4 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc TCC_HIT_sum TCC_MISS_sum`',
+       '(separate runs, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled (gfx950 reports half the bytes of',
+       'wide coalesced reads); WRITE_SIZE is taken as is (uncalibrated).', '']
+open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(hdr + lines) + '\n')
+json.dump(out, open(os.path.join(dst, tag + '_summary.json'), 'w'), indent=1, sort_keys=True)
+print('\n'.join(lines))
+print(json.dumps(out)[:600])
