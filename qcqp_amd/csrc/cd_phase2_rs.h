@@ -3,24 +3,26 @@
 // class, K == 1, MAXC == 1) and the diagonal of P0 is all positive (FAST == 1, convex scalar
 // objective) or all zero (FAST == 2, linear scalar objective, e.g. MAXCUT).
 //
-// One workgroup = 4 waves (one per SIMD, 512 VGPRs each) owns a tile of 16 restarts and walks the
-// blocks of 16 coordinates:
+// One workgroup = 8 waves owns a tile of 16 restarts and walks the blocks of 16 coordinates:
 //
 //   wave 0      ("chain")  visits the 16 coordinates of block b in order, lane = restart
 //                          (Gauss-Seidel: each accepted move is folded into the rest of the block
 //                          through the 16x16 diagonal block of P0);
-//   waves 1..3  ("mfma")   meanwhile compute, for the NEXT block b', the partial products
+//   waves 1,2,3,5,6,7 ("mfma", two per SIMD) meanwhile compute, for the NEXT block b', the partial products
 //                          G' = P0[I_b', k] X[k]  over all k outside block b on
-//                          v_mfma_f64_16x16x4_f64 (K split 3 ways) -- rows of X outside block b do
+//                          v_mfma_f64_16x16x4_f64 (K split 6 ways) -- rows of X outside block b do
 //                          not change while the chain works on block b.  The A fragments do not
 //                          depend on X at all: they are fetched into registers a whole iteration
 //                          ahead (16-byte loads from a pair-packed copy of P0), double-buffered;
 //   then wave 0 adds the 4 missing k-steps (the freshly updated rows I_b) with 4 MFMAs, sums the
-//   3 partial tiles in a fixed order and starts the next chain.
+//   6 partial tiles in a fixed order and starts the next chain.  Wave 4 idles: it shares the
+//   chain wave's SIMD.
 //
 // fp64 MFMA competes with fp64 VALU for a SIMD's double-precision pipe (measured: +54 % chain
-// time with an MFMA wave beside it), so the chain keeps its SIMD for itself; one wave per SIMD
-// already saturates the fp64 matrix pipe (64-cycle issue = 64-cycle dependent latency).
+// time with an MFMA wave beside it), so the chain keeps its SIMD for itself.  Any instruction
+// between two fp64 MFMAs of one wave delays the next MFMA by its issue time (measured 89 instead
+// of 64 cycles per MFMA with loads in the stream), hence TWO mfma waves per SIMD: one wave's loads
+// and LDS reads overlap the other's matrix work.
 //
 // Per block the critical path is   chain (16 dependent steps)  +  fix-up  +  2 barriers;
 // the MFMA work (2 n16^2 flops per restart-sweep, the roofline term) hides behind the chain.
@@ -52,8 +54,8 @@ __device__ inline v4d_ mfma_range(const double *__restrict__ Ab, XPtr Xs, int kk
     return acc;
 }
 
-constexpr int RS_NMW = 3;    // mfma waves
-constexpr int RS_PFU = 22;   // units (blocks of 16 coordinates) whose A fragments live in registers
+constexpr int RS_NMW = 6;    // mfma waves: 1,2,3,5,6,7 (two per SIMD; wave 4 shares the chain's SIMD and idles)
+constexpr int RS_PFU = 11;   // units (blocks of 16 coordinates) whose A fragments live in registers
 
 // ------------------------------------------------------------------------------ mfma role
 // Work is dealt in UNITS of 4 k-steps (= one block of 16 coordinates).  For the product of block
@@ -72,7 +74,11 @@ __device__ inline const v2d_ *rs_unit_ptr(const double *__restrict__ Apack2, int
     j = j < 0 ? 0 : j;                  // every load is unconditional so that s_waitcnt can count them
     int bb = j < hb ? j : j + 1;
     bb = bb < NB ? bb : NB - 1;
-    return reinterpret_cast<const v2d_ *>(Apack2) + ((int64_t)bn * (KS / 2) + 2 * bb) * 64 + lane;
+    // wave-uniform pointer; the caller adds the lane LAST so that the loads use the
+    // scalar-base + 32-bit lane offset form (no VALU address arithmetic between MFMAs: fp64 MFMA
+    // and VALU share the SIMD's pipe)
+    (void)lane;
+    return reinterpret_cast<const v2d_ *>(Apack2) + ((int64_t)bn * (KS / 2) + 2 * bb) * 64;
 }
 
 __device__ inline void rs_prefetch(v2d_ (&ar)[2 * RS_PFU], const double *__restrict__ Apack2, int NB,
@@ -80,8 +86,8 @@ __device__ inline void rs_prefetch(v2d_ (&ar)[2 * RS_PFU], const double *__restr
 #pragma unroll
     for (int U = 0; U < RS_PFU; U++) {
         const v2d_ *ap = rs_unit_ptr(Apack2, NB, KS, mw, lane, bn, bx, U);
-        ar[2 * U] = ap[0];
-        ar[2 * U + 1] = ap[64];
+        ar[2 * U] = ap[(unsigned)lane];
+        ar[2 * U + 1] = ap[64u + (unsigned)lane];
     }
 }
 
@@ -122,8 +128,8 @@ __device__ inline v4d_ rs_compute(v2d_ (&ar)[2 * RS_PFU], const double *__restri
         }
         {   // unconditional: s_waitcnt can then count exactly how many loads are younger
             const v2d_ *ap = rs_unit_ptr(Apack2, NB, KS, mw, lane, bn2, bx2, U);
-            ar[2 * U] = ap[0];
-            ar[2 * U + 1] = ap[64];
+            ar[2 * U] = ap[(unsigned)lane];
+            ar[2 * U + 1] = ap[64u + (unsigned)lane];
         }
     }
     acc = (acc + acc1) + (acc2 + acc3);
@@ -140,7 +146,7 @@ __device__ inline v4d_ rs_compute(v2d_ (&ar)[2 * RS_PFU], const double *__restri
 // ------------------------------------------------------------------------------------ kernel
 
 template <bool XLDS, int FAST>
-__global__ __launch_bounds__(256) void cd_phase2_rs_kernel(CdArgs a, const double *__restrict__ Apack,
+__global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const double *__restrict__ Apack,
                                                            const double *__restrict__ Apack2,
                                                            const double *__restrict__ P0,
                                                            const double *__restrict__ q0,
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256) void cd_phase2_rs_kernel(CdArgs a, const doubl
 
     double *Xs = XLDS ? Xl : Xg;
     if (XLDS)
-        for (int64_t idx = tid; idx < n16 * 16; idx += 256) Xl[idx] = Xg[idx];
+        for (int64_t idx = tid; idx < n16 * 16; idx += 512) Xl[idx] = Xg[idx];
     if (tid < 16) {
         const int64_t g = tile * 16 + tid;
         slk[tid] = (g < a.R) ? a.slack[g] : 0.0;
@@ -189,26 +195,33 @@ __global__ __launch_bounds__(256) void cd_phase2_rs_kernel(CdArgs a, const doubl
 
     const int64_t gmax = a.num_iters * (int64_t)NB;
 
-    if (wave != 0) {
+    if (wave == 4) {
+        // ============================================================================ idle role
+        // wave 4 lands on the chain wave's SIMD (waves w and w+4 of a workgroup share a SIMD): it
+        // only keeps the barrier protocol.
+        for (int64_t g = 0;; g++) {
+            __syncthreads();
+            if (*done || g >= gmax) break;
+            __syncthreads();
+        }
+    } else if (wave != 0) {
         // =========================================================================== mfma role
-        const int mw = wave - 1;
-        const int st = tid - 64;   // 0..191: staging slot of this thread
+        const int mw = wave < 4 ? wave - 1 : wave - 2;
+        const int st = wave < 4 ? tid - 64 : tid - 128;   // 0..383: staging slot of this thread
         v2d_ arP[2 * RS_PFU];
         long long qc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
 #define QTICK(slot) if (a.prof && wave == 1) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); qc[slot] += now_ - tq; tq = now_; }
         // staging of the small operands of a block: diagonal block of P0 (256 entries over 192
         // threads) and q/2, 1/P_ii of its 16 coordinates (threads 0..15).  Loads are issued early,
         // the LDS stores come after the matrix work.
-        double st_d0 = 0.0, st_d1 = 0.0, st_q = 0.0, st_r = 0.0;
+        double st_d0 = 0.0, st_q = 0.0, st_r = 0.0;
         auto stage_load = [&](int bn) {
-            st_d0 = P0[(16 * (int64_t)bn + (st >> 4)) * n16 + 16 * bn + (st & 15)];
-            if (st < 64) st_d1 = P0[(16 * (int64_t)bn + 12 + (st >> 4)) * n16 + 16 * bn + (st & 15)];
+            if (st < 256) st_d0 = P0[(16 * (int64_t)bn + (st >> 4)) * n16 + 16 * bn + (st & 15)];
             if (st < 16) { st_q = q0[16 * (int64_t)bn + st]; st_r = rcp2d[16 * (int64_t)bn + st]; }
         };
         auto stage_store = [&](int buf) {
             double *Dblk = Dblk2 + buf * 256;
-            Dblk[st] = st_d0;
-            if (st < 64) Dblk[192 + st] = st_d1;
+            if (st < 256) Dblk[st] = st_d0;
             if (st < 16) { hqb2[buf * 16 + st] = 0.5 * st_q; rtb2[buf * 16 + st] = st_r + st_r; }
         };
         auto store_part = [&](const v4d_ &acc) {
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(256) void cd_phase2_rs_kernel(CdArgs a, const doubl
     }
     __syncthreads();
     if (XLDS)
-        for (int64_t idx = tid; idx < n16 * 16; idx += 256) Xg[idx] = Xl[idx];
+        for (int64_t idx = tid; idx < n16 * 16; idx += 512) Xg[idx] = Xl[idx];
 }
 
 }  // namespace qcqpmi

@@ -41,5 +41,5 @@ names = (['mfma', 'stage', 'barrier1', 'sequential', 'barrier2'] if generic
 for k in range(len(names)):
     print('%-18s %10.0f cycles/block' % (names[k], s[k] / max(s[5], 1)))
 if not generic:
-    for k, nm in enumerate(['mfma wave: store+b1 wait', 'mfma wave: prefetch issue', 'mfma wave: b2 wait', 'mfma wave: mfma loop']):
+    for k, nm in enumerate(['mfma wave: store+b1 wait', 'mfma wave: prefetch issue', 'mfma wave: b2 wait', 'mfma wave: B preload + mfma', 'mfma wave:   of which B preload']):
         print('%-26s %10.0f cycles/block' % (nm, s[8 + k] / max(s[5], 1)))
