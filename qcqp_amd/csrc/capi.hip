@@ -228,7 +228,7 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
     const DevProblem &dp = c->dp;
     // role-split pipelined kernel for the single-class Boolean / box families
     if (MAXC == 1 && c->K == 1 && (c->objclass == 1 || c->objclass == 2) && !c->force_generic) {
-        const size_t rs_common = (size_t)(6 * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8) * sizeof(double);
+        const size_t rs_common = (size_t)(2 * 6 * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8) * sizeof(double);
         const size_t rs_with_x = rs_common + (size_t)c->n16 * 16 * sizeof(double);
         used_lds = rs_with_x <= 160 * 1024;
         const size_t rs_lds = used_lds ? rs_with_x : rs_common;

@@ -15,7 +15,8 @@
 //                          depend on X at all: they are fetched into registers a whole iteration
 //                          ahead (16-byte loads from a pair-packed copy of P0), double-buffered;
 //   then wave 0 adds the 4 missing k-steps (the freshly updated rows I_b) with 4 MFMAs, sums the
-//   6 partial tiles in a fixed order and starts the next chain.  Wave 4 idles: it shares the
+//   6 partial tiles in a fixed order and starts the next chain.  Partial tiles and the staged
+//   small operands are double-buffered by block parity: ONE s_barrier per block.  Wave 4 idles: it shares the
 //   chain wave's SIMD.
 //
 // fp64 MFMA competes with fp64 VALU for a SIMD's double-precision pipe (measured: +54 % chain
@@ -24,7 +25,7 @@
 // of 64 cycles per MFMA with loads in the stream), hence TWO mfma waves per SIMD: one wave's loads
 // and LDS reads overlap the other's matrix work.
 //
-// Per block the critical path is   chain (16 dependent steps)  +  fix-up  +  2 barriers;
+// Per block the critical path is   max(fix-up + chain (16 dependent steps), mfma)  +  1 barrier;
 // the MFMA work (2 n16^2 flops per restart-sweep, the roofline term) hides behind the chain.
 //
 // Arithmetic of the fast path: vertex xv = x_i - (G_i + q_i/2) / P_ii  (exact algebra for the
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
     // ---- dynamic LDS carve-up
     double *sp = smem;
     double *Xl = sp; if (XLDS) sp += n16 * 16;
-    double *part = sp; sp += RS_NMW * 256;   // partial G tiles of the mfma waves, [c][r] layout
+    double *part2 = sp; sp += 2 * RS_NMW * 256;   // partial G tiles of the mfma waves, [c][r] layout, double-buffered
     double *Gsc = sp; sp += 256;             // complete G (+ q/2) of the current block, [c][r]
     double *Dblk2 = sp; sp += 2 * 256;       // diagonal block of P0, double-buffered by block parity
     double *hqb2 = sp; sp += 2 * 16;         // q0 / 2
@@ -202,7 +203,6 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
         for (int64_t g = 0;; g++) {
             __syncthreads();
             if (*done || g >= gmax) break;
-            __syncthreads();
         }
     } else if (wave != 0) {
         // =========================================================================== mfma role
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
             if (st < 256) Dblk[st] = st_d0;
             if (st < 16) { hqb2[buf * 16 + st] = 0.5 * st_q; rtb2[buf * 16 + st] = st_r + st_r; }
         };
-        auto store_part = [&](const v4d_ &acc) {
+        auto store_part = [&](const v4d_ &acc, int buf) {
+            double *part = part2 + buf * RS_NMW * 256;
 #pragma unroll
             for (int v = 0; v < 4; v++) part[mw * 256 + ((lane >> 4) + 4 * v) * 16 + (lane & 15)] = acc[v];
         };
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
         stage_load(0);
         {
             v4d_ acc = rs_compute(arP, Apack, Apack2, Xs, NB, KS, mw, lane, 0, -1, 1 % NB, 0, 0);
-            store_part(acc);
+            store_part(acc, 0);
             stage_store(0);
         }
         if (a.prof) tq = (long long)__builtin_amdgcn_s_memtime();
@@ -247,12 +248,11 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
             if (*done || g >= gmax) break;                                            \
             stage_load((b + 1) % NB);                                                 \
             QTICK(1)                                                                  \
-            __syncthreads();                                                          \
             QTICK(2)                                                                  \
             v4d_ acc = {0.0, 0.0, 0.0, 0.0};                                          \
             if (!(a.dbg & 1)) acc = rs_compute(arP, Apack, Apack2, Xs, NB, KS, mw, lane, (b + 1) % NB, b, (b + 2) % NB, (b + 1) % NB, a.dbg); \
             QTICK(3)                                                                  \
-            store_part(acc);                                                          \
+            store_part(acc, (int)((g + 1) & 1));                                      \
             stage_store((int)((g + 1) & 1));                                          \
             g++;                                                                      \
         }
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
             const int bprev = (g > 0) ? (int)((g - 1) % NB) : -1;
             const int cur = (int)(g & 1);
             const double *Dblk = Dblk2 + cur * 256, *hqb = hqb2 + cur * 16, *rtb = rtb2 + cur * 16;
+            const double *part = part2 + cur * RS_NMW * 256;
             PROF_TICK(0)
             __syncthreads();                  // (1) part/Dblk/hq/rt of block b and X rows of bprev are ready
             PROF_TICK(1)
@@ -328,7 +329,6 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                 if (lane < 16 && b == 0 && !S.conv) S.sweeps++;
             }
             PROF_TICK(2)
-            __syncthreads();                  // (2) block b is in registers: part may be rewritten
             PROF_TICK(3)
             {   // A fragments for the fix-up of the NEXT block: k-steps of this block
                 const int bn = (b + 1) % NB;
@@ -346,19 +346,27 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
 #pragma unroll
                 for (int c = 0; c < 16; c++) xn_[c] = xb[c];
                 // row c of the diagonal block (wave-uniform LDS broadcast reads), fetched one step ahead
-                double drow[16], t2 = Dblk[0], rt = rtb[0];
+                // into ping-pong register sets (no copies).  The base address is laundered through
+                // a VGPR so that every read is `ds_read base, offset:imm` instead of one
+                // s_add + v_mov per read.
+                int vzero;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+                const double *Dv = Dblk + vzero, *rtv = rtb + vzero;
+                double dr[2][16], t2v[2], rv[2];
+                t2v[0] = Dv[0];
+                rv[0] = rtv[0];
 #pragma unroll
-                for (int c2 = 1; c2 < 16; c2++) drow[c2] = Dblk[c2];
+                for (int c2 = 1; c2 < 16; c2++) dr[0][c2] = Dv[c2];
 #pragma unroll
                 for (int c = 0; c < 16; c++) {
                     if (c >= cmax) continue;   // wave-uniform
-                    double dnext[16], t2n = 0.0, rtn = 0.0;
                     if (c + 1 < 16) {
-                        t2n = Dblk[(c + 1) * 16 + (c + 1)];
-                        rtn = rtb[c + 1];
+                        t2v[(c + 1) & 1] = Dv[(c + 1) * 16 + (c + 1)];
+                        rv[(c + 1) & 1] = rtv[c + 1];
 #pragma unroll
-                        for (int c2 = c + 2; c2 < 16; c2++) dnext[c2] = Dblk[(c + 1) * 16 + c2];
+                        for (int c2 = c + 2; c2 < 16; c2++) dr[(c + 1) & 1][c2] = Dv[(c + 1) * 16 + c2];
                     }
+                    const double t2 = t2v[c & 1], rt = rv[c & 1];
                     const double xi = xb[c];
                     const double g2 = gb[c];                      // G_i + q_i / 2  (includes P_ii x_i)
                     double pick;
@@ -386,11 +394,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                     accn += moved ? 1 : 0;
                     upd = moved ? 0 : upd + 1;
 #pragma unroll
-                    for (int c2 = c + 1; c2 < 16; c2++) gb[c2] = __builtin_fma(drow[c2], delta, gb[c2]);
-#pragma unroll
-                    for (int c2 = c + 2; c2 < 16; c2++) drow[c2] = dnext[c2];
-                    t2 = t2n;
-                    rt = rtn;
+                    for (int c2 = c + 1; c2 < 16; c2++) gb[c2] = __builtin_fma(dr[c & 1][c2], delta, gb[c2]);
                 }
                 redo = act && U.n > 0 && (redo || U.slow != 0);
                 if (__builtin_amdgcn_ballot_w64(redo) == 0ull) {

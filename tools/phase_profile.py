@@ -37,7 +37,7 @@ blocks = s[5] / tiles
 print('blocks per tile', blocks, '= sweeps', blocks / (n / 16))
 print('generic-path blocks', s[6], 'of', s[5])
 names = (['mfma', 'stage', 'barrier1', 'sequential', 'barrier2'] if generic
-         else ['chain', 'barrier1 wait', 'fix-up + preload', 'barrier2 wait'])
+         else ['chain', 'barrier wait', 'fix-up + preload', '-'])
 for k in range(len(names)):
     print('%-18s %10.0f cycles/block' % (names[k], s[k] / max(s[5], 1)))
 if not generic:
