@@ -104,6 +104,19 @@ int qcqpmi_cd_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double viol_to
                   int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
                   double *maxviol);
 
+/* ---- improve(ADMM) on the resident population (improve_admm qcqp.py:254-285; admm_phase1 :195-212;
+ * admm_phase2 :215-251; onecons_qcqp utilities.py:149-196).  The host supplies what the reference
+ * obtains from LAPACK / SuperLU: the eigendecomposition of every constraint matrix (lmb: m x n,
+ * Q: m x n x n, NumPy eigh layout: Q[k][:, j] = eigenvector j; cached on the context like f.eigh,
+ * utilities.py:160-162) and, for phase 2, Minv = (2 (P0 + rho m I))^-1 (n x n) in place of the
+ * SuperLU factorisation of qcqp.py:224-227.  rho must already be validated / chosen by the caller
+ * (qcqp.py:261-278).  Outputs (R entries each, may be NULL): iterations of phase 1 / phase 2, objective
+ * and max violation of the returned points. */
+int qcqpmi_admm_set_eig(qcqpmi_ctx *ctx, const double *lmb, const double *Q);
+int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, double viol_lim,
+                    double rho, const double *Minv, int64_t *iters1, int64_t *iters2, double *f0,
+                    double *maxviol);
+
 /* ---- QCQPForm.better ordering over the population (utilities.py:135-146):
  * lexicographic minimum of (int(maxviol/tol), f0), ties -> lowest index.  Evaluates the
  * population if needed.  best_x (n doubles) may be NULL. */
@@ -111,7 +124,7 @@ int qcqpmi_select_best(qcqpmi_ctx *ctx, double tol, int64_t *best_index, double 
                        double *best_maxviol, double *best_x);
 
 /* ---- timing of the hot kernels (HIP events on the context's stream) ---------------------
- * which: 0 = eval, 1 = cd phase 1, 2 = cd phase 2, 3 = sdr sampling.  Returns the duration of
+ * which: 0 = eval, 1 = cd phase 1, 2 = cd phase 2, 3 = sdr sampling, 4 = admm secular kernel.  Returns the duration of
  * the most recent launch of that kernel in milliseconds. */
 int qcqpmi_last_kernel_ms(qcqpmi_ctx *ctx, int which, double *ms);
 int qcqpmi_sync(qcqpmi_ctx *ctx);

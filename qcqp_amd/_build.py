@@ -6,7 +6,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libqcqp_mi.so')
-SOURCES = ['capi.hip', 'kernels.hip', 'kernels.h', 'onevar.h', 'philox.h']
+SOURCES = ['capi.hip', 'capi_admm.inc', 'kernels.hip', 'kernels.h', 'onevar.h', 'philox.h', 'cd_phase2.h',
+           'cd_phase2_rs.h', 'admm.h']
 
 
 def needs_build():

@@ -202,7 +202,7 @@ class QCQP(object):
             self.last_stats = out
             return self._publish(out['f0'], out['maxviol'])
         elif method == s.ADMM:
-            raise Exception("improve(ADMM) is not available in the HIP engine yet.")
+            return self._improve_admm(*args, **kwargs)
         elif method == s.DCCP:
             try:
                 import dccp  # noqa: F401
@@ -215,6 +215,45 @@ class QCQP(object):
             except ImportError:
                 raise Exception("PyIpopt package is not installed.")
             raise Exception("improve(IPOPT) delegates to an external solver and is out of scope of the HIP engine.")
+
+    def _improve_admm(self, *args, **kwargs):
+        """improve_admm (qcqp.py:254-285): kwargs, rho check / auto-rho and the LAPACK work stay on
+        the host exactly like in the reference; the iterations run on the GPU."""
+        form = self.qcqp_form
+        num_iters = kwargs.get('num_iters', 1000)
+        viol_lim = kwargs.get('viol_lim', 1e4)
+        tol = kwargs.get('tol', 1e-2)
+        rho = kwargs.get('rho', None)
+        phase1 = kwargs.get('phase1', True)
+        P0 = np.asarray(form.f0.P.todense()) if hasattr(form.f0.P, 'todense') else np.asarray(form.f0.P)
+        lmb0 = np.linalg.eigh(P0)[0]
+        lmb_min = np.min(lmb0)
+        if rho is not None:
+            if lmb_min + form.m * rho < 0:
+                raise Exception("rho parameter is too small, need at least %.3f." % rho)
+        else:
+            if lmb_min < 0:
+                rho = 2. * (1. - lmb_min) / form.m
+            else:
+                rho = 1. / form.m
+            rho *= 50.
+        if not getattr(self, '_eig_uploaded', False):
+            lm = np.zeros((form.m, form.n))
+            Q = np.zeros((form.m, form.n, form.n))
+            for k, f in enumerate(form.fs):
+                if f.eigh is None:   # cached like utilities.py:160-162
+                    Pk = np.asarray(f.P.todense()) if hasattr(f.P, 'todense') else np.asarray(f.P)
+                    f.eigh = np.linalg.eigh((Pk + Pk.T) / 2.)
+                lm[k], Q[k] = f.eigh
+            self.engine.admm_set_eig(lm, Q)
+            self._eig_uploaded = True
+        if form.rho != rho or form.z_solver is None:
+            form.rho = rho
+            form.z_solver = np.linalg.inv(2. * (P0 + rho * form.m * np.eye(form.n)))   # qcqp.py:224-227
+        out = self.engine.admm_run(rho, form.z_solver, phase1=phase1, num_iters=num_iters, tol=tol,
+                                   viol_lim=viol_lim)
+        self.last_stats = out
+        return self._publish(out['f0'], out['maxviol'])
 
     def improve(self, method, *args, **kwargs):
         if not isinstance(method, list):

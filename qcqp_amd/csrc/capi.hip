@@ -14,6 +14,7 @@
 
 #include "../../include/qcqp_mi.h"
 #include "kernels.hip"
+#include "admm.h"
 
 using namespace qcqpmi;
 
@@ -99,7 +100,11 @@ struct qcqpmi_ctx {
     bool evaluated = false;
     // SDR factor
     double *d_Fpack = nullptr, *d_Frow = nullptr, *d_mu = nullptr;
-    Timer timers[4];
+    Timer timers[5];
+    // ADMM: stacked eigenvectors W = [Q_1 ... Q_m] (n x mn col-major), eigenvalues, Q^T q, brackets
+    double *ad_W = nullptr, *ad_lam = nullptr, *ad_qhat = nullptr, *ad_rk = nullptr, *ad_slo = nullptr, *ad_ehi = nullptr, *ad_Minv = nullptr;
+    int *ad_relop = nullptr;
+    void *rb_handle = nullptr;
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -111,6 +116,8 @@ struct qcqpmi_ctx {
 };
 
 namespace {
+
+void admm_free(qcqpmi_ctx *c);
 
 int fail(qcqpmi_ctx *c, int code, const char *fmt, ...) {
     char buf[1024];
@@ -323,7 +330,7 @@ int qcqpmi_ctx_create(qcqpmi_ctx **out, int64_t n, int64_t m, int device) {
     c->quads.resize((size_t)m + 1);
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; i++) {
+    for (int i = 0; i < 5 && e == hipSuccess; i++) {
         e = hipEventCreate(&c->timers[i].beg);
         if (e == hipSuccess) e = hipEventCreate(&c->timers[i].end);
     }
@@ -342,6 +349,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->comm);
     free_population(c);
+    admm_free(c);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -741,7 +749,7 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 }
 
 int qcqpmi_last_kernel_ms(qcqpmi_ctx *c, int which, double *ms) {
-    if (!c || which < 0 || which > 3 || !ms) return QCQPMI_EINVAL;
+    if (!c || which < 0 || which > 4 || !ms) return QCQPMI_EINVAL;
     if (!c->timers[which].valid) return fail(c, QCQPMI_ESTATE, "kernel %d has not been launched", which);
     HIPCHK(c, hipEventSynchronize(c->timers[which].end));
     float f = 0.f;
@@ -859,3 +867,5 @@ int qcqpmi_comm_select_best(qcqpmi_ctx *c, double tol, int64_t index_offset, int
 }
 
 }  // extern "C"
+
+#include "capi_admm.inc"

@@ -29,7 +29,7 @@ def device_count():
 
 
 class Engine(object):
-    KERNEL_EVAL, KERNEL_CD1, KERNEL_CD2, KERNEL_SDR = 0, 1, 2, 3
+    KERNEL_EVAL, KERNEL_CD1, KERNEL_CD2, KERNEL_SDR, KERNEL_ADMM = 0, 1, 2, 3, 4
 
     def __init__(self, form, device=0):
         self.L = _ffi.lib()
@@ -138,6 +138,25 @@ class Engine(object):
                                        float(tol), int(seed), int(first_index), _ip(out['sweeps1']),
                                        _ip(out['sweeps2']), _ip(out['visits2']), _ip(out['accepted2']),
                                        _bp(out['ran_phase2']), _dp(out['f0']), _dp(out['maxviol'])))
+        return out
+
+    # ----------------------------------------------------------------------- ADMM
+    def admm_set_eig(self, lmb, Q):
+        """lmb: (m, n), Q: (m, n, n) in NumPy eigh layout (Q[k][:, j] = eigenvector j)."""
+        lmb = np.ascontiguousarray(lmb, dtype=np.float64)
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        assert lmb.shape == (self.m, self.n) and Q.shape == (self.m, self.n, self.n)
+        self._chk(self.L.qcqpmi_admm_set_eig(self.h, _dp(lmb), _dp(Q)))
+
+    def admm_run(self, rho, Minv, phase1=True, num_iters=1000, tol=1e-2, viol_lim=1e4):
+        R = self.pop_size
+        Minv = np.ascontiguousarray(Minv, dtype=np.float64)
+        assert Minv.shape == (self.n, self.n)
+        out = dict(iters1=np.zeros(R, dtype=np.int64), iters2=np.zeros(R, dtype=np.int64),
+                   f0=np.empty(R), maxviol=np.empty(R))
+        self._chk(self.L.qcqpmi_admm_run(self.h, int(bool(phase1)), int(num_iters), float(tol),
+                                         float(viol_lim), float(rho), _dp(Minv), _ip(out['iters1']),
+                                         _ip(out['iters2']), _dp(out['f0']), _dp(out['maxviol'])))
         return out
 
     # ------------------------------------------------------------------ selection

@@ -93,3 +93,27 @@ def test_errors_mirror_reference():
     with pytest.raises(Exception) as ei:
         q.improve('dccp')
     assert 'DCCP package is not installed.' in str(ei.value)
+
+
+def test_improve_method_list_with_admm_matches_reference():
+    """G10, third call: improve([COORD_DESCENT, ADMM], phase1=False, num_iters=50) started from the
+    reference's coordinate-descent point reproduces the reference's (f, v) and point (same kwargs go to
+    both methods, auto-rho, phase-1 skipped: everything deterministic)."""
+    from qcqp_amd import COORD_DESCENT, ADMM
+    z = load_golden('g10_api_bls10')
+    q = handler(funcs_from_npz(z))
+    q.prob.variables()[0].value = z['x_cd'].reshape(-1, 1)
+    f, v = q.improve([COORD_DESCENT, ADMM], phase1=False, num_iters=50)
+    assert abs(f - z['fv'][2, 0]) <= 1e-6 * (1 + abs(f))
+    assert abs(v - z['fv'][2, 1]) <= 1e-6
+    assert np.max(np.abs(np.ravel(q.prob.variables()[0].value) - z['x_chain'])) < 1e-6
+
+
+def test_admm_rho_too_small_raises_like_reference():
+    from qcqp_amd import ADMM, RANDOM, problems
+    funcs, _, _ = problems.maxcut(8, 0.5, seed=1)      # indefinite objective
+    q = handler(funcs, maximize=True)
+    q.suggest(RANDOM)
+    with pytest.raises(Exception) as ei:
+        q.improve(ADMM, rho=1e-6)
+    assert 'rho parameter is too small' in str(ei.value)

@@ -195,3 +195,50 @@ def test_full_size_headline_config(eng_mod, orc):
     assert np.array_equal(e.download(), X[:, :256])
     assert out3['accepted2'].sum() == 0 and np.all(out3['visits2'][ran[:256]] == n)
     # best-of-population rule
+
+
+# ------------------------------------------------------------------------------------- ADMM
+@pytest.mark.parametrize('name', ['beam10', 'beam40', 'bls10', 'dense16'])
+def test_admm_matches_reference_golden(eng_mod, orc, name):
+    """improve_admm on the GPU (eigenbasis formulation, rocBLAS products + hand-written secular
+    kernel) against the reference's own result (golden G8), fed the reference's eigenpairs."""
+    z = load_golden('g8_admm_' + name)
+    funcs = funcs_from_npz(z)
+    e = make(eng_mod, funcs)
+    n = int(z['n'])
+    m = len(funcs) - 1
+    e.admm_set_eig(z['lmb'], z['Q'])
+    rho = float(z['rho'])
+    P0 = np.asarray(funcs[0][0])
+    Minv = np.linalg.inv(2. * (P0 + rho * m * np.eye(n)))
+    iters = int(z['iters'])
+    # several copies of the same start: every restart must follow the reference
+    e.upload(np.stack([z['x0']] * 5, axis=1))
+    out = e.admm_run(rho, Minv, phase1=True, num_iters=iters)
+    X = e.download()
+    for r in range(5):
+        assert rel(X[:, r], z['xa']) < 1e-6, (name, r)     # north-star tolerance (bisection tol is 1e-6)
+    assert rel(out['f0'], np.full(5, z['fva'][0])) < 1e-6
+    assert np.max(np.abs(out['maxviol'] - z['fva'][1])) < 1e-6 * (1 + abs(z['fva'][1]))
+
+
+def test_admm_population_vs_oracle(eng_mod, orc):
+    from qcqp_amd import problems
+    funcs, _, _ = problems.beamforming(12, 4, 3, seed=2)
+    e = make(eng_mod, funcs)
+    prob = orc.Problem(funcs)
+    n, m = prob.n, prob.m
+    lm, Q = prob.eig()
+    e.admm_set_eig(lm, Q)
+    rho = float(np.sqrt(m))
+    P0 = np.asarray(funcs[0][0])
+    Minv = np.linalg.inv(2. * (P0 + rho * m * np.eye(n)))
+    R = 9
+    X0 = np.random.RandomState(4).randn(n, R)
+    e.upload(X0)
+    out = e.admm_run(rho, Minv, phase1=True, num_iters=80)
+    X = e.download()
+    for r in range(R):
+        xa = prob.improve_admm(X0[:, r], num_iters=80, rho=rho)
+        assert rel(X[:, r], xa) < 1e-6, r
+        assert abs(out['f0'][r] - prob.eval(0, xa)) <= 1e-6 * (1 + abs(out['f0'][r]))
