@@ -65,7 +65,7 @@ def main():
     ap.add_argument('--m-rows', type=int, default=256)
     ap.add_argument('--restarts', type=int, default=4096, help='restarts per GPU')
     ap.add_argument('--seed', type=int, default=2024)
-    ap.add_argument('--cpu-restarts', type=int, default=3)
+    ap.add_argument('--cpu-restarts', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

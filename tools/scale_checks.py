@@ -1,0 +1,58 @@
+"""Timing + sanity of the other BASELINE configs at full size (cfg3 SDR sampling, cfg4 ADMM)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from qcqp_amd import problems
+from qcqp_amd.engine import Engine
+from qcqp_amd.form import QCQPForm
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
+if which == 'cfg3':
+    n, S = 2000, 8192
+    funcs, maxi, ex = problems.maxcut(n, 0.5, seed=1)
+    e = Engine(QCQPForm.from_arrays(funcs))
+    # stand-in for the SDP optimum: random unit-diagonal PSD matrix of rank 40
+    rs = np.random.RandomState(0)
+    V = rs.randn(n, 40); V /= np.linalg.norm(V, axis=1)[:, None]
+    Sigma = V.dot(V.T) + 1e-8 * np.eye(n)
+    t0 = time.time(); F = np.linalg.cholesky(Sigma); tch = time.time() - t0
+    mu = np.zeros(n)
+    e.sdr_sample(mu, F, S, seed=3)          # warm-up (includes factor upload)
+    t0 = time.time(); e.sdr_sample(mu, F, S, seed=4); t1 = time.time()
+    f0, mv = e.eval(); t2 = time.time()
+    print('cfg3: host cholesky %.3f s; sample call %.1f ms (kernel %.3f ms); eval call %.1f ms (kernel %.3f ms)'
+          % (tch, 1e3 * (t1 - t0), e.kernel_ms(3), 1e3 * (t2 - t1), e.kernel_ms(0)))
+    X = e.download()
+    # properties: sample covariance ~ Sigma, objective identity f0 = x'P0x + r0, cut value of sign rounding
+    C = X.dot(X.T) / S
+    print('   cov error (rel fro) %.3e' % (np.linalg.norm(C - Sigma) / np.linalg.norm(Sigma)))
+    P0, r0 = funcs[0][0], funcs[0][2]
+    chk = np.einsum('is,ij,js->s', X[:, :16], P0, X[:, :16]) + r0
+    print('   f0 check (16 samples) rel err %.2e' % np.max(np.abs(chk - f0[:16]) / np.abs(chk)))
+    xs = np.sign(X); cuts = -(np.einsum('is,ij,js->s', xs[:, :256], P0, xs[:, :256]) + r0)
+    print('   GW-rounded cut (256 samples): mean %.0f max %.0f; edges %d' % (cuts.mean(), cuts.max(), ex['W'].sum() / 2))
+    flops = 2.0 * n * n * S
+    print('   sampling %.1f TFLOP/s, eval %.1f TFLOP/s' % (flops / e.kernel_ms(3) / 1e9, flops / e.kernel_ms(0) / 1e9))
+else:
+    nant, mh, l, R = 512, 16, 64, int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    funcs, _, _ = problems.beamforming(nant, mh, l, seed=1)
+    n, m = 2 * nant, mh + l
+    t0 = time.time()
+    e = Engine(QCQPForm.from_arrays(funcs)); t1 = time.time()
+    lm = np.zeros((m, n)); Q = np.zeros((m, n, n))
+    for k in range(m):
+        lm[k], Q[k] = np.linalg.eigh(np.asarray(funcs[k + 1][0]))
+    t2 = time.time()
+    e.admm_set_eig(lm, Q); t3 = time.time()
+    rho = 1.0
+    Minv = np.linalg.inv(2. * (np.eye(n) + rho * m * np.eye(n)))
+    e.randn(R, seed=1)
+    e.admm_run(rho, Minv, phase1=True, num_iters=2)   # warm-up: rocBLAS initialisation
+    e.randn(R, seed=1)
+    ta = time.time(); out = e.admm_run(rho, Minv, phase1=True, num_iters=iters); tb = time.time()
+    its = out['iters1'].sum() + out['iters2'].sum()
+    print('cfg4 (n=%d, m=%d, R=%d): engine %.1f s, eigh %.1f s, upload %.1f s; admm_run(num_iters=%d) %.2f s; '
+          '%d restart-iterations -> %.1f restart-iterations/s; secular kernel %.2f ms'
+          % (n, m, R, t1 - t0, t2 - t1, t3 - t2, iters, tb - ta, its, its / (tb - ta), e.kernel_ms(4)))
+    print('   f0 range %.3f..%.3f, maxviol max %.3e' % (out['f0'].min(), out['f0'].max(), out['maxviol'].max()))
