@@ -59,7 +59,8 @@ __device__ inline void compute_set(const DevProblem &P, int list, double slack, 
         cp[k] = ok ? P.cp[e0 + k] : 0.0; cq[k] = ok ? P.cq[e0 + k] : 0.0;
         cr[k] = ok ? P.cr[e0 + k] : 0.0; crel[k] = ok ? P.crel[e0 + k] : RELOP_LE;
     }
-    feasible_set<MAXC>(cp, cq, cr, crel, mf, slack, C);
+    if (mf == 1) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], slack, C);
+    else feasible_set<MAXC>(cp, cq, cr, crel, mf, slack, C);
 }
 
 // near-IEEE quotient num/den from a precomputed reciprocal: one Newton correction in fma

@@ -289,7 +289,8 @@ __global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
                 while (es - ss > a.tol) {
                     double s = (ss + es) / 2.0;
                     FeasSet<MAXC> C;
-                    feasible_set<MAXC>(cp, cq, cr, crel, mf, s, C);
+                    if (mf == 1) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], s, C);
+                    else feasible_set<MAXC>(cp, cq, cr, crel, mf, s, C);
                     DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t, it++};
                     double xn;
                     int got = onevar_minimise<MAXC>(0.0, 0.0, 0.0, C, dk, &xn);

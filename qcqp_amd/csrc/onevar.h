@@ -152,6 +152,42 @@ __device__ inline void feasible_set(const double *__restrict__ cp, const double 
     }
 }
 
+// The same feasible set for the common case of ONE constraint on the coordinate (mf == 1), derived
+// from the counting sweep in closed form: the constraint's intervals, with touching intervals
+// merged (hi0 == lo1: the shared key nets to zero), zero-width intervals dropped (lo == hi nets to
+// zero) and intervals that end at +inf dropped (the base interval also ends there: the event is -2,
+// not -1 -- SURVEY.md A.6).
+template <int MAXC>
+__device__ inline void feasible_set_single(double p, double q, double r, int relop, double s,
+                                           FeasSet<MAXC> &out) {
+    Seg2 iv = feasible_intervals(p, q, r, relop, s);
+    double lo0 = iv.lo0, hi0 = iv.hi0, lo1 = iv.lo1, hi1 = iv.hi1;
+    int n = iv.n;
+    if (n == 2 && lo0 == lo1 && hi0 == hi1) {
+        // two identical intervals: +2 / -2 events, never a -1: nothing is recorded
+        n = 0;
+    } else if (n == 2 && hi0 == lo1) { hi0 = hi1; n = 1; }           // [a,b] [b,c] -> [a,c]
+    else if (n == 2 && hi1 == lo0) { lo0 = lo1; n = 1; }              // (same, other order)
+    bool k0 = n >= 1 && lo0 != hi0 && hi0 != QM_INF;
+    bool k1 = n >= 2 && lo1 != hi1 && hi1 != QM_INF;
+    // a left end at -inf coincides with the base interval's start: the count there is +2, harmless
+    // -- unless BOTH intervals start at -inf (cannot happen for one constraint).
+    if (k0 && k1 && lo1 < lo0) {   // keep ascending order
+        double t;
+        t = lo0; lo0 = lo1; lo1 = t;
+        t = hi0; hi0 = hi1; hi1 = t;
+    }
+    out.n = 0;
+#pragma unroll
+    for (int j = 0; j <= MAXC; j++) { out.lo[j] = 0.0; out.hi[j] = 0.0; }
+    if (k0) { out.lo[0] = lo0; out.hi[0] = hi0; out.n = 1; }
+    if (k1) {
+        if (out.n == 0) { out.lo[0] = lo1; out.hi[0] = hi1; }
+        else { out.lo[1] = lo1; out.hi[1] = hi1; }
+        out.n++;
+    }
+}
+
 // OneVarQuadraticFunction.eval with the +-inf branches (utilities.py:115-120); the reference
 // raises NameError for P == q == 0 at +-inf, signalled here through *err.
 __device__ inline double onevar_eval(double p, double q, double r, double x, int *err) {

@@ -242,3 +242,89 @@ def test_admm_population_vs_oracle(eng_mod, orc):
         xa = prob.improve_admm(X0[:, r], num_iters=80, rho=rho)
         assert rel(X[:, r], xa) < 1e-6, r
         assert abs(out['f0'][r] - prob.eval(0, xa)) <= 1e-6 * (1 + abs(out['f0'][r]))
+
+
+# --------------------------------------------------------------- general separable constraints
+def mixed_separable(n, per_coord, seed, objective='psd'):
+    """Every coordinate carries `per_coord` constraints of random kinds that all leave a common
+    feasible region around +-[0.6, 1.6]: box (linear <=), disc (x^2 <= c), annulus (-x^2 <= -c),
+    equality x^2 == c with slack.  Several constraint classes, two-interval sets, infinite end points."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(seed)
+    G = rs.randn(n, n)
+    if objective == 'psd':
+        P0 = G.dot(G.T) / n + 0.5 * np.eye(n)
+    elif objective == 'indef':
+        P0 = (G + G.T) / 2.
+        P0[np.arange(0, n, 3), np.arange(0, n, 3)] = 0.0          # zero, positive and negative curvature
+    else:
+        P0 = (G + G.T) / 2.
+        np.fill_diagonal(P0, 0.0)
+    funcs = [(P0, rs.randn(n), 0.3, None)]
+    kinds = ['box_hi', 'box_lo', 'annulus']
+    for i in range(n):
+        # the first constraint keeps the feasible set bounded (the reference raises OverflowError in
+        # phase 1 on unbounded sets, see test_cd_unbounded_set_raises_like_reference)
+        chosen = [rs.choice(['disc', 'eq'])] + [kinds[c] for c in rs.choice(len(kinds), size=per_coord - 1, replace=False)]
+        for kind in chosen:
+            P = np.zeros((n, n)); q = np.zeros(n)
+            if kind == 'box_hi':
+                q[i] = 1.0; r = -(1.7 + 0.1 * rs.rand()); P = sp.csr_matrix((n, n))
+            elif kind == 'box_lo':
+                q[i] = -1.0; r = -(1.8 + 0.1 * rs.rand()); P = sp.csr_matrix((n, n))
+            elif kind == 'disc':
+                P = sp.csr_matrix(([1.0], ([i], [i])), shape=(n, n)); r = -(2.5 + rs.rand())
+            elif kind == 'eq':
+                P = sp.csr_matrix(([1.0], ([i], [i])), shape=(n, n)); r = -(1.0 + 0.5 * rs.rand())
+                funcs.append((P, q, r, '=='))
+                continue
+            else:
+                P = sp.csr_matrix(([-1.0], ([i], [i])), shape=(n, n)); r = 0.3 + 0.1 * rs.rand()
+            funcs.append((P, q, r, '<='))
+    return funcs
+
+
+@pytest.mark.parametrize('per_coord,objective', [(1, 'psd'), (1, 'indef'), (2, 'psd'), (3, 'indef'), (2, 'zero')])
+def test_cd_general_separable_vs_oracle(eng_mod, orc, per_coord, objective):
+    """Exercises the general phase-1/phase-2 kernels (several constraints per coordinate, many
+    constraint classes, unbounded intervals, all curvature signs) against the oracle."""
+    n, R, seed = 40, 19, 77
+    funcs = mixed_separable(n, per_coord, seed=5 + per_coord, objective=objective)
+    e = make(eng_mod, funcs)
+    assert e.separable
+    prob = orc.Problem(funcs)
+    X0 = 1.2 * np.random.RandomState(2).randn(n, R)
+    e.upload(X0)
+    try:
+        out = e.cd_run(phase1=True, num_iters=60, seed=seed, first_index=3)
+        gpu_err = None
+    except eng_mod.EngineError as err:
+        gpu_err = str(err)
+    X = e.download()
+    for r in range(R):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(3 + r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=60, rng=rng)
+        assert gpu_err is None, gpu_err
+        assert rel(X[:, r], x) < 1e-9, (r, np.max(np.abs(X[:, r] - x)))
+        assert out['visits2'][r] == s2[1] and out['accepted2'][r] == s2[2], r
+
+
+def test_cd_unbounded_set_raises_like_reference(eng_mod, orc):
+    """A coordinate whose only constraint is a one-sided bound has an unbounded feasible interval:
+    the reference's phase 1 dies in np.random.uniform (OverflowError); the engine reports it."""
+    import scipy.sparse as sp
+    n = 8
+    funcs = [(np.eye(n), np.zeros(n), 0.0, None)]
+    for i in range(n):
+        q = np.zeros(n); q[i] = 1.0
+        funcs.append((sp.csr_matrix((n, n)), q, -1.0, '<='))
+    e = make(eng_mod, funcs)
+    prob = orc.Problem(funcs)
+    x0 = 3.0 + np.abs(np.random.RandomState(0).randn(n))
+    with pytest.raises(RuntimeError):
+        prob.improve_cd(x0, rng=orc.Rng(orc.RNG_KEYED, 1))
+    e.upload(x0)
+    with pytest.raises(eng_mod.EngineError) as ei:
+        e.cd_run(seed=1)
+    assert 'OverflowError' in str(ei.value)
