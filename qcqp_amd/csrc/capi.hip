@@ -15,6 +15,7 @@
 #include "../../include/qcqp_mi.h"
 #include "kernels.hip"
 #include "admm.h"
+#include "cd_general.h"
 
 using namespace qcqpmi;
 
@@ -105,6 +106,7 @@ struct qcqpmi_ctx {
     double *ad_W = nullptr, *ad_lam = nullptr, *ad_qhat = nullptr, *ad_rk = nullptr, *ad_slo = nullptr, *ad_ehi = nullptr, *ad_Minv = nullptr;
     int *ad_relop = nullptr;
     void *rb_handle = nullptr;
+    double *d_gP = nullptr;   // dense constraint matrices [m][n][n] (problems whose constraints couple coordinates)
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -303,6 +305,74 @@ int check_ready(qcqpmi_ctx *c, bool need_pop) {
 
 }  // namespace
 
+// coordinate descent for constraints that couple coordinates (cd_general.h)
+int cd_run_general(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol, double tol, uint64_t seed,
+                   uint64_t first_index, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
+                   uint8_t *ran_phase2, double *f0, double *maxviol) {
+    if (!c->d_gP) return fail(c, QCQPMI_EUNSUPPORTED, "coupled constraints: dense storage m*n*n exceeds 16 GB");
+    if (num_iters < 0 || !(tol > 0.0)) return fail(c, QCQPMI_EINVAL, "cd_run: bad num_iters / tol");
+    const int64_t m = c->m;
+    const size_t lds = ((size_t)(m + 1) * 16 * 4 + 4 * 16 * GEN_CAP + 16 * GEN_CAP + 16) * sizeof(double);
+    if (lds > 160 * 1024) return fail(c, QCQPMI_EUNSUPPORTED, "coupled constraints: m = %lld too large for the LDS-resident coefficient table", (long long)m);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    CdGenArgs g;
+    CdArgs &a = g.b;
+    a.P = c->dp; a.X = c->X; a.R = c->R; a.f0cur = c->d_f0; a.slack = c->d_mv;
+    a.num_iters = num_iters; a.viol_tol = viol_tol; a.tol = tol; a.seed = seed; a.first_index = first_index;
+    a.visits = c->d_visits; a.accepted = c->d_acc; a.sweeps = c->d_sweeps; a.status = c->d_status;
+    a.flag = c->d_flag; a.prof = nullptr; a.dbg = 0;
+    g.gP = c->d_gP; g.Rpad = c->Rpad;
+    g.exact_t0 = (c->n <= 64 && !(c->dbg & 16)) ? 1 : 0;   // small problems: the reference's own arithmetic for t0
+    dim3 grid((unsigned)(c->Rpad / 16)), block(256);
+    auto k1 = cd_general_kernel<1>;
+    auto k2 = cd_general_kernel<2>;
+    HIPCHK(c, hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipMemsetAsync(c->d_sweeps1, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_status1, 0, (size_t)c->Rpad * sizeof(int), c->stream));
+    if (phase1) {
+        if ((rc = launch_eval(c, true))) return rc;
+        g.F = c->d_F;
+        CdGenArgs g1 = g;
+        g1.b.sweeps = c->d_sweeps1;
+        g1.b.status = c->d_status1;
+        tic(c, 1);
+        hipLaunchKernelGGL(k1, grid, block, lds, c->stream, g1);
+        toc(c, 1);
+        HIPCHK(c, hipGetLastError());
+    }
+    if ((rc = launch_eval(c, true))) return rc;
+    g.F = c->d_F;
+    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((c->Rpad + 255) / 256)), dim3(256), 0, c->stream, c->d_mv,
+                       c->d_status1, c->d_flag, c->R, c->Rpad, viol_tol);
+    HIPCHK(c, hipGetLastError());
+    if (ran_phase2) HIPCHK(c, hipMemcpyAsync(ran_phase2, c->d_flag, (size_t)c->R, hipMemcpyDeviceToHost, c->stream));
+    tic(c, 2);
+    hipLaunchKernelGGL(k2, grid, block, lds, c->stream, g);
+    toc(c, 2);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = launch_eval(c, false))) return rc;
+    std::vector<int> st((size_t)c->R), st1((size_t)c->R);
+    if (sweeps1) HIPCHK(c, hipMemcpyAsync(sweeps1, c->d_sweeps1, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (sweeps2) HIPCHK(c, hipMemcpyAsync(sweeps2, c->d_sweeps, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (visits2) HIPCHK(c, hipMemcpyAsync(visits2, c->d_visits, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (accepted2) HIPCHK(c, hipMemcpyAsync(accepted2, c->d_acc, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (f0) HIPCHK(c, hipMemcpyAsync(f0, c->d_f0, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (maxviol) HIPCHK(c, hipMemcpyAsync(maxviol, c->d_mv, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st1.data(), c->d_status1, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int64_t r = 0; r < c->R; r++) {
+        const int s1 = st1[(size_t)r], s2 = st[(size_t)r];
+        if (s1 == -3) return fail(c, QCQPMI_EREFERENCE, "phase 1: a variable appears in no constraint (reference: ValueError: max() arg is an empty sequence, qcqp.py:117); restart %lld", (long long)r);
+        if (s1 == -4 || s2 == -4) return fail(c, QCQPMI_EUNSUPPORTED, "feasible set with more than %d segments; restart %lld", GEN_CAP, (long long)r);
+        if (s1) return fail(c, QCQPMI_EREFERENCE, "phase 1: unbounded feasible interval with zero objective (reference: OverflowError in np.random.uniform, utilities.py:267); restart %lld", (long long)r);
+        if (s2) return fail(c, QCQPMI_EREFERENCE, "phase 2: the reference raises on restart %lld (code %d)", (long long)r, s2);
+    }
+    return 0;
+}
+
 // ============================================================================================
 
 extern "C" {
@@ -351,7 +421,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     free_population(c);
     admm_free(c);
     for (void *p : c->prob_allocs) (void)hipFree(p);
-    void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm};
+    void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm};   // d_gP is in prob_allocs
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -522,6 +592,17 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
             for (int64_t j = 0; j < n; j++) gq[(size_t)k * n16 + j] = h.q[j];
             gr[k] = h.r; grel[k] = h.relop;
         }
+        if ((double)m * (double)n * (double)n * 8.0 <= 16e9) {
+            std::vector<double> gP((size_t)m * n * n, 0.0);
+            for (int64_t k = 0; k < m; k++) {
+                const HostQuad &h = c->quads[(size_t)k + 1];
+                for (size_t e = 0; e < h.cv.size(); e++) gP[((size_t)k * n + h.ci[e]) * n + h.cj[e]] += h.cv[e];
+            }
+            const double *tmp = nullptr;
+            if ((rc = prob_upload(c, &tmp, gP))) return rc;
+            c->d_gP = const_cast<double *>(tmp);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
         if ((rc = prob_upload(c, &dp.gptr, gptr))) return rc;
         if ((rc = prob_upload(c, &dp.gi, gi))) return rc;
         if ((rc = prob_upload(c, &dp.gj, gj))) return rc;
@@ -657,9 +738,8 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
                   double *maxviol) {
     int rc = check_ready(c, true);
     if (rc) return rc;
-    if (!c->sep)
-        return fail(c, QCQPMI_EUNSUPPORTED,
-                    "COORD_DESCENT on the HIP engine currently needs separable constraints (each constraint touching one coordinate); this problem couples coordinates inside a constraint");
+    if (!c->sep) return cd_run_general(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
+                                       accepted2, ran_phase2, f0, maxviol);
     if (c->maxc > 4)
         return fail(c, QCQPMI_EUNSUPPORTED, "more than 4 constraints on one coordinate (%d)", c->maxc);
     if (num_iters < 0 || !(tol > 0.0)) return fail(c, QCQPMI_EINVAL, "cd_run: bad num_iters / tol");
