@@ -16,6 +16,7 @@
 #include "kernels.hip"
 #include "admm.h"
 #include "cd_general.h"
+#include "cd_dense.h"
 
 using namespace qcqpmi;
 
@@ -107,6 +108,12 @@ struct qcqpmi_ctx {
     int *ad_relop = nullptr;
     void *rb_handle = nullptr;
     double *d_gP = nullptr;   // dense constraint matrices [m][n][n] (problems whose constraints couple coordinates)
+    // dense-constraint path (cd_dense.h): all matrices in block-major fragment order + work buffers
+    const double *dn_Gpack = nullptr, *dn_q = nullptr, *dn_qT = nullptr, *dn_r = nullptr;
+    const int *dn_relop = nullptr;
+    double *dn_G = nullptr, *dn_Dg = nullptr, *dn_Ft = nullptr;
+    int64_t dn_G_cap = 0, dn_state_cap = 0;
+    void *dn_state = nullptr;
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -203,7 +210,11 @@ void toc(qcqpmi_ctx *c, int which) {
     c->timers[which].valid = true;
 }
 
+bool dense_on(const qcqpmi_ctx *c);
+int launch_eval_dense(qcqpmi_ctx *c, bool with_Ft);
+
 int launch_eval(qcqpmi_ctx *c, bool want_F) {
+    if (dense_on(c)) return launch_eval_dense(c, false);   // coupled constraints: every function on the matrix cores
     if (want_F) {
         int64_t need = (c->m + 1) * c->Rpad;
         if (need > c->F_cap) {
@@ -304,6 +315,8 @@ int check_ready(qcqpmi_ctx *c, bool need_pop) {
 }
 
 }  // namespace
+
+#include "capi_dense.inc"
 
 // coordinate descent for constraints that couple coordinates (cd_general.h)
 int cd_run_general(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol, double tol, uint64_t seed,
@@ -421,7 +434,8 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     free_population(c);
     admm_free(c);
     for (void *p : c->prob_allocs) (void)hipFree(p);
-    void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm};   // d_gP is in prob_allocs
+    void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -610,6 +624,7 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
         if ((rc = prob_upload(c, &dp.gq, gq))) return rc;
         if ((rc = prob_upload(c, &dp.gr, gr))) return rc;
         if ((rc = prob_upload(c, &dp.grel, grel))) return rc;
+        if (c->d_gP && (double)(m + 1) * (double)n16 * (double)n16 * 8.0 <= 64e9 && (rc = dense_build(c, gq, gr, grel))) return rc;
     }
     if ((rc = dev_alloc(c, &c->d_best_idx, 2))) return rc;
     if ((rc = dev_alloc(c, &c->d_best_key, 2))) return rc;
@@ -738,6 +753,8 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
                   double *maxviol) {
     int rc = check_ready(c, true);
     if (rc) return rc;
+    if (dense_on(c)) return cd_run_dense(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
+                                         accepted2, ran_phase2, f0, maxviol);
     if (!c->sep) return cd_run_general(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
                                        accepted2, ran_phase2, f0, maxviol);
     if (c->maxc > 4)

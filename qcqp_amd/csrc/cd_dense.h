@@ -1,0 +1,580 @@
+// Dense-constraint path: problems whose constraints couple coordinates (beamforming, dense
+// indefinite QCQPs) at sizes where the one-workgroup-per-tile kernel of cd_general.h is hopeless.
+//
+//   QuadraticFunction.eval / violations   utilities.py:49-62,133-134   -> dense_products_kernel<1> + dense_viol_kernel
+//   get_onevar_func                       utilities.py:99-105          -> dense_products_kernel<0> (+ lazy block correction)
+//   get_feasible_intervals, onevar_qcqp   utilities.py:198-288         -> dense_chain_kernel (bounds + gap sweep)
+//   coord_descent_phase1 / phase2         qcqp.py:101-178              -> sweep_begin / chain / sweep_end kernels + host loop
+//
+// Data layout.  ALL m+1 matrices (objective = function 0) live in one array in MFMA A-fragment order,
+// block-major:   Gpack[b][k][kk][l] = P_k[16 b + (l & 15)][4 kk + (l >> 4)],
+// so that everything a block of 16 coordinates needs -- the 16 rows of every P_k -- is ONE contiguous
+// chunk of (m+1) 16 n16 doubles, streamed once per block visit and shared by all tiles of restarts
+// (L2 / MALL), and each A operand is a coalesced 512-byte wave load.  The population keeps its
+// tile-major layout (kernels.h), which is exactly the B-fragment order.  Everything the chain reads
+// per function (G, diagonal blocks, q, tracked f_k) is laid out FUNCTION-FASTEST (padded to m1p, a
+// multiple of 64) because the chain's lanes run over functions.
+//
+// A coordinate sweep is a loop over blocks; per block three launches:
+//   products  G[tile][c][r][k] = (P_k[I_b, :] X[tile])[c][r]   16(m+1) x n16 by n16 x 16 per tile on
+//             the matrix cores; grid = function groups x tile groups, so the whole chip works on one
+//             block even when there are few restarts (cfg5: 32 tiles per GPU but 1025 functions);
+//   diag      the 16 x 16 diagonal blocks P_k[I_b, I_b] -> Dg[c][c'][k] (shared by all restarts);
+//   chain     ONE WAVEFRONT PER RESTART walks the 16 coordinates in order, lane = function slot
+//             (k = lane, lane + 64, ...).  Everything that belongs to the restart (x_i, the moves made
+//             so far, slack, bounds) is wave-uniform, so there is no workgroup barrier anywhere: cross
+//             lane traffic is DPP reductions, ballots and the wave's own in-order LDS queue.
+//             Coordinate c: every lane forms (t2, t1, t0) of its functions -- G corrected by the moves
+//             already made inside the block (Gauss-Seidel, through Dg) and t0 from the tracked f_k(x)
+//             -- then the feasible set is built WITHOUT sorting all end points:
+//               each constraint allows  [lo, hi]  minus at most one gap  (hi0, lo1);
+//               L = max lo, H = min hi are wave reductions over the constraints;
+//               only gaps that cut into [L, H] survive (typically none or a few), they are sorted
+//               and swept by lane 0.
+//             The reference's end-point rules (zero-width segments, segments
+//             ending at +inf and segments whose right end is shared by two intervals vanish) become
+//             a multiplicity count of H and of coincident gap starts.
+// Arithmetic differs from the reference by summation order (MFMA) and by tracking f_k incrementally;
+// bit-exact parity is the job of cd_general.h's exact mode (n <= 64), this path is checked within
+// tolerance / statistically (tests/test_gpu_parity.py).
+#pragma once
+#include "cd_general.h"
+
+namespace qcqpmi {
+
+constexpr int DN_GC = 64;    // gaps kept per restart
+constexpr int DN_SC = 32;    // segments kept per restart
+constexpr int DN_WPB = 4;    // restarts (= waves) per workgroup of the chain kernel
+// LDS doubles per wave of the chain kernel besides the 4 per-function arrays (t2, t1, t0, f_k)
+constexpr int DN_LDS_WAVE = 2 * DN_GC + 2 * DN_SC + 32 + 8;
+
+typedef double dn_v4d __attribute__((ext_vector_type(4)));
+
+struct DenseProblem {
+    const double *Gpack;   // [NB][m1][KS][64]
+    const double *q;       // [m1][n16]
+    const double *qT;      // [n16][m1p]
+    const double *r;       // [m1]
+    const int *relop;      // [m1]  (0 for the objective)
+    int64_t n, n16;
+    int NB, KS, m1, m1p;
+};
+
+// ------------------------------------------------------------------------------------ packing
+// src: row-major matrix of function k (objective: P0 with ld n16; constraint: gP + (k-1) n^2, ld n)
+__global__ void dense_pack_kernel(const double *__restrict__ P0, const double *__restrict__ gP,
+                                  double *__restrict__ Gpack, int64_t n, int64_t n16, int m1) {
+    const int k = blockIdx.y;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n16 * n16) return;
+    const int KS = (int)(n16 / 4);
+    const int l = (int)(idx & 63);
+    const int64_t fk = idx >> 6;          // b * KS + kk
+    const int64_t b = fk / KS, kk = fk % KS;
+    const int64_t row = 16 * b + (l & 15), col = 4 * kk + (l >> 4);
+    double v = 0.0;
+    if (row < n && col < n) v = (k == 0) ? P0[row * n16 + col] : gP[((int64_t)(k - 1) * n + row) * n + col];
+    Gpack[((b * m1 + k) * KS + kk) * 64 + l] = v;
+}
+
+// ----------------------------------------------------------------------------------- products
+struct DenseProdArgs {
+    DenseProblem D;
+    const double *X;        // tile-major population
+    int ntiles;
+    int b;                  // MODE 0: the block
+    double *G;              // MODE 0: [ntiles][16 c][16 r][m1p]
+    double *F;              // MODE 1: [m1][Rpad]
+    int64_t Rpad;
+    const uint8_t *tile_on; // MODE 0: optional per-tile "any restart sweeping" flags, or nullptr
+};
+
+// One wave = 4 functions x TB tiles (register block of 4 TB accumulators): per k-step 4 + TB
+// fragment loads feed 4 TB MFMAs.  Workgroup = 4 waves on 4 TB consecutive tiles, same functions
+// (their A fragments hit the L1 / L2 lines the sibling waves just fetched).
+//   MODE 0: G of block a.b;   MODE 1: quadratic forms f_k(x) = x' P_k x + q_k' x + r_k over all blocks
+template <int MODE, int TB>
+__global__ __launch_bounds__(256) void dense_products_kernel(DenseProdArgs a) {
+    const DenseProblem &D = a.D;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k0 = 4 * blockIdx.x;
+    const int t0 = (4 * blockIdx.y + wave) * TB;
+    if (t0 >= a.ntiles) return;
+    int kf[4], tl[TB];
+#pragma unroll
+    for (int u = 0; u < 4; u++) kf[u] = (k0 + u < D.m1) ? k0 + u : D.m1 - 1;     // clamped: recomputed, not stored
+#pragma unroll
+    for (int t = 0; t < TB; t++) tl[t] = (t0 + t < a.ntiles) ? t0 + t : a.ntiles - 1;
+    if (MODE == 0 && a.tile_on) {
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < TB; t++) any = any || a.tile_on[tl[t]];
+        if (!any) return;
+    }
+    const double *Xp[TB];
+#pragma unroll
+    for (int t = 0; t < TB; t++) Xp[t] = a.X + (int64_t)tl[t] * D.n16 * 16 + lane;
+    double fa[4][TB];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int t = 0; t < TB; t++) fa[u][t] = 0.0;
+    const int b_lo = (MODE == 0) ? a.b : 0, b_hi = (MODE == 0) ? a.b + 1 : D.NB;
+    for (int b = b_lo; b < b_hi; b++) {
+        dn_v4d acc[4][TB];
+        const double *Ap[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            Ap[u] = D.Gpack + (((int64_t)b * D.m1 + kf[u]) * D.KS) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < TB; t++) acc[u][t] = dn_v4d{0.0, 0.0, 0.0, 0.0};
+        }
+        // software pipeline: fragments of k-step kk+1 are in flight while kk multiplies
+        double an[4], xn[TB];
+#pragma unroll
+        for (int u = 0; u < 4; u++) an[u] = Ap[u][0];
+#pragma unroll
+        for (int t = 0; t < TB; t++) xn[t] = Xp[t][0];
+        for (int kk = 0; kk < D.KS; kk++) {
+            double ac[4], xc[TB];
+#pragma unroll
+            for (int u = 0; u < 4; u++) ac[u] = an[u];
+#pragma unroll
+            for (int t = 0; t < TB; t++) xc[t] = xn[t];
+            const int kn = (kk + 1 < D.KS) ? kk + 1 : kk;   // unconditional loads (s_waitcnt counts them)
+#pragma unroll
+            for (int u = 0; u < 4; u++) an[u] = Ap[u][(int64_t)kn * 64];
+#pragma unroll
+            for (int t = 0; t < TB; t++) xn[t] = Xp[t][(int64_t)kn * 64];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int t = 0; t < TB; t++)
+                    acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], xc[t], acc[u][t], 0, 0, 0);
+        }
+        if (MODE == 0) {
+            // D layout: register v of lane l = row c = (l >> 4) + 4 v, column r = l & 15
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (k0 + u >= D.m1) continue;
+#pragma unroll
+                for (int t = 0; t < TB; t++) {
+                    if (t0 + t >= a.ntiles) continue;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int c = (lane >> 4) + 4 * v, r = lane & 15;
+                        a.G[(((int64_t)tl[t] * 16 + c) * 16 + r) * D.m1p + kf[u]] = acc[u][t][v];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int64_t i = 16 * (int64_t)b + (lane >> 4) + 4 * v;
+#pragma unroll
+                for (int t = 0; t < TB; t++) {
+                    const double xi = a.X[(int64_t)tl[t] * D.n16 * 16 + i * 16 + (lane & 15)];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) fa[u][t] += xi * (acc[u][t][v] + D.q[(int64_t)kf[u] * D.n16 + i]);
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int t = 0; t < TB; t++) {
+                double s = fa[u][t];
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                if (lane < 16 && k0 + u < D.m1 && t0 + t < a.ntiles)
+                    a.F[(int64_t)kf[u] * a.Rpad + (int64_t)tl[t] * 16 + lane] = s + D.r[kf[u]];
+            }
+    }
+}
+
+// f0 and the maximum violation of every candidate from the table of function values; also the
+// restart-major copy Ft[gr][k] the chain kernel tracks
+__global__ void dense_viol_kernel(const double *__restrict__ F, const int *__restrict__ relop, int m1, int m1p,
+                                  int64_t Rpad, double *__restrict__ f0, double *__restrict__ maxviol,
+                                  double *__restrict__ Ft) {
+    const int64_t gr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gr >= Rpad) return;
+    double v = -QM_INF;
+    for (int k = 0; k < m1; k++) {
+        const double f = F[(int64_t)k * Rpad + gr];
+        if (Ft) Ft[gr * m1p + k] = f;
+        if (k == 0) continue;
+        const double w = (relop[k] == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+        v = w > v ? w : v;
+    }
+    f0[gr] = F[gr];
+    maxviol[gr] = v;
+}
+
+// diagonal blocks of every function for block b:  Dg[c][c'][k] = P_k[16 b + c][16 b + c']
+__global__ __launch_bounds__(256) void dense_diag_kernel(DenseProblem D, int b, double *__restrict__ Dg) {
+    const int k = blockIdx.x, t = threadIdx.x;
+    const int c = t >> 4, c2 = t & 15;
+    const int kk = 4 * b + (c2 >> 2), l = (c2 & 3) * 16 + c;
+    Dg[(int64_t)t * D.m1p + k] = D.Gpack[(((int64_t)b * D.m1 + k) * D.KS + kk) * 64 + l];
+}
+
+// -------------------------------------------------------------------------------- sweep state
+struct DenseState {          // one entry per restart (Rpad), persistent across the block launches
+    int64_t *upd, *visits, *accepted, *sweeps;
+    uint8_t *live, *on;      // live: still iterating; on: takes part in the current sweep
+    double *viol_last;
+    int *status;
+    uint8_t *tile_on;        // [ntiles] any restart of the tile is on
+    int *nlive;              // [1]
+};
+
+template <int PHASE>
+__global__ void dense_sweep_begin_kernel(DenseState S, int64_t R, int64_t Rpad, double viol_tol) {
+    const int64_t gr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // blockDim = 64 = 4 tiles
+    bool live = false;
+    if (gr < R) {
+        live = S.live[gr] != 0;
+        if (PHASE == 1 && live && S.viol_last[gr] < viol_tol) live = false;   // qcqp.py:111
+        S.live[gr] = live ? 1 : 0;
+        S.on[gr] = live ? 1 : 0;
+        if (live) S.sweeps[gr]++;
+    }
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(live);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 15) == 0 && gr < Rpad) S.tile_on[gr >> 4] = ((bal >> lane) & 0xffffull) ? 1 : 0;
+    if (lane == 0 && bal) atomicAdd(S.nlive, __builtin_popcountll(bal));
+}
+
+__global__ void dense_state_init_kernel(DenseState S, const uint8_t *flag, int64_t R, int64_t Rpad) {
+    const int64_t gr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gr >= Rpad) return;
+    S.upd[gr] = 0; S.visits[gr] = 0; S.accepted[gr] = 0; S.sweeps[gr] = 0; S.status[gr] = 0;
+    S.viol_last[gr] = QM_INF;
+    S.live[gr] = (gr < R && (!flag || flag[gr])) ? 1 : 0;
+    S.on[gr] = 0;
+}
+
+// phase 1, end of a sweep: viol = max(prob.violations(x)) (qcqp.py:142) from the tracked f_k
+__global__ void dense_sweep_end_kernel(DenseState S, const double *__restrict__ Ft, const int *__restrict__ relop,
+                                       int m1, int m1p, int64_t R) {
+    const int64_t gr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gr >= R || !S.live[gr]) return;
+    double v = -QM_INF;
+    for (int k = 1; k < m1; k++) {
+        const double f = Ft[gr * m1p + k];
+        const double w = (relop[k] == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+        v = w > v ? w : v;
+    }
+    S.viol_last[gr] = v;
+}
+
+// ------------------------------------------------------------------------- wave-level helpers
+// cross-lane traffic through the wave's LDS region: the hardware keeps a wave's LDS operations in
+// order, the fence keeps the compiler from reordering them
+__device__ inline void dn_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ inline double dn_dpp(double v) {
+    // lanes without a source lane (or masked rows) keep their own value: harmless for max / min
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double dn_bcast63(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double dn_bcast0(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+#define DN_WAVE_REDUCE(OP)                                             \
+    { double w_;                                                       \
+      w_ = dn_dpp<0x111, 0xf>(v); v = OP(v, w_);   /* row_shr:1 */     \
+      w_ = dn_dpp<0x112, 0xf>(v); v = OP(v, w_);   /* row_shr:2 */     \
+      w_ = dn_dpp<0x114, 0xf>(v); v = OP(v, w_);   /* row_shr:4 */     \
+      w_ = dn_dpp<0x118, 0xf>(v); v = OP(v, w_);   /* row_shr:8 */     \
+      w_ = dn_dpp<0x142, 0xa>(v); v = OP(v, w_);   /* row_bcast:15 */  \
+      w_ = dn_dpp<0x143, 0xc>(v); v = OP(v, w_);   /* row_bcast:31 */  \
+      return dn_bcast63(v); }
+
+__device__ inline double dn_max2(double a, double b) { return a > b ? a : b; }
+__device__ inline double dn_min2(double a, double b) { return a < b ? a : b; }
+__device__ inline double dn_wave_max(double v) DN_WAVE_REDUCE(dn_max2)
+__device__ inline double dn_wave_min(double v) DN_WAVE_REDUCE(dn_min2)
+
+// --------------------------------------------------------------------------------- chain kernel
+struct DenseChainArgs {
+    DenseProblem D;
+    double *X;
+    int64_t R, Rpad;
+    const double *G;       // [ntiles][16][16][m1p]
+    const double *Dg;      // [16][16][m1p]
+    double *Ft;            // [Rpad][m1p] tracked function values
+    const double *slack;   // [Rpad] phase 2: the fixed slack
+    DenseState S;
+    int b;
+    int64_t t;             // sweep number
+    double tol, viol_tol;
+    uint64_t seed, first_index;
+};
+
+struct DnWave {            // the wave's LDS region
+    double *t2, *t1, *t0, *F;    // [m1p]
+    double *gapa, *gapb;         // [DN_GC]
+    double *seglo, *seghi;       // [DN_SC]
+    double *xb, *dlt;            // [16]
+    int *misc;                   // [0] number of segments
+};
+
+// lane 0: [L, H] minus the sorted gaps -> segment list, filtered with the end-point rules
+__device__ inline int dn_sweep_segments(double *ga, double *gb, int ng, double *slo, double *shi, double L, double H,
+                                        int mH, int *overflow) {
+    for (int i = 1; i < ng; i++) {   // insertion sort by gap start
+        const double a = ga[i], b = gb[i];
+        int j = i - 1;
+        while (j >= 0 && ga[j] > a) { ga[j + 1] = ga[j]; gb[j + 1] = gb[j]; j--; }
+        ga[j + 1] = a; gb[j + 1] = b;
+    }
+    int ns = 0, idx = 0;
+    double cur = L;
+    bool closed = false;   // cur ran past H
+    while (idx < ng) {
+        const double a = ga[idx];
+        if (a >= cur) {
+            int cnt = 0, j = idx;
+            double nb = cur;
+            while (j < ng && ga[j] == a) { cnt++; nb = gb[j] > nb ? gb[j] : nb; j++; }
+            if (a == H) cnt += mH;
+            if (cur != a && cnt == 1) {
+                if (ns < DN_SC) { slo[ns] = cur; shi[ns] = a; ns++; } else *overflow = 1;
+            }
+            cur = nb;
+            idx = j;
+        } else {
+            cur = gb[idx] > cur ? gb[idx] : cur;
+            idx++;
+        }
+        if (cur > H) { closed = true; break; }
+    }
+    if (!closed && cur <= H && cur != H && mH == 1) {
+        if (ns < DN_SC) { slo[ns] = cur; shi[ns] = H; ns++; } else *overflow = 1;
+    }
+    return ns;
+}
+
+// Feasible set of the current coordinate at slack s from the coefficient arrays in LDS.
+// Returns the number of segments (wave-uniform); the list is in W.seglo / W.seghi.
+__device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, int lane, double s, int *overflow) {
+    // pass 1: bounds of this lane's constraints
+    double L = -QM_INF, H = QM_INF;
+    int mH = 0;
+    bool empty = false;
+    unsigned n2 = 0;   // bit j: function lane + 64 j allows two intervals
+    int j = 0;
+    for (int k = lane; k < D.m1; k += 64, j++) {
+        if (k == 0) continue;
+        const double t2 = W.t2[k], t1 = W.t1[k];
+        if (t2 == 0.0 && t1 == 0.0) continue;   // qcqp.py:116,166
+        const Seg2 iv = feasible_intervals(t2, t1, W.t0[k], D.relop[k], s);
+        if (iv.n == 0) { empty = true; continue; }
+        const double lo = iv.lo0, hi = (iv.n == 2) ? iv.hi1 : iv.hi0;
+        if (iv.n == 2) n2 |= 1u << j;
+        L = lo > L ? lo : L;
+        if (hi < H) { H = hi; mH = 1; } else if (hi == H) mH++;
+    }
+    const double Lg = dn_wave_max(L), Hg = dn_wave_min(H);
+    const bool anyempty = __builtin_amdgcn_ballot_w64(empty) != 0ull;
+    // multiplicity of Hg; the base interval (-inf, +inf) is one more interval ending at +inf
+    int mHg = (Hg == QM_INF) ? 1 : 0;
+    {
+        unsigned long long mk = __builtin_amdgcn_ballot_w64(H == Hg && mH > 0);
+        while (mk) {
+            const int l = __builtin_ctzll(mk);
+            mk &= mk - 1;
+            mHg += __builtin_amdgcn_readlane(mH, l);
+        }
+    }
+    // pass 2: gaps that cut into [Lg, Hg]  (two-interval constraints only, recomputed)
+    int ng = 0;
+    const int kpt = (D.m1 + 63) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (__builtin_amdgcn_ballot_w64(n2 != 0u) != 0ull) {
+        for (int jj = 0; jj < kpt; jj++) {
+            const int k = lane + 64 * jj;
+            bool has = false;
+            double ga = 0.0, gb = 0.0;
+            if ((n2 >> jj) & 1u) {
+                const Seg2 iv = feasible_intervals(W.t2[k], W.t1[k], W.t0[k], D.relop[k], s);
+                ga = iv.hi0; gb = iv.lo1;
+                has = gb > Lg && ga <= Hg;
+            }
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(has);
+            if (has) {
+                const int pos = ng + __builtin_popcountll(mk & lt);
+                if (pos < DN_GC) { W.gapa[pos] = ga; W.gapb[pos] = gb; }
+            }
+            ng += __builtin_popcountll(mk);
+        }
+    }
+    if (ng > DN_GC) { *overflow = 1; ng = DN_GC; }
+    dn_wave_sync();
+    if (lane == 0) {
+        int ns = 0;
+        if (!anyempty && Lg <= Hg) ns = dn_sweep_segments(W.gapa, W.gapb, ng, W.seglo, W.seghi, Lg, Hg, mHg, overflow);
+        W.misc[0] = ns;
+    }
+    dn_wave_sync();
+    return __builtin_amdgcn_readfirstlane(W.misc[0]);
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs a) {
+    extern __shared__ double smem[];
+    const DenseProblem &D = a.D;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t gr = (int64_t)blockIdx.x * DN_WPB + wave;
+    if (gr >= a.R) return;            // no workgroup barrier anywhere below: waves are independent
+    if (!a.S.on[gr]) return;
+    const int m1 = D.m1, m1p = D.m1p;
+    DnWave W;
+    {
+        double *sp = smem + (size_t)wave * (4 * (size_t)m1p + DN_LDS_WAVE);
+        W.t2 = sp; sp += m1p; W.t1 = sp; sp += m1p; W.t0 = sp; sp += m1p; W.F = sp; sp += m1p;
+        W.gapa = sp; sp += DN_GC; W.gapb = sp; sp += DN_GC;
+        W.seglo = sp; sp += DN_SC; W.seghi = sp; sp += DN_SC;
+        W.xb = sp; sp += 16; W.dlt = sp; sp += 16;
+        W.misc = (int *)sp;
+    }
+    const int b = a.b;
+    const int64_t tile = gr >> 4;
+    const int r = (int)(gr & 15);
+    double *Xt = a.X + tile * D.n16 * 16;
+    double *Ftr = a.Ft + gr * m1p;
+    for (int k = lane; k < m1; k += 64) W.F[k] = Ftr[k];
+    if (lane < 16) { W.xb[lane] = Xt[(16 * (int64_t)b + lane) * 16 + r]; W.dlt[lane] = 0.0; }
+    // per-restart state: wave-uniform
+    bool live = a.S.live[gr] != 0, on = true;
+    int64_t upd = a.S.upd[gr], visits = a.S.visits[gr], accepted = a.S.accepted[gr];
+    int status = a.S.status[gr], overflow = 0;
+    const double slack = (PHASE == 2) ? a.slack[gr] : 0.0;
+    unsigned mvmask = 0;   // coordinates of this block that moved
+    dn_wave_sync();
+    const int cmax = (D.n - 16 * (int64_t)b) < 16 ? (int)(D.n - 16 * (int64_t)b) : 16;
+    const SegList SL{W.seglo, W.seghi, nullptr, 0};
+
+    for (int c = 0; c < cmax && on; c++) {
+        const int64_t i = 16 * (int64_t)b + c;
+        const double xi = W.xb[c];
+        // ---- A. one-variable coefficients of the lane's functions (utilities.py:99-105)
+        const double *Gc = a.G + ((tile * 16 + c) * 16 + r) * m1p;
+        const double *Dc = a.Dg + (int64_t)(c * 16) * m1p;
+        const double *qi = D.qT + i * m1p;
+        double vloc = -QM_INF;
+        bool inv = false;
+        for (int k = lane; k < m1; k += 64) {
+            double g = Gc[k];
+            unsigned mm = mvmask;
+            while (mm) {   // Gauss-Seidel inside the block: moves made so far, in coordinate order
+                const int c2 = __builtin_ctz(mm);
+                mm &= mm - 1;
+                g = __builtin_fma(Dc[(int64_t)c2 * m1p + k], W.dlt[c2], g);
+            }
+            const double t2 = Dc[(int64_t)c * m1p + k];
+            const double t1 = 2.0 * (g - t2 * xi) + qi[k];
+            const double t0 = W.F[k] - xi * (t2 * xi + t1);
+            W.t2[k] = t2; W.t1[k] = t1; W.t0[k] = t0;
+            if (PHASE == 1 && k > 0 && !(t2 == 0.0 && t1 == 0.0)) {
+                const double f = xi * (t2 * xi + t1) + t0;
+                const double v = (D.relop[k] == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+                vloc = v > vloc ? v : vloc;
+                inv = true;
+            }
+        }
+        bool moved = false;
+        double xn = xi;
+        visits++;
+        if (PHASE == 2) {
+            // ---- B. feasible set at the fixed slack, minimiser of the scalar objective
+            const int ns = dn_feasible_set(W, D, lane, slack, &overflow);
+            int got = 0;
+            if (lane == 0) {
+                SegList C = SL;
+                C.n = ns;
+                DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)a.t | 0x80000000u, 0u};
+                got = general_minimise(W.t2[0], W.t1[0], W.t0[0], C, dk, &xn);
+            }
+            got = __builtin_amdgcn_readfirstlane(got);
+            xn = dn_bcast0(xn);
+            if (got < 0) { status = got; live = false; on = false; }
+            else if (got && fabs(xn - xi) > a.tol) { moved = true; upd = 0; accepted++; }
+            else {
+                upd++;
+                if (upd == D.n) { live = false; on = false; }   // converged (qcqp.py:172-176)
+            }
+        } else {
+            // ---- B. smallest achievable slack by bisection (qcqp.py:117-131)
+            const double viol = dn_wave_max(vloc);
+            if (__builtin_amdgcn_ballot_w64(inv) == 0ull) { status = -3; live = false; on = false; }   // ValueError (qcqp.py:117)
+            else {
+                double new_viol = viol, ss = -a.tol, es = viol - a.viol_tol;
+                uint32_t it = 0;
+                while (es - ss > a.tol) {
+                    const double sm = (ss + es) / 2.0;
+                    const int ns = dn_feasible_set(W, D, lane, sm, &overflow);
+                    int got = 0;
+                    double xc = 0.0;
+                    if (lane == 0) {
+                        SegList C = SL;
+                        C.n = ns;
+                        DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)a.t, it};
+                        got = general_minimise(0.0, 0.0, 0.0, C, dk, &xc);
+                    }
+                    it++;
+                    got = __builtin_amdgcn_readfirstlane(got);
+                    xc = dn_bcast0(xc);
+                    if (got < 0) { status = got; live = false; on = false; break; }
+                    if (!got) ss = sm;
+                    else { xn = xc; new_viol = sm; es = sm; }
+                }
+                if (status == 0) {
+                    if (new_viol < viol) { moved = true; upd = 0; accepted++; }
+                    else {
+                        upd++;
+                        if (upd == D.n) on = false;   // "failed": leaves this sweep only (qcqp.py:138-141)
+                    }
+                }
+            }
+        }
+        // ---- C. commit: x_i, the block-local move list, f_k(x) += delta (t2 (xn + xi) + t1)
+        if (moved) {
+            const double d = xn - xi;
+            if (lane == 0) { W.xb[c] = xn; W.dlt[c] = d; }
+            mvmask |= 1u << c;
+            for (int k = lane; k < m1; k += 64) W.F[k] += d * (W.t2[k] * (xn + xi) + W.t1[k]);
+            dn_wave_sync();
+        }
+    }
+    dn_wave_sync();
+    if (lane < 16) Xt[(16 * (int64_t)b + lane) * 16 + r] = W.xb[lane];
+    for (int k = lane; k < m1; k += 64) Ftr[k] = W.F[k];
+    if (lane == 0) {
+        a.S.live[gr] = live ? 1 : 0; a.S.on[gr] = on ? 1 : 0;
+        a.S.upd[gr] = upd; a.S.visits[gr] = visits; a.S.accepted[gr] = accepted;
+        a.S.status[gr] = overflow ? -4 : status;
+    }
+}
+
+}  // namespace qcqpmi

@@ -392,3 +392,76 @@ def test_cd_coupled_constraints_tracked_mode_quality(eng_mod, orc):
     for r in np.flatnonzero(okg)[:8]:
         assert abs(prob.max_violation(X[:, r]) - out['maxviol'][r]) < 1e-9
         assert abs(prob.eval(0, X[:, r]) - out['f0'][r]) <= 1e-9 * (1 + abs(out['f0'][r]))
+
+
+# ------------------------------------------------------- dense-constraint path (matrix cores)
+DENSE_PATH = 32 << 4   # qcqpmi_debug_profile switch: take the dense path on small problems too (default: n > 64)
+
+
+def test_dense_path_eval_matches_oracle(eng_mod, orc):
+    """All m+1 quadratic forms on the matrix cores (dense_products_kernel<1>) against the oracle's
+    row-by-row evaluation; ragged sizes (n, m+1 and R not multiples of the tile sizes)."""
+    from qcqp_amd import problems
+    for (n, m, R) in [(100, 7, 37), (70, 13, 300)]:
+        funcs, _, _ = problems.dense_indefinite(n, m, seed=3)
+        e = make(eng_mod, funcs)
+        prob = orc.Problem(funcs)
+        X = np.random.RandomState(n).randn(n, R)
+        f0, mv, F = e.eval_batch(X, want_F=True)
+        g0, gv = prob.eval_batch(X)
+        assert rel(f0, g0) < 1e-12 and rel(mv, gv) < 1e-12
+        for r in (0, R - 1):
+            for k in range(m + 1):
+                assert abs(F[k, r] - prob.eval(k, X[:, r])) <= 1e-11 * (1 + abs(F[k, r]))
+
+
+@pytest.mark.parametrize('name', ['dense16', 'dense32'])
+def test_dense_path_phase2_matches_reference_golden(eng_mod, name):
+    """Blocked products + bounds/gap sweep: same points as the reference (golden G6) up to rounding
+    (MFMA summation order, tracked f_k)."""
+    z = load_golden('g6_cd_' + name)
+    e = make(eng_mod, funcs_from_npz(z))
+    e.L.qcqpmi_debug_profile(e.h, DENSE_PATH, None)
+    e.upload(z['X0'])
+    out = e.cd_run(phase1=False)
+    X = e.download()
+    assert rel(X, z['p2_x']) < 1e-6
+    assert rel(out['f0'], z['p2_fv'][:, 0]) < 1e-6
+    assert np.max(np.abs(out['maxviol'] - z['p2_fv'][:, 1])) < 1e-6
+
+
+@pytest.mark.parametrize('family', ['dense', 'beam'])
+def test_dense_path_full_driver_vs_general_kernel(eng_mod, orc, family):
+    """Phase 1 + gate + phase 2 through the dense path against the oracle (same keyed random
+    stream).  The dense family follows the oracle's trajectory to rounding; the beamforming family is
+    chaotic (see test_cd_coupled_constraints_tracked_mode_quality) and is compared by outcome."""
+    from qcqp_amd import problems
+    if family == 'dense':
+        funcs, _, _ = problems.dense_indefinite(24, 6, seed=11)
+        X0 = 0.3 * np.random.RandomState(1).randn(24, 10)
+    else:
+        funcs, _, _ = problems.beamforming(8, 3, 2, seed=4)
+        X0 = 2.0 * np.random.RandomState(1).randn(16, 10)
+    e = make(eng_mod, funcs)
+    e.L.qcqpmi_debug_profile(e.h, DENSE_PATH, None)
+    prob = orc.Problem(funcs)
+    seed, first, iters = 99, 5, 40
+    e.upload(X0)
+    out = e.cd_run(phase1=True, num_iters=iters, seed=seed, first_index=first)
+    X = e.download()
+    close = 0
+    for r in range(X0.shape[1]):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(first + r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+        # reported values are those of the returned point
+        assert abs(prob.max_violation(X[:, r]) - out['maxviol'][r]) < 1e-9
+        assert abs(prob.eval(0, X[:, r]) - out['f0'][r]) <= 1e-9 * (1 + abs(out['f0'][r]))
+        if rel(X[:, r], x) < 1e-6:
+            close += 1
+            assert out['sweeps1'][r] == s1[0]
+        # never worse in feasibility class than the oracle's run of the same restart
+        assert (out['maxviol'][r] < 1e-2) == (prob.max_violation(x) < 1e-2), r
+    print(family, 'restarts on the oracle trajectory:', close, 'of', X0.shape[1])
+    if family == 'dense':
+        assert close == X0.shape[1]

@@ -33,6 +33,36 @@ if which == 'cfg3':
     print('   GW-rounded cut (256 samples): mean %.0f max %.0f; edges %d' % (cuts.mean(), cuts.max(), ex['W'].sum() / 2))
     flops = 2.0 * n * n * S
     print('   sampling %.1f TFLOP/s, eval %.1f TFLOP/s' % (flops / e.kernel_ms(3) / 1e9, flops / e.kernel_ms(0) / 1e9))
+elif which in ('cfg5', 'cdbeam'):
+    # coordinate descent with constraints that couple coordinates (dense path): reduced cfg5 / cfg4's family
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    if which == 'cfg5':
+        n = int(sys.argv[4]) if len(sys.argv) > 4 else 512
+        m = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+        funcs, _, _ = problems.dense_indefinite(n, m, seed=7)
+        x0s = 0.1
+    else:
+        nant = int(sys.argv[4]) if len(sys.argv) > 4 else 512
+        funcs, _, _ = problems.beamforming(nant, 16, 64, seed=1)
+        n, m, x0s = 2 * nant, 80, 1.0
+    t0 = time.time(); e = Engine(QCQPForm.from_arrays(funcs)); t1 = time.time()
+    rs = np.random.RandomState(0)
+    e.upload(x0s * rs.randn(n, R))
+    e.eval(); e.sync()
+    ta = time.time(); f0, mv = e.eval(); tb = time.time()
+    fl = 2.0 * (m + 1) * n * n
+    print('%s (n=%d, m=%d, R=%d): engine %.1f s; eval call %.1f ms (kernels %.3f ms = %.1f TFLOP/s); start maxviol median %.3g'
+          % (which, n, m, R, t1 - t0, 1e3 * (tb - ta), e.kernel_ms(0), fl * R / e.kernel_ms(0) / 1e9, np.median(mv)))
+    ta = time.time(); out = e.cd_run(phase1=True, num_iters=iters, seed=1); tb = time.time()
+    s1, s2 = out['sweeps1'].sum(), out['sweeps2'].sum()
+    print('   cd_run(num_iters=%d) %.2f s: phase-1 restart-sweeps %d (%.1f ms), phase-2 restart-sweeps %d (%.1f ms); ran phase 2: %d; '
+          'feasible %d; f0 median %.4g' % (iters, tb - ta, s1, e.kernel_ms(1), s2, e.kernel_ms(2), out['ran_phase2'].sum(),
+                                          (out['maxviol'] < 1e-2).sum(), np.median(out['f0'])))
+    for nm, sw, ms in (('phase 1', s1, e.kernel_ms(1)), ('phase 2', s2, e.kernel_ms(2))):
+        if sw:
+            print('   %s: %.1f restart-sweeps/s, %.2f TFLOP/s algorithmic (2 (m+1) n^2 per restart-sweep)'
+                  % (nm, sw / ms * 1e3, fl * sw / ms / 1e9))
 else:
     nant, mh, l, R = 512, 16, 64, int(sys.argv[2]) if len(sys.argv) > 2 else 128
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
