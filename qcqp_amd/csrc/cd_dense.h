@@ -44,7 +44,7 @@ namespace qcqpmi {
 
 constexpr int DN_GC = 64;    // gaps kept per restart
 constexpr int DN_SC = 32;    // segments kept per restart
-constexpr int DN_WPB = 4;    // restarts (= waves) per workgroup of the chain kernel
+constexpr int DN_WPB = 4;    // at most this many restarts (= waves) per workgroup of the chain kernel
 // LDS doubles per wave of the chain kernel besides the 4 per-function arrays (t2, t1, t0, f_k)
 constexpr int DN_LDS_WAVE = 2 * DN_GC + 2 * DN_SC + 32 + 8;
 
@@ -83,89 +83,119 @@ struct DenseProdArgs {
     const double *X;        // tile-major population
     int ntiles;
     int b;                  // MODE 0: the block
-    double *G;              // MODE 0: [ntiles][16 c][16 r][m1p]
-    double *F;              // MODE 1: [m1][Rpad]
+    int zs;                 // grid.z: MODE 0 splits the contraction (K), MODE 1 splits the row blocks
+    double *G;              // MODE 0: [zs][ntiles][16 c][16 r][m1p] partial products (summed by the reader in z order)
+    double *F;              // MODE 1: [zs][m1][Rpad] partial quadratic forms
     int64_t Rpad;
     const uint8_t *tile_on; // MODE 0: optional per-tile "any restart sweeping" flags, or nullptr
 };
 
-// One wave = 4 functions x TB tiles (register block of 4 TB accumulators): per k-step 4 + TB
-// fragment loads feed 4 TB MFMAs.  Workgroup = 4 waves on 4 TB consecutive tiles, same functions
-// (their A fragments hit the L1 / L2 lines the sibling waves just fetched).
-//   MODE 0: G of block a.b;   MODE 1: quadratic forms f_k(x) = x' P_k x + q_k' x + r_k over all blocks
-template <int MODE, int TB>
+constexpr int DP_FG = 8;    // functions per workgroup
+constexpr int DP_TG = 8;    // tiles of 16 candidates per workgroup
+constexpr int DP_KC = 4;    // k-steps per LDS stage (= one block of 16 coordinates)
+constexpr int DP_LDS_BYTES = 2 * (DP_FG + DP_TG) * DP_KC * 64 * 8;
+
+typedef double dn_v2d __attribute__((ext_vector_type(2)));
+
+// LDS-tiled fp64 GEMM on v_mfma_f64_16x16x4_f64:  (16 DP_FG rows of the packed matrices) x (16 DP_TG
+// candidates) per workgroup, 4 waves as 2 x 2, each wave a register block of 4 functions x 4 tiles
+// (16 accumulators).  Both operands are already stored in fragment order, so a stage is 16 contiguous
+// 2-KB streams (8 functions, 8 tiles) copied with 16-byte loads; the next stage's loads are in flight
+// while the current one multiplies (register prefetch + LDS double buffer, one barrier per stage).
+// Per stage and wave: 32 ds_read_b64 feed 64 MFMAs.
+//   MODE 0: G of block a.b (contraction split over grid.z);
+//   MODE 1: quadratic forms f_k(x) = x' P_k x + q_k' x + r_k (row blocks split over grid.z)
+template <int MODE>
 __global__ __launch_bounds__(256) void dense_products_kernel(DenseProdArgs a) {
+    extern __shared__ double smem[];
     const DenseProblem &D = a.D;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int k0 = 4 * blockIdx.x;
-    const int t0 = (4 * blockIdx.y + wave) * TB;
-    if (t0 >= a.ntiles) return;
-    int kf[4], tl[TB];
-#pragma unroll
-    for (int u = 0; u < 4; u++) kf[u] = (k0 + u < D.m1) ? k0 + u : D.m1 - 1;     // clamped: recomputed, not stored
-#pragma unroll
-    for (int t = 0; t < TB; t++) tl[t] = (t0 + t < a.ntiles) ? t0 + t : a.ntiles - 1;
-    if (MODE == 0 && a.tile_on) {
+    const int wm = wave >> 1, wn = wave & 1;
+    const int f0 = DP_FG * blockIdx.x, tg0 = DP_TG * blockIdx.y, z = blockIdx.z;
+    if (MODE == 0 && a.tile_on) {   // uniform for the workgroup
         bool any = false;
-#pragma unroll
-        for (int t = 0; t < TB; t++) any = any || a.tile_on[tl[t]];
+        for (int t = 0; t < DP_TG; t++) any = any || (tg0 + t < a.ntiles && a.tile_on[tg0 + t]);
         if (!any) return;
     }
-    const double *Xp[TB];
+    // this thread's slice of the 16 streams: passes 0..3 -> functions, 4..7 -> tiles
+    const int half = tid >> 7, off = (tid & 127) * 2;
+    int fs[4], ts[4];
 #pragma unroll
-    for (int t = 0; t < TB; t++) Xp[t] = a.X + (int64_t)tl[t] * D.n16 * 16 + lane;
-    double fa[4][TB];
+    for (int p = 0; p < 4; p++) {
+        const int f = f0 + 2 * p + half, t = tg0 + 2 * p + half;
+        fs[p] = f < D.m1 ? f : D.m1 - 1;            // clamped: loaded, multiplied, never stored
+        ts[p] = t < a.ntiles ? t : a.ntiles - 1;
+    }
+    const int kf0 = f0 + 4 * wm, tl0 = tg0 + 4 * wn;   // this wave's functions / tiles
+    double fa[4][4];
 #pragma unroll
     for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int t = 0; t < TB; t++) fa[u][t] = 0.0;
-    const int b_lo = (MODE == 0) ? a.b : 0, b_hi = (MODE == 0) ? a.b + 1 : D.NB;
+        for (int t = 0; t < 4; t++) fa[u][t] = 0.0;
+    const int NBc = D.NB;   // stages per full contraction
+    const int b_lo = (MODE == 0) ? a.b : (int)((int64_t)z * D.NB / a.zs);
+    const int b_hi = (MODE == 0) ? a.b + 1 : (int)((int64_t)(z + 1) * D.NB / a.zs);
+    const int ch_lo = (MODE == 0) ? (int)((int64_t)z * NBc / a.zs) : 0;
+    const int ch_hi = (MODE == 0) ? (int)((int64_t)(z + 1) * NBc / a.zs) : NBc;
     for (int b = b_lo; b < b_hi; b++) {
-        dn_v4d acc[4][TB];
-        const double *Ap[4];
+        dn_v4d acc[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            Ap[u] = D.Gpack + (((int64_t)b * D.m1 + kf[u]) * D.KS) * 64 + lane;
+        for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int t = 0; t < TB; t++) acc[u][t] = dn_v4d{0.0, 0.0, 0.0, 0.0};
+            for (int t = 0; t < 4; t++) acc[u][t] = dn_v4d{0.0, 0.0, 0.0, 0.0};
+        const double *src[8];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            src[p] = D.Gpack + (((int64_t)b * D.m1 + fs[p]) * D.KS) * 64 + off;
+            src[4 + p] = a.X + (int64_t)ts[p] * D.n16 * 16 + off;
         }
-        // software pipeline: fragments of k-step kk+1 are in flight while kk multiplies
-        double an[4], xn[TB];
+        dn_v2d pf[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) an[u] = Ap[u][0];
+        for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)ch_lo * 256);
+        int buf = 0;
+        __syncthreads();   // the previous row block's readers are done with both buffers
 #pragma unroll
-        for (int t = 0; t < TB; t++) xn[t] = Xp[t][0];
-        for (int kk = 0; kk < D.KS; kk++) {
-            double ac[4], xc[TB];
+        for (int p = 0; p < 8; p++)
+            *reinterpret_cast<dn_v2d *>(smem + ((buf * 16 + 2 * p + half) * 256 + off)) = pf[p];
+        __syncthreads();
+        for (int ch = ch_lo; ch < ch_hi; ch++) {
+            const int chn = (ch + 1 < ch_hi) ? ch + 1 : ch;   // unconditional (clamped) prefetch
 #pragma unroll
-            for (int u = 0; u < 4; u++) ac[u] = an[u];
+            for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)chn * 256);
+            const double *As = smem + (buf * 16 + 4 * wm) * 256 + lane;
+            const double *Bs = smem + (buf * 16 + 8 + 4 * wn) * 256 + lane;
+            double av[DP_KC][4], bv[DP_KC][4];
 #pragma unroll
-            for (int t = 0; t < TB; t++) xc[t] = xn[t];
-            const int kn = (kk + 1 < D.KS) ? kk + 1 : kk;   // unconditional loads (s_waitcnt counts them)
+            for (int ks = 0; ks < DP_KC; ks++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) an[u] = Ap[u][(int64_t)kn * 64];
+                for (int u = 0; u < 4; u++) { av[ks][u] = As[u * 256 + ks * 64]; bv[ks][u] = Bs[u * 256 + ks * 64]; }
 #pragma unroll
-            for (int t = 0; t < TB; t++) xn[t] = Xp[t][(int64_t)kn * 64];
+            for (int ks = 0; ks < DP_KC; ks++)
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+                for (int u = 0; u < 4; u++)
 #pragma unroll
-                for (int t = 0; t < TB; t++)
-                    acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], xc[t], acc[u][t], 0, 0, 0);
+                    for (int t = 0; t < 4; t++)
+                        acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][u], bv[ks][t], acc[u][t], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 8; p++)
+                *reinterpret_cast<dn_v2d *>(smem + (((buf ^ 1) * 16 + 2 * p + half) * 256 + off)) = pf[p];
+            __syncthreads();
+            buf ^= 1;
         }
         if (MODE == 0) {
             // D layout: register v of lane l = row c = (l >> 4) + 4 v, column r = l & 15
+            double *Gz = a.G + (int64_t)z * a.ntiles * 256 * D.m1p;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (k0 + u >= D.m1) continue;
+            for (int t = 0; t < 4; t++) {
+                if (tl0 + t >= a.ntiles) continue;
 #pragma unroll
-                for (int t = 0; t < TB; t++) {
-                    if (t0 + t >= a.ntiles) continue;
+                for (int v = 0; v < 4; v++) {
+                    const int c = (lane >> 4) + 4 * v, r = lane & 15;
+                    double *g = Gz + (((int64_t)(tl0 + t) * 16 + c) * 16 + r) * D.m1p + kf0;
 #pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const int c = (lane >> 4) + 4 * v, r = lane & 15;
-                        a.G[(((int64_t)tl[t] * 16 + c) * 16 + r) * D.m1p + kf[u]] = acc[u][t][v];
-                    }
+                    for (int u = 0; u < 4; u++)
+                        if (kf0 + u < D.m1) g[u] = acc[u][t][v];
                 }
             }
         } else {
@@ -173,38 +203,45 @@ __global__ __launch_bounds__(256) void dense_products_kernel(DenseProdArgs a) {
             for (int v = 0; v < 4; v++) {
                 const int64_t i = 16 * (int64_t)b + (lane >> 4) + 4 * v;
 #pragma unroll
-                for (int t = 0; t < TB; t++) {
-                    const double xi = a.X[(int64_t)tl[t] * D.n16 * 16 + i * 16 + (lane & 15)];
+                for (int t = 0; t < 4; t++) {
+                    const int tt = (tl0 + t < a.ntiles) ? tl0 + t : a.ntiles - 1;
+                    const double xi = a.X[(int64_t)tt * D.n16 * 16 + i * 16 + (lane & 15)];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) fa[u][t] += xi * (acc[u][t][v] + D.q[(int64_t)kf[u] * D.n16 + i]);
+                    for (int u = 0; u < 4; u++) {
+                        const int kk = (kf0 + u < D.m1) ? kf0 + u : D.m1 - 1;
+                        fa[u][t] += xi * (acc[u][t][v] + D.q[(int64_t)kk * D.n16 + i]);
+                    }
                 }
             }
         }
     }
     if (MODE == 1) {
+        double *Fz = a.F + (int64_t)z * D.m1 * a.Rpad;
 #pragma unroll
         for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int t = 0; t < TB; t++) {
+            for (int t = 0; t < 4; t++) {
                 double s = fa[u][t];
                 s += __shfl_xor(s, 16);
                 s += __shfl_xor(s, 32);
-                if (lane < 16 && k0 + u < D.m1 && t0 + t < a.ntiles)
-                    a.F[(int64_t)kf[u] * a.Rpad + (int64_t)tl[t] * 16 + lane] = s + D.r[kf[u]];
+                if (lane < 16 && kf0 + u < D.m1 && tl0 + t < a.ntiles)
+                    Fz[(int64_t)(kf0 + u) * a.Rpad + (int64_t)(tl0 + t) * 16 + lane] = s + (z == 0 ? D.r[kf0 + u] : 0.0);
             }
     }
 }
 
 // f0 and the maximum violation of every candidate from the table of function values; also the
 // restart-major copy Ft[gr][k] the chain kernel tracks
-__global__ void dense_viol_kernel(const double *__restrict__ F, const int *__restrict__ relop, int m1, int m1p,
+__global__ void dense_viol_kernel(double *__restrict__ F, int zs, const int *__restrict__ relop, int m1, int m1p,
                                   int64_t Rpad, double *__restrict__ f0, double *__restrict__ maxviol,
                                   double *__restrict__ Ft) {
     const int64_t gr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gr >= Rpad) return;
     double v = -QM_INF;
     for (int k = 0; k < m1; k++) {
-        const double f = F[(int64_t)k * Rpad + gr];
+        double f = F[(int64_t)k * Rpad + gr];
+        for (int z = 1; z < zs; z++) f += F[((int64_t)z * m1 + k) * Rpad + gr];   // partial planes, fixed order
+        F[(int64_t)k * Rpad + gr] = f;
         if (Ft) Ft[gr * m1p + k] = f;
         if (k == 0) continue;
         const double w = (relop[k] == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
@@ -319,7 +356,9 @@ struct DenseChainArgs {
     DenseProblem D;
     double *X;
     int64_t R, Rpad;
-    const double *G;       // [ntiles][16][16][m1p]
+    const double *G;       // [zs][ntiles][16][16][m1p] partial products
+    int zs;
+    int64_t gz_stride;
     const double *Dg;      // [16][16][m1p]
     double *Ft;            // [Rpad][m1p] tracked function values
     const double *slack;   // [Rpad] phase 2: the fixed slack
@@ -336,6 +375,7 @@ struct DnWave {            // the wave's LDS region
     double *seglo, *seghi;       // [DN_SC]
     double *xb, *dlt;            // [16]
     int *misc;                   // [0] number of segments
+    double *G;                   // GLDS: [16][m1p]
 };
 
 // lane 0: [L, H] minus the sorted gaps -> segment list, filtered with the end-point rules
@@ -439,24 +479,28 @@ __device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, in
     return __builtin_amdgcn_readfirstlane(W.misc[0]);
 }
 
-template <int PHASE>
+// GLDS: the restart's 16 rows of G (K-split partials summed) are staged in LDS in one burst of
+// coalesced loads at kernel start instead of being fetched coordinate by coordinate.
+template <int PHASE, bool GLDS>
 __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs a) {
     extern __shared__ double smem[];
     const DenseProblem &D = a.D;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t gr = (int64_t)blockIdx.x * DN_WPB + wave;
+    const int wpb = (int)(blockDim.x >> 6);
+    const int64_t gr = (int64_t)blockIdx.x * wpb + wave;
     if (gr >= a.R) return;            // no workgroup barrier anywhere below: waves are independent
     if (!a.S.on[gr]) return;
     const int m1 = D.m1, m1p = D.m1p;
     DnWave W;
     {
-        double *sp = smem + (size_t)wave * (4 * (size_t)m1p + DN_LDS_WAVE);
+        double *sp = smem + (size_t)wave * ((GLDS ? 20 : 4) * (size_t)m1p + DN_LDS_WAVE);
         W.t2 = sp; sp += m1p; W.t1 = sp; sp += m1p; W.t0 = sp; sp += m1p; W.F = sp; sp += m1p;
         W.gapa = sp; sp += DN_GC; W.gapb = sp; sp += DN_GC;
         W.seglo = sp; sp += DN_SC; W.seghi = sp; sp += DN_SC;
         W.xb = sp; sp += 16; W.dlt = sp; sp += 16;
-        W.misc = (int *)sp;
+        W.misc = (int *)sp; sp += 8;
+        W.G = sp;
     }
     const int b = a.b;
     const int64_t tile = gr >> 4;
@@ -464,6 +508,22 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
     double *Xt = a.X + tile * D.n16 * 16;
     double *Ftr = a.Ft + gr * m1p;
     for (int k = lane; k < m1; k += 64) W.F[k] = Ftr[k];
+    if (GLDS) {
+        const double *Gr = a.G + (tile * 256 + r) * m1p;   // row c of this restart: + c * 16 * m1p
+        const int tot = 16 * m1p;
+#pragma unroll 4
+        for (int idx = lane; idx < tot; idx += 64) {
+            const int c = idx / m1p, k = idx - c * m1p;
+            const double *g0 = Gr + (int64_t)c * 16 * m1p + k;
+            double gz[8];
+#pragma unroll
+            for (int z = 0; z < 8; z++) gz[z] = (z < a.zs) ? g0[(int64_t)z * a.gz_stride] : 0.0;
+            double g = gz[0];
+#pragma unroll
+            for (int z = 1; z < 8; z++) g += gz[z];   // K-split partials, fixed order (absent planes add 0)
+            W.G[idx] = g;
+        }
+    }
     if (lane < 16) { W.xb[lane] = Xt[(16 * (int64_t)b + lane) * 16 + r]; W.dlt[lane] = 0.0; }
     // per-restart state: wave-uniform
     bool live = a.S.live[gr] != 0, on = true;
@@ -485,7 +545,12 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
         double vloc = -QM_INF;
         bool inv = false;
         for (int k = lane; k < m1; k += 64) {
-            double g = Gc[k];
+            double g;
+            if (GLDS) g = W.G[c * m1p + k];
+            else {
+                g = Gc[k];
+                for (int z = 1; z < a.zs; z++) g += Gc[(int64_t)z * a.gz_stride + k];   // K-split partials, fixed order
+            }
             unsigned mm = mvmask;
             while (mm) {   // Gauss-Seidel inside the block: moves made so far, in coordinate order
                 const int c2 = __builtin_ctz(mm);

@@ -465,3 +465,37 @@ def test_dense_path_full_driver_vs_general_kernel(eng_mod, orc, family):
     print(family, 'restarts on the oracle trajectory:', close, 'of', X0.shape[1])
     if family == 'dense':
         assert close == X0.shape[1]
+
+
+def test_dense_path_default_dispatch_vs_oracle(eng_mod, orc):
+    """n > 64 takes the dense path without any switch: dense indefinite family, phase 1 + phase 2
+    against the oracle with the same keyed stream (trajectories agree to rounding: this family is not
+    chaotic), ragged sizes (n, m + 1, R not multiples of 16 / 8 / 16)."""
+    from qcqp_amd import problems
+    n, m, R = 100, 11, 5
+    funcs, _, _ = problems.dense_indefinite(n, m, seed=5)
+    e = make(eng_mod, funcs)
+    prob = orc.Problem(funcs)
+    seed, first, iters = 7, 3, 6
+    X0 = 1.5 * np.random.RandomState(2).randn(n, R)
+    e.upload(X0)
+    out = e.cd_run(phase1=True, num_iters=iters, seed=seed, first_index=first)
+    X = e.download()
+    exact = 0
+    for r in range(R):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(first + r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+        d = np.max(np.abs(X[:, r] - x))
+        # a move of size tol +- rounding may be accepted on one side and rejected on the other
+        # (qcqp.py:168): such restarts differ by O(tol) in a few coordinates, never more
+        assert d < 1e-3, (r, d)
+        exact += d < 1e-6 * (1 + np.max(np.abs(x)))
+        fo = prob.eval(0, x)
+        assert abs(out['f0'][r] - fo) <= 1e-4 * (1 + abs(fo)), r
+        assert (out['maxviol'][r] < 1e-2) == (prob.max_violation(x) < 1e-2), r
+        assert out['sweeps1'][r] == s1[0], r
+        assert abs(prob.eval(0, X[:, r]) - out['f0'][r]) <= 1e-9 * (1 + abs(out['f0'][r]))
+        assert abs(prob.max_violation(X[:, r]) - out['maxviol'][r]) < 1e-9
+    print('restarts identical to rounding:', exact, 'of', R)
+    assert exact >= R // 2
