@@ -63,6 +63,16 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *ctx);
 int qcqpmi_set_quad(qcqpmi_ctx *ctx, int64_t k, int format, const double *vals,
                     const int64_t *idx, const int64_t *ptr, int64_t nnz, const double *q,
                     double r, int relop);
+/* Synthetic dense function generated ON THE DEVICE, in place of qcqpmi_set_quad for function k
+ * (BASELINE.json configs[4]: 1025 dense 4096 x 4096 matrices = 137.6 GB never exist on the host;
+ * SURVEY.md section 8(d) cfg5 "generate on device with Philox from the seed"):
+ *     P_k[i][j] = scale * w_ij * N(seed, k, min(i,j) n + max(i,j)) + diag_add * [i == j],
+ *     w_ii = 1, w_ij = 1/sqrt(2)            (the law of (G + G^T)/2 with G_ij ~ N(0,1), symmetric)
+ *     q_k[j]    = qscale * N'(seed, k, j)
+ * N, N' = the engine's keyed Philox normal (the generator of qcqpmi_pop_randn; oracle:
+ * orc_keyed_normal(seed, 2^48 + k, elem) and orc_keyed_normal(seed, 2^49 + k, j)). */
+int qcqpmi_set_quad_generated(qcqpmi_ctx *ctx, int64_t k, uint64_t seed, double scale, double qscale,
+                              double diag_add, double r, int relop);
 /* Build the device layouts (MFMA-packed P0, per-coordinate constraint lists). */
 int qcqpmi_finalize(qcqpmi_ctx *ctx);
 /* 1 if every constraint touches exactly one coordinate (Boolean / box families) */

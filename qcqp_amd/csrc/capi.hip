@@ -31,6 +31,10 @@ struct HostQuad {
     std::vector<double> q;
     double r = 0.0;
     int relop = 0;
+    // generated on the device (qcqpmi_set_quad_generated)
+    bool gen = false;
+    uint64_t gseed = 0;
+    double gscale = 0.0, gqscale = 0.0, gdiag = 0.0;
 };
 
 struct Timer {
@@ -114,6 +118,7 @@ struct qcqpmi_ctx {
     double *dn_G = nullptr, *dn_Dg = nullptr, *dn_Ft = nullptr;
     int64_t dn_G_cap = 0, dn_state_cap = 0;
     void *dn_state = nullptr;
+    bool dn_force = false;    // generated functions: the dense path is the only one that holds them
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -474,6 +479,30 @@ int qcqpmi_set_quad(qcqpmi_ctx *c, int64_t k, int format, const double *vals, co
     return 0;
 }
 
+int qcqpmi_set_quad_generated(qcqpmi_ctx *c, int64_t k, uint64_t seed, double scale, double qscale,
+                              double diag_add, double r, int relop) {
+    if (!c) return QCQPMI_EINVAL;
+    if (c->finalized) return fail(c, QCQPMI_ESTATE, "set_quad_generated after finalize");
+    if (k < 0 || k > c->m) return fail(c, QCQPMI_EINVAL, "set_quad_generated: bad k");
+    if ((k == 0) != (relop == 0) || relop < 0 || relop > 2)
+        return fail(c, QCQPMI_EINVAL, "set_quad_generated: relop %d invalid for function %lld", relop, (long long)k);
+    HostQuad &h = c->quads[(size_t)k];
+    h = HostQuad();
+    h.gen = true; h.gseed = seed; h.gscale = scale; h.gqscale = qscale; h.gdiag = diag_add;
+    h.r = r; h.relop = relop; h.set = true;
+    // the linear term comes back to the host (n values): the generic finalize code reads it there
+    HIPCHK(c, hipSetDevice(c->device));
+    double *dq = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dq, (size_t)c->n * sizeof(double)));
+    hipLaunchKernelGGL(dense_gen_q_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, dq, c->n, (int)k, seed, qscale);
+    h.q.resize((size_t)c->n);
+    hipError_t e = hipMemcpyAsync(h.q.data(), dq, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dq);
+    if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "set_quad_generated: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int qcqpmi_finalize(qcqpmi_ctx *c) {
     if (!c) return QCQPMI_EINVAL;
     if (c->finalized) return 0;
@@ -490,6 +519,16 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
         for (size_t e = 0; e < h.cv.size(); e++) P[(size_t)h.ci[e] * n16 + h.cj[e]] += h.cv[e];
         for (int64_t j = 0; j < n; j++) q[j] = h.q[j];
         int rc;
+        if (h.gen) {   // generated on the device, mirrored to the host for the diagonal classification below
+            double *tmp = nullptr;
+            if ((rc = dev_alloc(c, &tmp, (size_t)n16 * n16, false))) return rc;
+            hipLaunchKernelGGL(dense_gen_rowmajor_kernel, dim3((unsigned)((n16 * n16 + 255) / 256)), dim3(256), 0, c->stream,
+                               tmp, n, n16, 0, h.gseed, h.gscale, h.gdiag);
+            hipError_t e = hipMemcpyAsync(P.data(), tmp, P.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            (void)hipFree(tmp);
+            if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "finalize: generated objective: %s", hipGetErrorString(e));
+        }
         if ((rc = prob_upload(c, &dp.P0, P))) return rc;
         if ((rc = prob_upload(c, &dp.q0, q))) return rc;
         std::vector<double> rcp2d((size_t)n16, 0.0);
@@ -531,6 +570,7 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
     for (int64_t k = 1; k <= m && sep; k++) {
         const HostQuad &h = c->quads[(size_t)k];
         int coord = -1;
+        if (h.gen) { sep = false; break; }
         for (size_t e = 0; e < h.cv.size(); e++) {
             if (h.ci[e] != h.cj[e]) { sep = false; break; }
             if (coord >= 0 && coord != h.ci[e]) { sep = false; break; }
@@ -606,7 +646,11 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
             for (int64_t j = 0; j < n; j++) gq[(size_t)k * n16 + j] = h.q[j];
             gr[k] = h.r; grel[k] = h.relop;
         }
-        if ((double)m * (double)n * (double)n * 8.0 <= 16e9) {
+        bool all_gen = true;
+        for (int64_t k = 1; k <= m; k++) all_gen = all_gen && c->quads[(size_t)k].gen;
+        c->dn_force = false;
+        for (int64_t k = 0; k <= m; k++) c->dn_force = c->dn_force || c->quads[(size_t)k].gen;
+        if (!all_gen && (double)m * (double)n * (double)n * 8.0 <= 16e9) {
             std::vector<double> gP((size_t)m * n * n, 0.0);
             for (int64_t k = 0; k < m; k++) {
                 const HostQuad &h = c->quads[(size_t)k + 1];
@@ -624,7 +668,8 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
         if ((rc = prob_upload(c, &dp.gq, gq))) return rc;
         if ((rc = prob_upload(c, &dp.gr, gr))) return rc;
         if ((rc = prob_upload(c, &dp.grel, grel))) return rc;
-        if (c->d_gP && (double)(m + 1) * (double)n16 * (double)n16 * 8.0 <= 64e9 && (rc = dense_build(c, gq, gr, grel))) return rc;
+        if ((c->d_gP || all_gen) && (double)(m + 1) * (double)n16 * (double)n16 * 8.0 <= 200e9 && (rc = dense_build(c, gq, gr, grel))) return rc;
+        if (c->dn_force && !c->dn_Gpack) return fail(c, QCQPMI_EUNSUPPORTED, "generated functions need the dense path (matrices exceed 200 GB, or generated and uploaded coupled constraints are mixed beyond 16 GB)");
     }
     if ((rc = dev_alloc(c, &c->d_best_idx, 2))) return rc;
     if ((rc = dev_alloc(c, &c->d_best_key, 2))) return rc;

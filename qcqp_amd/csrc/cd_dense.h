@@ -63,8 +63,8 @@ struct DenseProblem {
 // ------------------------------------------------------------------------------------ packing
 // src: row-major matrix of function k (objective: P0 with ld n16; constraint: gP + (k-1) n^2, ld n)
 __global__ void dense_pack_kernel(const double *__restrict__ P0, const double *__restrict__ gP,
-                                  double *__restrict__ Gpack, int64_t n, int64_t n16, int m1) {
-    const int k = blockIdx.y;
+                                  double *__restrict__ Gpack, int64_t n, int64_t n16, int m1, int kbase) {
+    const int k = kbase + blockIdx.y;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n16 * n16) return;
     const int KS = (int)(n16 / 4);
@@ -75,6 +75,43 @@ __global__ void dense_pack_kernel(const double *__restrict__ P0, const double *_
     double v = 0.0;
     if (row < n && col < n) v = (k == 0) ? P0[row * n16 + col] : gP[((int64_t)(k - 1) * n + row) * n + col];
     Gpack[((b * m1 + k) * KS + kk) * 64 + l] = v;
+}
+
+// synthetic dense function (qcqpmi_set_quad_generated): element (row, col) of function k
+__device__ inline double dense_gen_value(uint64_t seed, int k, int64_t n, int64_t row, int64_t col, double scale,
+                                         double diag_add) {
+    const int64_t lo = row < col ? row : col, hi = row < col ? col : row;
+    const double g = keyed_normal(seed, (1ull << 48) + (uint64_t)k, (uint64_t)(lo * n + hi));
+    return (row == col) ? scale * g + diag_add : scale * 0.70710678118654752440 * g;
+}
+
+// straight into the block-major fragment layout
+__global__ void dense_gen_pack_kernel(double *__restrict__ Gpack, int64_t n, int64_t n16, int m1, int k, uint64_t seed,
+                                      double scale, double diag_add) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n16 * n16) return;
+    const int KS = (int)(n16 / 4);
+    const int l = (int)(idx & 63);
+    const int64_t fk = idx >> 6;
+    const int64_t b = fk / KS, kk = fk % KS;
+    const int64_t row = 16 * b + (l & 15), col = 4 * kk + (l >> 4);
+    double v = 0.0;
+    if (row < n && col < n) v = dense_gen_value(seed, k, n, row, col, scale, diag_add);
+    Gpack[((b * m1 + k) * KS + kk) * 64 + l] = v;
+}
+
+// row-major padded (the objective's P0) and the linear term
+__global__ void dense_gen_rowmajor_kernel(double *__restrict__ P, int64_t n, int64_t n16, int k, uint64_t seed,
+                                          double scale, double diag_add) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n16 * n16) return;
+    const int64_t row = idx / n16, col = idx % n16;
+    P[idx] = (row < n && col < n) ? dense_gen_value(seed, k, n, row, col, scale, diag_add) : 0.0;
+}
+
+__global__ void dense_gen_q_kernel(double *__restrict__ q, int64_t n, int k, uint64_t seed, double qscale) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) q[j] = (qscale == 0.0) ? 0.0 : qscale * keyed_normal(seed, (2ull << 48) + (uint64_t)k, (uint64_t)j);
 }
 
 // ----------------------------------------------------------------------------------- products

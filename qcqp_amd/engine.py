@@ -39,8 +39,13 @@ class Engine(object):
         if rc:
             raise EngineError(self.L.qcqpmi_last_error(None).decode())
         self.h = h
-        for k, f in enumerate([form.f0] + list(form.fs)):
-            self._set_quad(k, f)
+        if hasattr(form, 'specs'):     # GeneratedForm: functions synthesised on the device
+            for k, g in enumerate(form.specs):
+                self._chk(self.L.qcqpmi_set_quad_generated(self.h, k, int(g['seed']), float(g['scale']), float(g['qscale']),
+                                                           float(g['diag_add']), float(g['r']), RELOP_CODE[g['relop']]))
+        else:
+            for k, f in enumerate([form.f0] + list(form.fs)):
+                self._set_quad(k, f)
         self._chk(self.L.qcqpmi_finalize(self.h))
 
     # ------------------------------------------------------------------ plumbing

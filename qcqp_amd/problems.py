@@ -96,3 +96,49 @@ def dense_indefinite(n, m, seed=7, easy=True):
         funcs.append((sym(), rs.randn(n), r, '<='))
     funcs.append((np.eye(n), np.zeros(n), -float(n), '<='))
     return funcs, False, {}
+
+
+class GeneratedForm(object):
+    """A QCQP whose dense functions are synthesised ON THE DEVICE from a seed
+    (qcqpmi_set_quad_generated; BASELINE.json configs[4] at full size is 137.6 GB of matrices).
+    specs[0] is the objective; every entry: seed, scale, qscale, diag_add, r, relop."""
+
+    def __init__(self, n, specs):
+        self.n, self.m, self.specs = int(n), len(specs) - 1, list(specs)
+
+
+def dense_indefinite_generated(n, m, seed=7, easy=True):
+    """The dense_indefinite family with device-side generation: P_k ~ (G+G^T)/2, G = randn/sqrt(n)
+    (same law, symmetric by construction), q_k = randn, r_k = -(1+|z_k|) [* n/8], last constraint the
+    ball ||x||^2 <= n."""
+    rs = np.random.RandomState(seed)
+    sc = 1.0 / np.sqrt(n)
+    specs = [dict(seed=seed, scale=sc, qscale=1.0, diag_add=0.0, r=0.0, relop=None)]
+    for k in range(m - 1):
+        r = -1. - abs(rs.randn())
+        if easy:
+            r *= n / 8.
+        specs.append(dict(seed=seed, scale=sc, qscale=1.0, diag_add=0.0, r=r, relop='<='))
+    specs.append(dict(seed=seed, scale=0.0, qscale=0.0, diag_add=1.0, r=-float(n), relop='<='))
+    return GeneratedForm(n, specs)
+
+
+def materialise_generated(form, keyed_normal):
+    """The same functions as NumPy arrays (small n only): keyed_normal(seed, stream, elem) is the
+    oracle's orc_keyed_normal.  Returns the usual [(P, q, r, relop), ...] list."""
+    n = form.n
+    funcs = []
+    for k, g in enumerate(form.specs):
+        P = np.zeros((n, n))
+        q = np.zeros(n)
+        for i in range(n):
+            for j in range(i, n):
+                v = g['scale'] * keyed_normal(g['seed'], (1 << 48) + k, i * n + j) if g['scale'] != 0.0 else 0.0
+                if i == j:
+                    P[i, i] = v + g['diag_add']
+                else:
+                    P[i, j] = P[j, i] = v * 0.70710678118654752440
+            if g['qscale'] != 0.0:
+                q[i] = g['qscale'] * keyed_normal(g['seed'], (2 << 48) + k, i)
+        funcs.append((P, q, g['r'], g['relop']))
+    return funcs

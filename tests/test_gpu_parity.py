@@ -499,3 +499,35 @@ def test_dense_path_default_dispatch_vs_oracle(eng_mod, orc):
         assert abs(prob.max_violation(X[:, r]) - out['maxviol'][r]) < 1e-9
     print('restarts identical to rounding:', exact, 'of', R)
     assert exact >= R // 2
+
+
+def test_generated_functions_match_oracle_stream(eng_mod, orc):
+    """qcqpmi_set_quad_generated: matrices synthesised on the device (cfg5 at full size never exists
+    on the host) are the ones the oracle's keyed generator defines -- checked through the function
+    values of random points, and a CD run on the generated problem against the oracle on the
+    materialised one."""
+    from qcqp_amd import problems
+    n, m, R = 40, 6, 9
+    form = problems.dense_indefinite_generated(n, m, seed=21)
+    funcs = problems.materialise_generated(form, orc.keyed_normal)
+    e = eng_mod.Engine(form)
+    assert not e.separable
+    prob = orc.Problem(funcs)
+    X = 0.7 * np.random.RandomState(3).randn(n, R)
+    f0, mv, F = e.eval_batch(X, want_F=True)
+    for r in range(R):
+        for k in range(m + 1):
+            assert abs(F[k, r] - prob.eval(k, X[:, r])) <= 1e-11 * (1 + abs(F[k, r])), (k, r)
+    g0, gv = prob.eval_batch(X)
+    assert rel(f0, g0) < 1e-11 and rel(mv, gv) < 1e-11
+    out = e.cd_run(phase1=True, num_iters=8, seed=5)
+    Xg = e.download()
+    close = 0
+    for r in range(R):
+        rng = orc.Rng(orc.RNG_KEYED, 5)
+        rng.set_restart(r)
+        x, s1, s2 = prob.improve_cd(X[:, r], num_iters=8, rng=rng)
+        assert np.max(np.abs(Xg[:, r] - x)) < 1e-3
+        close += np.max(np.abs(Xg[:, r] - x)) < 1e-6
+        assert abs(prob.eval(0, Xg[:, r]) - out['f0'][r]) <= 1e-9 * (1 + abs(out['f0'][r]))
+    assert close >= R // 2
