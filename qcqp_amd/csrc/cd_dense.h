@@ -143,7 +143,7 @@ typedef double dn_v2d __attribute__((ext_vector_type(2)));
 //   MODE 0: G of block a.b (contraction split over grid.z);
 //   MODE 1: quadratic forms f_k(x) = x' P_k x + q_k' x + r_k (row blocks split over grid.z)
 template <int MODE>
-__global__ __launch_bounds__(256) void dense_products_kernel(DenseProdArgs a) {
+__global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a) {
     extern __shared__ double smem[];
     const DenseProblem &D = a.D;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -195,28 +195,55 @@ __global__ __launch_bounds__(256) void dense_products_kernel(DenseProdArgs a) {
 #pragma unroll
         for (int p = 0; p < 8; p++)
             *reinterpret_cast<dn_v2d *>(smem + ((buf * 16 + 2 * p + half) * 256 + off)) = pf[p];
+        {
+            const int c1 = (ch_lo + 1 < ch_hi) ? ch_lo + 1 : ch_lo;
+#pragma unroll
+            for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)c1 * 256);
+        }
         __syncthreads();
+        // Stage ch multiplies out of `buf`.  The registers hold stage ch+1, fetched a whole stage ago:
+        // they go to the other buffer first (no wait), then the fetch of stage ch+2 is issued and
+        // stays in flight behind the 64 MFMAs.  All loads are unconditional (clamped).
         for (int ch = ch_lo; ch < ch_hi; ch++) {
-            const int chn = (ch + 1 < ch_hi) ? ch + 1 : ch;   // unconditional (clamped) prefetch
+#pragma unroll
+            for (int p = 0; p < 8; p++)
+                *reinterpret_cast<dn_v2d *>(smem + (((buf ^ 1) * 16 + 2 * p + half) * 256 + off)) = pf[p];
+            const int chn = (ch + 2 < ch_hi) ? ch + 2 : ch_hi - 1;
 #pragma unroll
             for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)chn * 256);
             const double *As = smem + (buf * 16 + 4 * wm) * 256 + lane;
             const double *Bs = smem + (buf * 16 + 8 + 4 * wn) * 256 + lane;
-            double av[DP_KC][4], bv[DP_KC][4];
+            if (MODE == 0) {
+                double av[DP_KC][4], bv[DP_KC][4];
 #pragma unroll
-            for (int ks = 0; ks < DP_KC; ks++)
+                for (int ks = 0; ks < DP_KC; ks++)
 #pragma unroll
-                for (int u = 0; u < 4; u++) { av[ks][u] = As[u * 256 + ks * 64]; bv[ks][u] = Bs[u * 256 + ks * 64]; }
+                    for (int u = 0; u < 4; u++) { av[ks][u] = As[u * 256 + ks * 64]; bv[ks][u] = Bs[u * 256 + ks * 64]; }
 #pragma unroll
-            for (int ks = 0; ks < DP_KC; ks++)
+                for (int ks = 0; ks < DP_KC; ks++)
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < 4; u++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][u], bv[ks][t], acc[u][t], 0, 0, 0);
+                        for (int t = 0; t < 4; t++)
+                            acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][u], bv[ks][t], acc[u][t], 0, 0, 0);
+            } else {
+                // the quadratic-form accumulators need 32 more registers: operands two k-steps at a time
 #pragma unroll
-            for (int p = 0; p < 8; p++)
-                *reinterpret_cast<dn_v2d *>(smem + (((buf ^ 1) * 16 + 2 * p + half) * 256 + off)) = pf[p];
+                for (int k2 = 0; k2 < DP_KC; k2 += 2) {
+                    double av[2][4], bv[2][4];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { av[ks][u] = As[u * 256 + (k2 + ks) * 64]; bv[ks][u] = Bs[u * 256 + (k2 + ks) * 64]; }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+#pragma unroll
+                            for (int t = 0; t < 4; t++)
+                                acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][u], bv[ks][t], acc[u][t], 0, 0, 0);
+                }
+            }
             __syncthreads();
             buf ^= 1;
         }
@@ -244,10 +271,7 @@ __global__ __launch_bounds__(256) void dense_products_kernel(DenseProdArgs a) {
                     const int tt = (tl0 + t < a.ntiles) ? tl0 + t : a.ntiles - 1;
                     const double xi = a.X[(int64_t)tt * D.n16 * 16 + i * 16 + (lane & 15)];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int kk = (kf0 + u < D.m1) ? kf0 + u : D.m1 - 1;
-                        fa[u][t] += xi * (acc[u][t][v] + D.q[(int64_t)kk * D.n16 + i]);
-                    }
+                    for (int u = 0; u < 4; u++) fa[u][t] += xi * acc[u][t][v];   // q_k' x: dense_linear_kernel
                 }
             }
         }
@@ -267,9 +291,26 @@ __global__ __launch_bounds__(256) void dense_products_kernel(DenseProdArgs a) {
     }
 }
 
+// linear terms  lin[k][gr] = q_k' x_gr  (2 m1 n flops per candidate: noise next to the quadratic forms)
+__global__ __launch_bounds__(256) void dense_linear_kernel(DenseProblem D, const double *__restrict__ X, int64_t Rpad,
+                                                           double *__restrict__ lin) {
+    const int r = threadIdx.x & 15, k = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int64_t tile = blockIdx.x;
+    if (k >= D.m1) return;
+    const double *q = D.q + (int64_t)k * D.n16, *x = X + tile * D.n16 * 16 + r;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int64_t j = 0; j < D.n16; j += 4) {
+        s0 = __builtin_fma(q[j], x[j * 16], s0);
+        s1 = __builtin_fma(q[j + 1], x[(j + 1) * 16], s1);
+        s2 = __builtin_fma(q[j + 2], x[(j + 2) * 16], s2);
+        s3 = __builtin_fma(q[j + 3], x[(j + 3) * 16], s3);
+    }
+    lin[(int64_t)k * Rpad + tile * 16 + r] = (s0 + s1) + (s2 + s3);
+}
+
 // f0 and the maximum violation of every candidate from the table of function values; also the
 // restart-major copy Ft[gr][k] the chain kernel tracks
-__global__ void dense_viol_kernel(double *__restrict__ F, int zs, const int *__restrict__ relop, int m1, int m1p,
+__global__ void dense_viol_kernel(double *__restrict__ F, int zs, const double *__restrict__ lin, const int *__restrict__ relop, int m1, int m1p,
                                   int64_t Rpad, double *__restrict__ f0, double *__restrict__ maxviol,
                                   double *__restrict__ Ft) {
     const int64_t gr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,6 +319,7 @@ __global__ void dense_viol_kernel(double *__restrict__ F, int zs, const int *__r
     for (int k = 0; k < m1; k++) {
         double f = F[(int64_t)k * Rpad + gr];
         for (int z = 1; z < zs; z++) f += F[((int64_t)z * m1 + k) * Rpad + gr];   // partial planes, fixed order
+        f += lin[(int64_t)k * Rpad + gr];
         F[(int64_t)k * Rpad + gr] = f;
         if (Ft) Ft[gr * m1p + k] = f;
         if (k == 0) continue;
