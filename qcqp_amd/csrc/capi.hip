@@ -118,6 +118,8 @@ struct qcqpmi_ctx {
     double *dn_G = nullptr, *dn_Dg = nullptr, *dn_Ft = nullptr;
     int64_t dn_G_cap = 0, dn_state_cap = 0;
     void *dn_state = nullptr;
+    hipStream_t stream2 = nullptr;   // second stream of the dense path: products of block b+1 while the chain walks b
+    hipEvent_t dn_ev[3] = {nullptr, nullptr, nullptr};
     bool dn_force = false;    // generated functions: the dense path is the only one that holds them
     // comm
     ncclComm_t comm = nullptr;
@@ -443,6 +445,8 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
                     c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
+    for (auto &e : c->dn_ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

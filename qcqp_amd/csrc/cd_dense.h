@@ -125,6 +125,9 @@ struct DenseProdArgs {
     double *F;              // MODE 1: [zs][m1][Rpad] partial quadratic forms
     int64_t Rpad;
     const uint8_t *tile_on; // MODE 0: optional per-tile "any restart sweeping" flags, or nullptr
+    int hole;               // MODE 0: stage (block of 16 columns) left out of the contraction, or -1
+    int ch_only;            // MODE 0: >= 0: contract over this stage alone and store into plane `zplane` (fix-up)
+    int zplane;
 };
 
 constexpr int DP_FG = 8;    // functions per workgroup
@@ -173,8 +176,16 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
     const int NBc = D.NB;   // stages per full contraction
     const int b_lo = (MODE == 0) ? a.b : (int)((int64_t)z * D.NB / a.zs);
     const int b_hi = (MODE == 0) ? a.b + 1 : (int)((int64_t)(z + 1) * D.NB / a.zs);
-    const int ch_lo = (MODE == 0) ? (int)((int64_t)z * NBc / a.zs) : 0;
-    const int ch_hi = (MODE == 0) ? (int)((int64_t)(z + 1) * NBc / a.zs) : NBc;
+    // MODE 0 walks a LIST of stages: all of them, all but the hole, or the fix-up stage alone
+    const int hole = (MODE == 0) ? a.hole : -1, only = (MODE == 0) ? a.ch_only : -1;
+    const int nch = only >= 0 ? 1 : (hole >= 0 ? NBc - 1 : NBc);
+    const int zsk = only >= 0 ? 1 : a.zs;
+    const int ch_lo = (MODE == 0) ? (int)((int64_t)z * nch / zsk) : 0;
+    const int ch_hi = (MODE == 0) ? (int)((int64_t)(z + 1) * nch / zsk) : NBc;
+    auto stage_of = [&](int j) {   // list position -> stage, clamped to a valid one
+        int st = only >= 0 ? only : ((hole >= 0 && j >= hole) ? j + 1 : j);
+        return st < NBc ? st : NBc - 1;
+    };
     for (int b = b_lo; b < b_hi; b++) {
         dn_v4d acc[4][4];
 #pragma unroll
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
         }
         dn_v2d pf[8];
 #pragma unroll
-        for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)ch_lo * 256);
+        for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)stage_of(ch_lo) * 256);
         int buf = 0;
         __syncthreads();   // the previous row block's readers are done with both buffers
 #pragma unroll
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
         {
             const int c1 = (ch_lo + 1 < ch_hi) ? ch_lo + 1 : ch_lo;
 #pragma unroll
-            for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)c1 * 256);
+            for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)stage_of(c1) * 256);
         }
         __syncthreads();
         // Stage ch multiplies out of `buf`.  The registers hold stage ch+1, fetched a whole stage ago:
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
                 *reinterpret_cast<dn_v2d *>(smem + (((buf ^ 1) * 16 + 2 * p + half) * 256 + off)) = pf[p];
             const int chn = (ch + 2 < ch_hi) ? ch + 2 : ch_hi - 1;
 #pragma unroll
-            for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)chn * 256);
+            for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)stage_of(chn) * 256);
             const double *As = smem + (buf * 16 + 4 * wm) * 256 + lane;
             const double *Bs = smem + (buf * 16 + 8 + 4 * wn) * 256 + lane;
             if (MODE == 0) {
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
         }
         if (MODE == 0) {
             // D layout: register v of lane l = row c = (l >> 4) + 4 v, column r = l & 15
-            double *Gz = a.G + (int64_t)z * a.ntiles * 256 * D.m1p;
+            double *Gz = a.G + (int64_t)(only >= 0 ? a.zplane : z) * a.ntiles * 256 * D.m1p;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 if (tl0 + t >= a.ntiles) continue;
