@@ -127,6 +127,17 @@ int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, 
                     double rho, const double *Minv, int64_t *iters1, int64_t *iters2, double *f0,
                     double *maxviol);
 
+/* solve_sdr (qcqp.py:72-97) for the UNIT-DIAGONAL family -- constraints x_i^2 = d_i, i.e. Boolean least
+ * squares, MAXCUT, partitioning; the host scales d to 1:
+ *     minimise <C, X>  s.t.  X_ii = 1, X PSD,   C symmetric N x N (N = n + 1, homogenised, row-major)
+ * in Burer-Monteiro form X = V V^T (V: N x 64, unit rows) by the mixing method on the device.  V holds the
+ * start on entry and the solution on return; hist[0] = start objective, hist[t] = objective after sweep
+ * t, hist[*sweeps_done + 1] = objective recomputed at the end (hist has max_sweeps + 2 entries).
+ * The reference delegates this to cvxpy + an SDP solver: parity unpinned, validated by optimality
+ * conditions. */
+int qcqpmi_sdr_solve_unitdiag(qcqpmi_ctx *ctx, const double *C, int64_t N, double *V, int max_sweeps,
+                              double tol, double *hist, int *sweeps_done);
+
 /* ---- QCQPForm.better ordering over the population (utilities.py:135-146):
  * lexicographic minimum of (int(maxviol/tol), f0), ties -> lowest index.  Evaluates the
  * population if needed.  best_x (n doubles) may be NULL. */

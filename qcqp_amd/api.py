@@ -158,8 +158,15 @@ class QCQP(object):
                 if hasattr(self, 'mu'):
                     del self.mu
             if self.sdr_sol is None:
-                raise Exception("SDR suggest needs the lifted SDP solution: no SDP solver is available; "
-                                "pass suggest(SDR, X=...) or set qcqp.sdr_sol / qcqp.sdr_bound first.")
+                # solve_sdr (qcqp.py:72-97): own solver for the unit-diagonal family, on the device
+                from . import sdr as _sdr
+                sol = _sdr.solve_sdr(self.engine, self.qcqp_form, seed=0 if seed is None else seed)
+                if sol is None:
+                    raise Exception("SDR suggest: the built-in SDP solver covers problems whose constraints are "
+                                    "x_i^2 == d_i (Boolean least squares, MAXCUT, partitioning); for other "
+                                    "families pass suggest(SDR, X=...) or set qcqp.sdr_sol / qcqp.sdr_bound first.")
+                self.sdr_sol, bound, self.sdr_info = sol
+                self.sdr_bound = -bound if self.maximize_flag else bound    # qcqp.py:392-393
             if not hasattr(self, 'mu'):
                 X = np.asarray(self.sdr_sol, dtype=np.float64)
                 self.mu = np.asarray(X[:-1, -1]).flatten()

@@ -17,6 +17,7 @@
 #include "admm.h"
 #include "cd_general.h"
 #include "cd_dense.h"
+#include "sdr_solve.h"
 
 using namespace qcqpmi;
 
@@ -681,6 +682,49 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
     // host copies are no longer needed
     for (auto &h : c->quads) { std::vector<int>().swap(h.ci); std::vector<int>().swap(h.cj); std::vector<double>().swap(h.cv); }
     c->finalized = true;
+    return 0;
+}
+
+int qcqpmi_sdr_solve_unitdiag(qcqpmi_ctx *c, const double *C, int64_t N, double *V, int max_sweeps, double tol,
+                              double *hist, int *sweeps_done) {
+    if (!c) return QCQPMI_EINVAL;
+    if (!C || !V || !hist || !sweeps_done || N < 2 || max_sweeps < 0 || !(tol >= 0.0))
+        return fail(c, QCQPMI_EINVAL, "sdr_solve_unitdiag: bad arguments");
+    if (N > SDR_NMAX) return fail(c, QCQPMI_EUNSUPPORTED, "sdr_solve_unitdiag: N = %lld exceeds %d", (long long)N, SDR_NMAX);
+    HIPCHK(c, hipSetDevice(c->device));
+    double *dC = nullptr, *dV = nullptr, *dh = nullptr;
+    int *ds = nullptr;
+    SdrWork *dw = nullptr;
+    int rc = 0;
+    if ((rc = dev_alloc(c, &dC, (size_t)N * N, false))) return rc;
+    if (!rc) rc = dev_alloc(c, &dV, (size_t)N * SDR_K, false);
+    if (!rc) rc = dev_alloc(c, &dh, (size_t)max_sweeps + 2);
+    if (!rc) rc = dev_alloc(c, &ds, 1);
+    if (!rc) rc = dev_alloc(c, &dw, 1);      // zeroed: arrival counter, abort flag
+    hipError_t e = hipSuccess;
+    int sw = 0;
+    if (!rc) {
+        e = hipMemcpyAsync(dC, C, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dV, V, (size_t)N * SDR_K * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            // 64 single-wave workgroups that synchronise through memory: cooperative launch = co-residency guaranteed
+            const double *aC = dC;
+            int aN = (int)N;
+            void *args[] = {(void *)&aC, (void *)&dV, (void *)&aN, (void *)&max_sweeps, (void *)&tol, (void *)&dh, (void *)&ds, (void *)&dw};
+            e = hipLaunchCooperativeKernel((const void *)sdr_mixing_kernel, dim3(SDR_K), dim3(64), args,
+                                           (unsigned)(2 * (size_t)N * sizeof(double)), c->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(V, dV, (size_t)N * SDR_K * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hist, dh, ((size_t)max_sweeps + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&sw, ds, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    void *ptrs[] = {dC, dV, dh, ds, dw};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "sdr_solve_unitdiag: %s", hipGetErrorString(e));
+    if (sw < 0) return fail(c, QCQPMI_EHIP, "sdr_solve_unitdiag: the workgroups lost step (spin limit reached)");
+    *sweeps_done = sw;
     return 0;
 }
 

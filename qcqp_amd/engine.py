@@ -164,6 +164,22 @@ class Engine(object):
                                          _ip(out['iters2']), _dp(out['f0']), _dp(out['maxviol'])))
         return out
 
+    # ------------------------------------------------------------ SDP relaxation
+    def sdr_solve_unitdiag(self, Cm, V0=None, max_sweeps=2000, tol=1e-10, seed=0):
+        """min <C, X> s.t. diag(X) = 1, X PSD (mixing method on the device).  Returns V (N x 64, unit
+        rows, X = V V^T), the objective history and the number of sweeps."""
+        Cm = np.ascontiguousarray(Cm, dtype=np.float64)
+        N = Cm.shape[0]
+        assert Cm.shape == (N, N)
+        if V0 is None:
+            V0 = np.random.RandomState(seed).randn(N, 64)
+            V0 /= np.linalg.norm(V0, axis=1)[:, None]
+        V = np.ascontiguousarray(V0, dtype=np.float64).copy()
+        hist = np.zeros(max_sweeps + 2)
+        sw = C.c_int(0)
+        self._chk(self.L.qcqpmi_sdr_solve_unitdiag(self.h, _dp(Cm), N, _dp(V), int(max_sweeps), float(tol), _dp(hist), C.byref(sw)))
+        return V, hist[:sw.value + 2], sw.value
+
     # ------------------------------------------------------------------ selection
     def select_best(self, tol=1e-4, want_x=True):
         idx = np.zeros(1, dtype=np.int64)

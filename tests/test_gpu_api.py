@@ -117,3 +117,67 @@ def test_admm_rho_too_small_raises_like_reference():
     with pytest.raises(Exception) as ei:
         q.improve(ADMM, rho=1e-6)
     assert 'rho parameter is too small' in str(ei.value)
+
+
+# ------------------------------------------------------------- own SDP relaxation (solve_sdr)
+def _brute_force_pm1(P0, q0, r0, n):
+    best = np.inf
+    for mask in range(1 << n):
+        x = np.array([1.0 if (mask >> i) & 1 else -1.0 for i in range(n)])
+        best = min(best, x.dot(P0.dot(x)) + q0.dot(x) + r0)
+    return best
+
+
+def test_sdr_solver_unit_diagonal_family_optimality():
+    """solve_sdr replacement (mixing method on the device): no reference result exists to compare with
+    (third-party solver), so the solution is validated by optimality conditions -- dual certificate
+    S = C + diag(y) PSD, zero duality gap -- and by brute force on small instances:
+    SDP bound <= optimum (BLS, minimise);  optimum <= SDP bound <= optimum / 0.878 (MAXCUT)."""
+    from qcqp_amd import problems, sdr
+    from qcqp_amd.engine import Engine
+    from qcqp_amd.form import QCQPForm
+    # Boolean least squares, the README data (np.random.seed(1), n=10, 15 rows): optimum 35.55097 (SURVEY 8c)
+    funcs, _, _ = problems.boolean_least_squares(10, 15, seed=1)
+    form = QCQPForm.from_arrays(funcs)
+    e = Engine(form)
+    X, bound, info = sdr.solve_sdr(e, form)
+    y, lmin, lower = sdr.dual_certificate(info['C'], info['V'])
+    assert lmin > -1e-6 * (1 + np.abs(info['C']).max())
+    assert abs(bound - (-y.sum())) <= 1e-6 * (1 + abs(bound))            # zero duality gap
+    assert np.allclose(np.diag(X), 1.0, atol=1e-12)
+    assert np.linalg.eigvalsh(X)[0] > -1e-9
+    P0, q0, r0 = np.asarray(funcs[0][0]), np.asarray(funcs[0][1]), funcs[0][2]
+    opt = _brute_force_pm1(P0, q0, r0, 10)
+    assert lower <= opt + 1e-9 and bound <= opt + 1e-6
+    assert bound > 0.5 * opt                                                   # and not a trivial bound
+    assert np.all(np.diff(info['hist'][:-1]) <= 1e-9)                         # monotone decrease
+    # MAXCUT n=12 (maximise): cut <= SDP bound <= cut / 0.878
+    funcs, maxi, ex = problems.maxcut(12, 0.5, seed=3)
+    form = QCQPForm.from_arrays(funcs)
+    e = Engine(form)
+    X, bound, info = sdr.solve_sdr(e, form)
+    y, lmin, lower = sdr.dual_certificate(info['C'], info['V'])
+    assert lmin > -1e-6
+    P0, q0, r0 = np.asarray(funcs[0][0]), np.asarray(funcs[0][1]), funcs[0][2]
+    best_cut = -_brute_force_pm1(P0, q0, r0, 12)
+    sdp_cut = -bound
+    assert best_cut <= sdp_cut + 1e-6 and sdp_cut <= best_cut / 0.878 + 1e-6
+
+
+def test_suggest_sdr_end_to_end_without_external_solver():
+    """BASELINE configs[0]: suggest(SDR) + improve(COORD_DESCENT) on the README problem, the SDP solved by
+    the engine itself; with samples from the relaxation the best point reaches the brute-force optimum."""
+    from qcqp_amd import QCQP, SDR, COORD_DESCENT, problems
+    from qcqp_amd.api import Problem
+    funcs, _, _ = problems.boolean_least_squares(10, 15, seed=1)
+    prob = Problem.from_minimize_form(funcs)
+    q = QCQP(prob)
+    f, v = q.suggest(SDR, num_samples=64, seed=11)
+    assert q.sdr_bound is not None and q.sdr_bound <= 35.55097 + 1e-4
+    f, v = q.improve(COORD_DESCENT, seed=3)
+    assert v < 1e-2
+    x = np.sign(prob.variables()[0].value).ravel()
+    P0, q0, r0 = np.asarray(funcs[0][0]), np.asarray(funcs[0][1]), funcs[0][2]
+    fx = x.dot(P0.dot(x)) + q0.dot(x) + r0
+    assert abs(fx - 35.55097) < 1e-3, fx
+    assert q.sdr_bound <= fx + 1e-6
