@@ -30,12 +30,18 @@ def unit_diagonal_family(form):
             return None
         if np.any(np.asarray(f.qarray) != 0.0):
             return None
-        P = _dense(f.P)
-        nz = np.argwhere(P != 0.0)
-        if len(nz) != 1 or nz[0][0] != nz[0][1]:
+        if hasattr(f.P, 'tocoo'):            # scipy sparse: never densify (n matrices of n x n)
+            Pc = f.P.tocoo()
+            keep = Pc.data != 0.0
+            rows, cols, vals = Pc.row[keep], Pc.col[keep], Pc.data[keep]
+        else:
+            P = np.asarray(f.P)
+            rows, cols = np.nonzero(P)
+            vals = P[rows, cols]
+        if len(vals) != 1 or rows[0] != cols[0]:
             return None
-        i = int(nz[0][0])
-        p = P[i, i]
+        i = int(rows[0])
+        p = float(vals[0])
         di = -f.r / p
         if not (di > 0.0) or not np.isnan(d[i]):
             return None
