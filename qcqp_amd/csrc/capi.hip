@@ -91,6 +91,7 @@ struct qcqpmi_ctx {
     int maxc = 0;
     int K = 0;
     int objclass = 0;  // 1: every P0[i,i] > 0, 2: every P0[i,i] == 0, 0: mixed
+    bool symcls = false;  // one constraint class of the form p x_i^2 + r == 0 (feasible sets mirrored about 0)
     DevProblem dp{};
     std::vector<void *> prob_allocs;
     // population
@@ -263,7 +264,8 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
         dim3 block512(512);
 #define QM_RS(XL, FA)                                                                               \
     do {                                                                                            \
-        auto k = cd_phase2_rs_kernel<XL, FA>;                                                       \
+        auto k = (c->n % 16 == 0) ? (c->symcls ? cd_phase2_rs_kernel<XL, FA, true, true> : cd_phase2_rs_kernel<XL, FA, true, false>) \
+                                  : (c->symcls ? cd_phase2_rs_kernel<XL, FA, false, true> : cd_phase2_rs_kernel<XL, FA, false, false>); \
         HIPCHK(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds)); \
         tic(c, 2);                                                                                  \
         hipLaunchKernelGGL(k, grid, block512, rs_lds, c->stream, a1, dp.Apack, dp.Apack2, dp.P0, dp.q0, dp.rcp2d); \
@@ -629,6 +631,11 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
             }
             dp.K = (int)krep.size();
             c->K = dp.K;
+            c->symcls = false;
+            if (dp.K == 1 && maxc == 1) {
+                const int e0 = cptr[krep[0]];
+                c->symcls = cq[e0] == 0.0 && crel[e0] == RELOP_EQ && cp[e0] != 0.0;
+            }
             if ((rc = prob_upload(c, &dp.krep, krep))) return rc;
             if ((rc = prob_upload(c, &dp.cls, cls))) return rc;
         }

@@ -34,6 +34,7 @@
 // block is then recomputed by the generic loop, which follows the reference's arithmetic
 // literally (onevar_minimise in onevar.h).
 #pragma once
+#include <stdint.h>
 #include "cd_phase2.h"
 
 namespace qcqpmi {
@@ -146,7 +147,9 @@ __device__ inline v4d_ rs_compute(v2d_ (&ar)[2 * RS_PFU], const double *__restri
 
 // ------------------------------------------------------------------------------------ kernel
 
-template <bool XLDS, int FAST>
+// FULL: n is a multiple of 16 (every block has 16 coordinates: no per-step bounds test in the chain)
+// SYM:  the constraint is p x_i^2 + r == 0 (no linear term): the feasible set is mirrored about 0 at every slack
+template <bool XLDS, int FAST, bool FULL, bool SYM>
 __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const double *__restrict__ Apack,
                                                            const double *__restrict__ Apack2,
                                                            const double *__restrict__ P0,
@@ -339,19 +342,21 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
             if (lane < 16 && !(a.dbg & 8)) {
                 const int cmax = (P.n - 16 * (int64_t)b) < 16 ? (int)(P.n - 16 * (int64_t)b) : 16;  // uniform
                 const bool act = !S.conv;
+                const bool actn = act && U.n > 0;
+                // SYM: [-b, -a] u [a, b]  (one interval [-b, b]: a = 0)
+                const double syma = (U.n >= 2) ? U.l1 : 0.0, symb = (U.n >= 2) ? U.h1 : U.h0;
                 int upd = (int)S.upd_counter, accn = 0;
-                bool redo = false;
+                unsigned mv = 0;     // FULL: bit 15 - c = coordinate c moved (instead of two counters per step)
+                bool allfar = true;  // no decision close to a tie, no NaN
                 double fcur = S.fcur;
-                double xn_[16];
-#pragma unroll
-                for (int c = 0; c < 16; c++) xn_[c] = xb[c];
                 // row c of the diagonal block (wave-uniform LDS broadcast reads), fetched one step ahead
-                // into ping-pong register sets (no copies).  The base address is laundered through
-                // a VGPR so that every read is `ds_read base, offset:imm` instead of one
-                // s_add + v_mov per read.
-                int vzero;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-                const double *Dv = Dblk + vzero, *rtv = rtb + vzero;
+                // into ping-pong register sets (no copies).  The LDS addresses are laundered through
+                // VGPRs so that every read is `ds_read base, offset:imm` (< 2 KB) with no address math.
+                typedef __attribute__((address_space(3))) const double lds_cdouble;
+                unsigned dva = (unsigned)(uintptr_t)(lds_cdouble *)Dblk, rta = (unsigned)(uintptr_t)(lds_cdouble *)rtb;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(dva) : "v"(dva));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(rta) : "v"(rta));
+                lds_cdouble *Dv = (lds_cdouble *)(uintptr_t)dva, *rtv = (lds_cdouble *)(uintptr_t)rta;
                 double dr[2][16], t2v[2], rv[2];
                 t2v[0] = Dv[0];
                 rv[0] = rtv[0];
@@ -359,7 +364,8 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                 for (int c2 = 1; c2 < 16; c2++) dr[0][c2] = Dv[c2];
 #pragma unroll
                 for (int c = 0; c < 16; c++) {
-                    if (c >= cmax) continue;   // wave-uniform
+                    if (!FULL && c >= cmax) continue;   // wave-uniform
+                    asm volatile("" ::: "memory");     // LDS reads stay exactly one step ahead (register pressure)
                     if (c + 1 < 16) {
                         t2v[(c + 1) & 1] = Dv[(c + 1) * 16 + (c + 1)];
                         rv[(c + 1) & 1] = rtv[c + 1];
@@ -370,32 +376,51 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                     const double xi = xb[c];
                     const double g2 = gb[c];                      // G_i + q_i / 2  (includes P_ii x_i)
                     double pick;
-                    bool nr;
-                    if (FAST == 1) {
+                    bool far;
+                    if (FAST == 1 && SYM) {
+                        // sets mirrored about 0 (x_i^2 within a band): clamp |xv|, put the sign back
                         const double xv = __builtin_fma(-g2, rt, xi);          // vertex of the scalar objective
+                        pick = __builtin_copysign(fmin(fmax(fabs(xv), syma), symb), xv);
+                        far = fabs(xv) > U.thr;                                // false for NaN as well
+                    } else if (FAST == 1) {
+                        const double xv = __builtin_fma(-g2, rt, xi);
                         const double p0 = fmin(fmax(xv, U.l0), U.h0);
                         const double p1 = fmin(fmax(xv, U.l1), U.h1);
                         pick = (xv > U.mid) ? p1 : p0;
-                        nr = fabs(xv - U.mid) <= U.thr;
+                        far = fabs(xv - U.mid) > U.thr;
                     } else {
                         // linear scalar objective: slope t1 = 2 (G_i + q_i/2), extreme end point against it
                         const double L = U.l0;
                         const double H = (U.n >= 2) ? U.h1 : U.h0;
                         pick = (g2 > 0.0) ? L : H;
-                        nr = 2.0 * fabs(g2) * (fabs(L) + fabs(H)) <= 1e-9 * fabs(fcur) + 1e-300;
+                        far = 2.0 * fabs(g2) * (fabs(L) + fabs(H)) > 1e-9 * fabs(fcur) + 1e-300 && pick == pick;
                     }
-                    redo = redo || nr || !(pick == pick);
+                    allfar = allfar && far;
                     const double dlt = pick - xi;
-                    const bool moved = act && U.n > 0 && fabs(dlt) > a.tol;
+                    const bool moved = actn && fabs(dlt) > a.tol;
                     const double delta = moved ? dlt : 0.0;
-                    xn_[c] = moved ? pick : xi;
+                    xb[c] = moved ? pick : xi;                    // in place: committed to LDS only if no redo
                     // f(pick) - f(xi) = delta (t2 delta + t1),  t1 = 2 (g2 - t2 xi)
-                    fcur += delta * __builtin_fma(t2, delta, 2.0 * (g2 - t2 * xi));
-                    accn += moved ? 1 : 0;
-                    upd = moved ? 0 : upd + 1;
+                    //                 = delta (t2 (delta - 2 xi) + 2 g2)
+                    const double hh = __builtin_fma(-2.0, xi, delta);
+                    fcur = __builtin_fma(delta, __builtin_fma(t2, hh, g2) + g2, fcur);
+                    if (FULL) {
+                        // pinned in place (a plain expression is sunk to the end of the block by the
+                        // scheduler, keeping 16 compare masks alive = SGPR spills)
+                        const unsigned b01 = moved ? 1u : 0u;
+                        asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(mv) : "v"(b01));
+                    } else {
+                        accn += moved ? 1 : 0;
+                        upd = moved ? 0 : upd + 1;
+                    }
 #pragma unroll
                     for (int c2 = c + 1; c2 < 16; c2++) gb[c2] = __builtin_fma(dr[c & 1][c2], delta, gb[c2]);
                 }
+                if (FULL) {
+                    accn = __builtin_popcount(mv);
+                    upd = mv ? __builtin_ctz(mv) : upd + 16;
+                }
+                bool redo = !allfar;
                 redo = act && U.n > 0 && (redo || U.slow != 0);
                 if (__builtin_amdgcn_ballot_w64(redo) == 0ull) {
                     if (act) {
@@ -408,14 +433,15 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                         if (over >= 0) S.conv = true;
                     }
 #pragma unroll
-                    for (int c = 0; c < 16; c++) Xs[(16 * b + c) * 16 + r] = xn_[c];
+                    for (int c = 0; c < 16; c++) Xs[(16 * b + c) * 16 + r] = xb[c];
                 } else {
                     // ---- generic loop (rare): the reference's arithmetic, state in LDS (Gsc, X rows)
                     pc[6]++;
                     for (int c = 0; c < cmax; c++) {
                         const int64_t i = 16 * (int64_t)b + c;
                         FeasSet<MAXC> C;
-                        C.n = U.n; C.lo[0] = U.l0; C.hi[0] = U.h0; C.lo[1] = U.l1; C.hi[1] = U.h1;
+                        // (rare path: the set comes back from the LDS table, not from registers held all kernel long)
+                        C.n = U.n; C.lo[0] = TC.lo[r]; C.hi[0] = TC.hi[r]; C.lo[1] = TC.lo[16 + r]; C.hi[1] = TC.hi[16 + r];
                         const double t2g = Dblk[c * 16 + c];
                         const double xi = Xs[i * 16 + r];
                         const double hq = hqb[c];

@@ -88,8 +88,12 @@ def test_errors_mirror_reference():
     with pytest.raises(Exception) as ei:
         q.improve('nope')
     assert 'Unknown improve method(s)' in str(ei.value.args[0])
-    with pytest.raises(Exception):
-        q.suggest(SDR)          # no SDP solution available
+    q.suggest(SDR)              # Boolean family: the engine's own SDP solver applies
+    assert q.sdr_sol is not None and q.sdr_bound is not None
+    funcs2, _, _ = problems.dense_indefinite(6, 3, seed=2)
+    with pytest.raises(Exception) as ei:
+        handler(funcs2).suggest(SDR)    # other families: X must come from the caller
+    assert 'suggest(SDR, X=...)' in str(ei.value)
     with pytest.raises(Exception) as ei:
         q.improve('dccp')
     assert 'DCCP package is not installed.' in str(ei.value)
