@@ -113,6 +113,8 @@ struct qcqpmi_ctx {
     double *ad_W = nullptr, *ad_lam = nullptr, *ad_qhat = nullptr, *ad_rk = nullptr, *ad_slo = nullptr, *ad_ehi = nullptr, *ad_Minv = nullptr;
     int *ad_relop = nullptr;
     void *rb_handle = nullptr;
+    double *d_planes = nullptr;   // partial planes of x'P0x from the GEMM evaluation
+    int64_t planes_cap = 0;
     double *d_gP = nullptr;   // dense constraint matrices [m][n][n] (problems whose constraints couple coordinates)
     // dense-constraint path (cd_dense.h): all matrices in block-major fragment order + work buffers
     const double *dn_Gpack = nullptr, *dn_q = nullptr, *dn_qT = nullptr, *dn_r = nullptr;
@@ -236,7 +238,29 @@ int launch_eval(qcqpmi_ctx *c, bool want_F) {
     EvalArgs a;
     a.P = c->dp; a.X = c->X; a.R = c->R; a.f0 = c->d_f0; a.maxviol = c->d_mv;
     a.F = want_F ? c->d_F : nullptr; a.Rpad = c->Rpad;
+    a.planes = nullptr; a.nplanes = 0;
     tic(c, 0);
+    const int NB = (int)(c->n16 / 16), ntiles = (int)(c->Rpad / 16);
+    if (NB >= 8 && ntiles >= 8) {
+        // x'P0x through the LDS-tiled GEMM: 8 row blocks x 8 tiles per workgroup share their operands
+        // (the per-tile MFMA loop of eval_kernel re-reads all of P0 from L2 for every tile)
+        const int groups = (NB + DP_FG - 1) / DP_FG, nplanes = 2 * groups;
+        if ((int64_t)nplanes * c->Rpad > c->planes_cap) {
+            if (c->d_planes) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_planes); c->d_planes = nullptr; }
+            int rc = dev_alloc(c, &c->d_planes, (size_t)nplanes * c->Rpad);
+            if (rc) return rc;
+            c->planes_cap = (int64_t)nplanes * c->Rpad;
+        }
+        DenseProdArgs pa;
+        pa.D.Gpack = c->dp.Apack; pa.D.q = nullptr; pa.D.qT = nullptr; pa.D.r = nullptr; pa.D.relop = nullptr;
+        pa.D.n = c->n; pa.D.n16 = c->n16; pa.D.NB = NB; pa.D.KS = (int)(c->n16 / 4); pa.D.m1 = 1; pa.D.m1p = 64;
+        pa.X = c->X; pa.ntiles = ntiles; pa.b = 0; pa.zs = 1; pa.G = nullptr; pa.F = c->d_planes; pa.Rpad = c->Rpad;
+        pa.tile_on = nullptr; pa.hole = -1; pa.ch_only = -1; pa.zplane = 0;
+        auto kg = dense_products_kernel<2>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES));
+        hipLaunchKernelGGL(kg, dim3((unsigned)groups, (unsigned)((ntiles + DP_TG - 1) / DP_TG), 1), dim3(256), DP_LDS_BYTES, c->stream, pa);
+        a.planes = c->d_planes; a.nplanes = nplanes;
+    }
     hipLaunchKernelGGL(eval_kernel, dim3((unsigned)(c->Rpad / 16)), dim3(256), 0, c->stream, a);
     toc(c, 0);
     HIPCHK(c, hipGetLastError());
@@ -445,7 +469,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
     for (auto &e : c->dn_ev) if (e) (void)hipEventDestroy(e);
@@ -815,8 +839,21 @@ int qcqpmi_pop_sdr_sample(qcqpmi_ctx *c, const double *mu, const double *F, int6
                            c->Xi, n, n16, S, c->Rpad, seed, first_index);
     }
     tic(c, 3);
-    hipLaunchKernelGGL(affine_tiles_kernel, dim3((unsigned)(c->Rpad / 16)), dim3(256), 0, c->stream,
-                       c->d_Fpack, c->d_mu, c->Xi, c->X, n, n16, c->dp.NB, c->dp.KS);
+    if (c->dp.NB >= 8 && c->Rpad / 16 >= 8) {
+        // x = mu + F xi as one LDS-tiled MFMA GEMM (8 row blocks of F x 8 tiles of samples per workgroup)
+        DenseProdArgs pa;
+        pa.D.Gpack = c->d_Fpack; pa.D.q = c->d_mu; pa.D.qT = nullptr; pa.D.r = nullptr; pa.D.relop = nullptr;
+        pa.D.n = n; pa.D.n16 = n16; pa.D.NB = (int)c->dp.NB; pa.D.KS = (int)c->dp.KS; pa.D.m1 = 1; pa.D.m1p = 64;
+        pa.X = c->Xi; pa.ntiles = (int)(c->Rpad / 16); pa.b = 0; pa.zs = 1; pa.G = c->X; pa.F = nullptr; pa.Rpad = c->Rpad;
+        pa.tile_on = nullptr; pa.hole = -1; pa.ch_only = -1; pa.zplane = 0;
+        auto kg = dense_products_kernel<3>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES));
+        hipLaunchKernelGGL(kg, dim3((unsigned)((pa.D.NB + DP_FG - 1) / DP_FG), (unsigned)((pa.ntiles + DP_TG - 1) / DP_TG), 1),
+                           dim3(256), DP_LDS_BYTES, c->stream, pa);
+    } else {
+        hipLaunchKernelGGL(affine_tiles_kernel, dim3((unsigned)(c->Rpad / 16)), dim3(256), 0, c->stream,
+                           c->d_Fpack, c->d_mu, c->Xi, c->X, n, n16, c->dp.NB, c->dp.KS);
+    }
     toc(c, 3);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -145,6 +145,10 @@ typedef double dn_v2d __attribute__((ext_vector_type(2)));
 // Per stage and wave: 32 ds_read_b64 feed 64 MFMAs.
 //   MODE 0: G of block a.b (contraction split over grid.z);
 //   MODE 1: quadratic forms f_k(x) = x' P_k x + q_k' x + r_k (row blocks split over grid.z)
+//   MODE 2: ONE matrix (D.m1 == 1, Gpack = the objective's Apack): the 8 streams are 8 ROW BLOCKS of it,
+//           x' P x accumulated per row-block group into partial planes F[2 blockIdx.x + wm][Rpad]
+//   MODE 3: ONE matrix as in MODE 2, affine map  OUT = mu 1' + M X  stored tile-major (SDR sampling
+//           x = mu + F xi, qcqp.py:396): a.G = OUT, D.q = mu
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a) {
     extern __shared__ double smem[];
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         const int f = f0 + 2 * p + half, t = tg0 + 2 * p + half;
-        fs[p] = f < D.m1 ? f : D.m1 - 1;            // clamped: loaded, multiplied, never stored
+        fs[p] = (MODE >= 2) ? (f < D.NB ? f : D.NB - 1) : (f < D.m1 ? f : D.m1 - 1);   // clamped: loaded, multiplied, never stored
         ts[p] = t < a.ntiles ? t : a.ntiles - 1;
     }
     const int kf0 = f0 + 4 * wm, tl0 = tg0 + 4 * wn;   // this wave's functions / tiles
@@ -174,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
 #pragma unroll
         for (int t = 0; t < 4; t++) fa[u][t] = 0.0;
     const int NBc = D.NB;   // stages per full contraction
-    const int b_lo = (MODE == 0) ? a.b : (int)((int64_t)z * D.NB / a.zs);
-    const int b_hi = (MODE == 0) ? a.b + 1 : (int)((int64_t)(z + 1) * D.NB / a.zs);
+    const int b_lo = (MODE == 0) ? a.b : (MODE >= 2 ? 0 : (int)((int64_t)z * D.NB / a.zs));
+    const int b_hi = (MODE == 0) ? a.b + 1 : (MODE >= 2 ? 1 : (int)((int64_t)(z + 1) * D.NB / a.zs));
     // MODE 0 walks a LIST of stages: all of them, all but the hole, or the fix-up stage alone
     const int hole = (MODE == 0) ? a.hole : -1, only = (MODE == 0) ? a.ch_only : -1;
     const int nch = only >= 0 ? 1 : (hole >= 0 ? NBc - 1 : NBc);
@@ -195,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
         const double *src[8];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            src[p] = D.Gpack + (((int64_t)b * D.m1 + fs[p]) * D.KS) * 64 + off;
+            src[p] = (MODE >= 2) ? D.Gpack + ((int64_t)fs[p] * D.KS) * 64 + off
+                                 : D.Gpack + (((int64_t)b * D.m1 + fs[p]) * D.KS) * 64 + off;
             src[4 + p] = a.X + (int64_t)ts[p] * D.n16 * 16 + off;
         }
         dn_v2d pf[8];
@@ -273,6 +278,35 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
                         if (kf0 + u < D.m1) g[u] = acc[u][t][v];
                 }
             }
+        } else if (MODE == 3) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (kf0 + u >= D.NB) continue;   // wave-uniform
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (tl0 + t >= a.ntiles) continue;
+                    double *xo = a.G + (int64_t)(tl0 + t) * D.n16 * 16;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int64_t i = 16 * (int64_t)(kf0 + u) + (lane >> 4) + 4 * v;
+                        xo[i * 16 + (lane & 15)] = (i < D.n) ? D.q[i] + acc[u][t][v] : 0.0;
+                    }
+                }
+            }
+        } else if (MODE == 2) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (kf0 + u >= D.NB) continue;   // wave-uniform
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int64_t i = 16 * (int64_t)(kf0 + u) + (lane >> 4) + 4 * v;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int tt = (tl0 + t < a.ntiles) ? tl0 + t : a.ntiles - 1;
+                        fa[0][t] += a.X[(int64_t)tt * D.n16 * 16 + i * 16 + (lane & 15)] * acc[u][t][v];
+                    }
+                }
+            }
         } else {
 #pragma unroll
             for (int v = 0; v < 4; v++) {
@@ -285,6 +319,16 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
                     for (int u = 0; u < 4; u++) fa[u][t] += xi * acc[u][t][v];   // q_k' x: dense_linear_kernel
                 }
             }
+        }
+    }
+    if (MODE == 2) {
+        double *Fz = a.F + (int64_t)(2 * blockIdx.x + wm) * a.Rpad;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            double s = fa[0][t];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16 && tl0 + t < a.ntiles) Fz[(int64_t)(tl0 + t) * 16 + lane] = s;
         }
     }
     if (MODE == 1) {

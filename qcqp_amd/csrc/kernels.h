@@ -51,6 +51,8 @@ struct EvalArgs {
     double *maxviol;   // [Rpad]
     double *F;         // optional (m+1) x Rpad row-major, or nullptr
     int64_t Rpad;
+    const double *planes;   // optional: x'P0x already computed as nplanes partial sums [nplanes][Rpad]
+    int nplanes;            // (dense_products_kernel<2>); the kernel then only adds q0'x + r0 and the constraints
 };
 
 struct CdArgs {

@@ -145,7 +145,13 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a) {
     // between run at ~90-140 cycles instead of 64).
     double facc = 0.0;
     const int xoff = (lane >> 4) * 16 + (lane & 15);
-    for (int64_t b0 = 4 * wave; b0 < P.NB; b0 += 16) {
+    if (a.planes) {
+        // quadratic part from the LDS-tiled GEMM (partial planes, fixed order); linear part here
+        for (int64_t i = tid >> 4; i < P.n; i += 16) facc = __builtin_fma(Xs[i * 16 + r], P.q0[i], facc);
+        if (tid < 16)
+            for (int p = 0; p < a.nplanes; p++) facc += a.planes[(int64_t)p * a.Rpad + tile * 16 + tid];
+    }
+    for (int64_t b0 = 4 * wave; b0 < P.NB && !a.planes; b0 += 16) {
         v4d acc[4];
         const double *Ab[4];
 #pragma unroll
