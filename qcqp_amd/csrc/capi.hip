@@ -113,6 +113,9 @@ struct qcqpmi_ctx {
     double *ad_W = nullptr, *ad_lam = nullptr, *ad_qhat = nullptr, *ad_rk = nullptr, *ad_slo = nullptr, *ad_ehi = nullptr, *ad_Minv = nullptr;
     int *ad_relop = nullptr;
     void *rb_handle = nullptr;
+    // outputs of a run packed into one device buffer, copied with ONE transfer into pinned host memory
+    char *d_out = nullptr, *h_out = nullptr;
+    int64_t out_cap = 0;
     double *d_planes = nullptr;   // partial planes of x'P0x from the GEMM evaluation
     int64_t planes_cap = 0;
     double *d_gP = nullptr;   // dense constraint matrices [m][n][n] (problems whose constraints couple coordinates)
@@ -223,6 +226,56 @@ void toc(qcqpmi_ctx *c, int which) {
 
 bool dense_on(const qcqpmi_ctx *c);
 int launch_eval_dense(qcqpmi_ctx *c, bool with_Ft);
+
+// per-restart results of a coordinate-descent run -> host: one pack kernel, one copy into pinned memory,
+// one synchronisation (nine pageable copies cost ~0.3 ms of staging kernels per call)
+__global__ void pack_cd_outputs_kernel(char *out, int64_t R, const int64_t *s1, const int64_t *s2, const int64_t *vis,
+                                       const int64_t *acc, const double *f0, const double *mv, const int *st,
+                                       const int *st1, const uint8_t *flag) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    int64_t *o64 = (int64_t *)out;
+    o64[r] = s1[r]; o64[R + r] = s2[r]; o64[2 * R + r] = vis[r]; o64[3 * R + r] = acc[r];
+    double *od = (double *)(out + 32 * R);
+    od[r] = f0[r]; od[R + r] = mv[r];
+    int *oi = (int *)(out + 48 * R);
+    oi[r] = st[r]; oi[R + r] = st1[r];
+    ((uint8_t *)(out + 56 * R))[r] = flag[r];
+}
+
+int fetch_cd_outputs(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
+                     uint8_t *ran_phase2, double *f0, double *maxviol, std::vector<int> &st, std::vector<int> &st1) {
+    const int64_t R = c->R, bytes = 57 * R;
+    if (bytes > c->out_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_out) (void)hipFree(c->d_out);
+        if (c->h_out) (void)hipHostFree(c->h_out);
+        c->d_out = c->h_out = nullptr;
+        HIPCHK(c, hipMalloc((void **)&c->d_out, (size_t)bytes));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_out, (size_t)bytes, hipHostMallocDefault));
+        c->out_cap = bytes;
+    }
+    hipLaunchKernelGGL(pack_cd_outputs_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream, c->d_out, R,
+                       (const int64_t *)c->d_sweeps1, (const int64_t *)c->d_sweeps, (const int64_t *)c->d_visits,
+                       (const int64_t *)c->d_acc, (const double *)c->d_f0, (const double *)c->d_mv,
+                       (const int *)c->d_status, (const int *)c->d_status1, (const uint8_t *)c->d_flag);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const char *h = c->h_out;
+    const size_t n8 = (size_t)R * 8;
+    if (sweeps1) memcpy(sweeps1, h, n8);
+    if (sweeps2) memcpy(sweeps2, h + n8, n8);
+    if (visits2) memcpy(visits2, h + 2 * n8, n8);
+    if (accepted2) memcpy(accepted2, h + 3 * n8, n8);
+    if (f0) memcpy(f0, h + 4 * n8, n8);
+    if (maxviol) memcpy(maxviol, h + 5 * n8, n8);
+    st.resize((size_t)R); st1.resize((size_t)R);
+    memcpy(st.data(), h + 6 * n8, (size_t)R * 4);
+    memcpy(st1.data(), h + 6 * n8 + (size_t)R * 4, (size_t)R * 4);
+    if (ran_phase2) memcpy(ran_phase2, h + 7 * n8, (size_t)R);
+    return 0;
+}
 
 int launch_eval(qcqpmi_ctx *c, bool want_F) {
     if (dense_on(c)) return launch_eval_dense(c, false);   // coupled constraints: every function on the matrix cores
@@ -469,7 +522,8 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes, c->d_out};
+    if (c->h_out) (void)hipHostFree(c->h_out);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
     for (auto &e : c->dn_ev) if (e) (void)hipEventDestroy(e);
@@ -928,20 +982,11 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
     hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((c->Rpad + 255) / 256)), dim3(256), 0, c->stream, c->d_mv,
                        c->d_status1, c->d_flag, c->R, c->Rpad, viol_tol);
     HIPCHK(c, hipGetLastError());
-    if (ran_phase2) HIPCHK(c, hipMemcpyAsync(ran_phase2, c->d_flag, (size_t)c->R, hipMemcpyDeviceToHost, c->stream));
     rc = (c->maxc <= 1) ? launch_cd<1>(c, a, false, used_lds) : launch_cd<4>(c, a, false, used_lds);
     if (rc) return rc;
     if ((rc = launch_eval(c, false))) return rc;
-    std::vector<int> st((size_t)c->R), st1((size_t)c->R);
-    if (sweeps1) HIPCHK(c, hipMemcpyAsync(sweeps1, c->d_sweeps1, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    if (sweeps2) HIPCHK(c, hipMemcpyAsync(sweeps2, c->d_sweeps, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    if (visits2) HIPCHK(c, hipMemcpyAsync(visits2, c->d_visits, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    if (accepted2) HIPCHK(c, hipMemcpyAsync(accepted2, c->d_acc, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    if (f0) HIPCHK(c, hipMemcpyAsync(f0, c->d_f0, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (maxviol) HIPCHK(c, hipMemcpyAsync(maxviol, c->d_mv, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st1.data(), c->d_status1, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int> st, st1;
+    if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
     for (int64_t r = 0; r < c->R; r++) {
         if (st1[(size_t)r] == -3)
             return fail(c, QCQPMI_EREFERENCE, "phase 1: a variable appears in no constraint (reference: ValueError: max() arg is an empty sequence, qcqp.py:117); restart %lld", (long long)r);
