@@ -292,17 +292,39 @@ __global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
                 double ss = -a.tol, es = viol - a.viol_tol;
                 uint32_t it = 0;
                 my_visits++;
+                // Only the LAST successful bisection step decides the point (qcqp.py:126-131 overwrite new_xi
+                // each time) and every draw of the counter-based stream is independent of the others, so
+                // the Philox draw is deferred: a successful step just remembers its set and its draw
+                // index.  A set with an unbounded piece draws at once (the reference may raise there).
+                FeasSet<MAXC> Cp;
+                uint32_t itp = 0;
+                bool pending = false;
                 while (es - ss > a.tol) {
                     double s = (ss + es) / 2.0;
                     FeasSet<MAXC> C;
                     if (mf == 1) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], s, C);
                     else feasible_set<MAXC>(cp, cq, cr, crel, mf, s, C);
-                    DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t, it++};
+                    const uint32_t itc = it++;
+                    if (C.n == 0) { ss = s; continue; }
+                    bool unb = false;
+#pragma unroll
+                    for (int j = 0; j <= MAXC; j++) unb = unb || (j < C.n && (__builtin_isinf(C.lo[j]) || __builtin_isinf(C.hi[j])));
+                    if (unb) {
+                        DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t, itc};
+                        double xn;
+                        int got = onevar_minimise<MAXC>(0.0, 0.0, 0.0, C, dk, &xn);
+                        if (got < 0) { my_status = got; pending = false; break; }
+                        new_xi = xn; pending = false;
+                    } else {
+                        Cp = C; itp = itc; pending = true;
+                    }
+                    new_viol = s; es = s;
+                }
+                if (pending) {
+                    DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t, itp};
                     double xn;
-                    int got = onevar_minimise<MAXC>(0.0, 0.0, 0.0, C, dk, &xn);
-                    if (got < 0) { my_status = got; break; }
-                    if (!got) ss = s;
-                    else { new_xi = xn; new_viol = s; es = s; }
+                    (void)onevar_minimise<MAXC>(0.0, 0.0, 0.0, Cp, dk, &xn);
+                    new_xi = xn;
                 }
                 if (new_viol < viol) { xi = new_xi; Xs[i * 16 + r] = xi; upd = 1; my_acc++; }
                 // violation of the constraints on x_i after the update (feeds qcqp.py:142)
