@@ -283,7 +283,10 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
         ChainState S;
         S.fcur = 0.0; S.upd_counter = 0; S.visits = 0; S.accepted = 0; S.sweeps = 0;
         S.conv = true; S.status = 0;
-        if (lane < 16 && gr < a.R) {
+        // ALL 64 lanes walk the chain: lanes l, l+16, l+32, l+48 carry the same restart (r = l & 15) and
+        // compute the same values.  No divergent region = fix-up and chain are one basic block, and the
+        // scheduler starts the chain's LDS reads under the fix-up MFMAs.
+        if (gr < a.R) {
             S.conv = a.flag[gr] ? false : true;
             S.fcur = a.f0cur[gr];
         }
@@ -322,14 +325,12 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                     Gsc[c * 16 + (lane & 15)] = s + hqb[c];
                 }
                 // same wave: LDS operations complete in order, no barrier needed before reading Gsc
-                if (lane < 16) {
 #pragma unroll
-                    for (int c = 0; c < 16; c++) {
-                        gb[c] = Gsc[c * 16 + r];
-                        xb[c] = Xs[(16 * b + c) * 16 + r];
-                    }
+                for (int c = 0; c < 16; c++) {
+                    gb[c] = Gsc[c * 16 + r];
+                    xb[c] = Xs[(16 * b + c) * 16 + r];
                 }
-                if (lane < 16 && b == 0 && !S.conv) S.sweeps++;
+                if (b == 0 && !S.conv) S.sweeps++;
             }
             PROF_TICK(2)
             PROF_TICK(3)
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
 #pragma unroll
                 for (int u = 0; u < 4; u++) afix[u] = ap[u * 64];
             }
-            if (lane < 16 && !(a.dbg & 8)) {
+            {
                 const int cmax = (P.n - 16 * (int64_t)b) < 16 ? (int)(P.n - 16 * (int64_t)b) : 16;  // uniform
                 const bool act = !S.conv;
                 const bool actn = act && U.n > 0;
@@ -432,8 +433,10 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                         S.upd_counter = upd;
                         if (over >= 0) S.conv = true;
                     }
+                    if (lane < 16) {
 #pragma unroll
-                    for (int c = 0; c < 16; c++) Xs[(16 * b + c) * 16 + r] = xb[c];
+                        for (int c = 0; c < 16; c++) Xs[(16 * b + c) * 16 + r] = xb[c];
+                    }
                 } else {
                     // ---- generic loop (rare): the reference's arithmetic, state in LDS (Gsc, X rows)
                     pc[6]++;
