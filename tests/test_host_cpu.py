@@ -156,3 +156,59 @@ def test_two_process_gloo_selection(tmp_path, orc):
     key = dist.select_best_host(f0, mv, 1e-4)
     assert int(r0[2]) == key[2] and r0[1] == key[1]
     assert np.array_equal(r0[3:], xs[:, key[2]])
+
+
+# ------------------------------------------------------------------ host logic of the SDP relaxation
+def test_sdr_family_detection_and_lifted_cost():
+    """qcqp_amd/sdr.py (no GPU): the unit-diagonal family is recognised (dense and sparse constraint
+    matrices, any positive d_i), everything else is refused, and the lifted cost reproduces the objective:
+    f0(x) = [y; 1]' C [y; 1] with x = sqrt(d) * y."""
+    import scipy.sparse as sp
+    from qcqp_amd import problems, sdr
+    from qcqp_amd.form import QCQPForm
+    funcs, _, _ = problems.boolean_least_squares(7, 9, seed=3)
+    form = QCQPForm.from_arrays(funcs)
+    d = sdr.unit_diagonal_family(form)
+    assert d is not None and np.allclose(d, 1.0)
+    # x_i^2 = d_i with different d, sparse matrices
+    n = 5
+    rs = np.random.RandomState(0)
+    G = rs.randn(n, n)
+    dd = np.array([0.5, 2.0, 1.0, 4.0, 0.25])
+    fs = [((G + G.T) / 2, rs.randn(n), 0.3, None)]
+    for i in range(n):
+        P = sp.csr_matrix(([3.0], ([i], [i])), shape=(n, n))
+        fs.append((P, np.zeros(n), -3.0 * dd[i], '=='))
+    form2 = QCQPForm.from_arrays(fs)
+    d2 = sdr.unit_diagonal_family(form2)
+    assert np.allclose(d2, dd)
+    C, sc = sdr.lifted_cost(form2, d2)
+    assert np.allclose(C, C.T) and np.allclose(sc, np.append(np.sqrt(dd), 1.0))
+    y = rs.randn(n)
+    x = np.sqrt(dd) * y
+    P0, q0, r0 = fs[0][0], fs[0][1], fs[0][2]
+    z = np.append(y, 1.0)
+    assert abs(z.dot(C.dot(z)) - (x.dot(P0.dot(x)) + q0.dot(x) + r0)) < 1e-12
+    # refused: inequality, linear term, off-diagonal entry, a coordinate without constraint, d <= 0
+    bad = [fs[:1] + [(np.eye(n), np.zeros(n), -1.0, '<=')] * n,
+           fs[:1] + [(np.diag(np.eye(n)[i]), np.eye(n)[i], -1.0, '==') for i in range(n)],
+           fs[:1] + [(np.ones((n, n)), np.zeros(n), -1.0, '==')] * n,
+           fs[:-1],
+           fs[:1] + [(np.diag(np.eye(n)[i]), np.zeros(n), +1.0, '==') for i in range(n)]]
+    for b in bad:
+        assert sdr.unit_diagonal_family(QCQPForm.from_arrays(b)) is None
+
+
+def test_sdr_dual_certificate_on_a_known_solution():
+    """C = -J (all ones) has the SDP optimum X = J (rank one, v_i identical): y_i = N - ... certificate PSD,
+    zero gap; a non-optimal V gives a negative lambda_min and a bound below the optimum."""
+    from qcqp_amd import sdr
+    N = 6
+    C = -np.ones((N, N))
+    V = np.zeros((N, 64)); V[:, 0] = 1.0            # X = J
+    y, lmin, lower = sdr.dual_certificate(C, V)
+    assert np.allclose(y, N) and lmin > -1e-12
+    assert abs(lower - (-N * N)) < 1e-9              # = <C, J>: zero duality gap
+    V2 = np.zeros((N, 64)); V2[np.arange(N), np.arange(N)] = 1.0   # X = I: feasible, not optimal
+    y2, lmin2, lower2 = sdr.dual_certificate(C, V2)
+    assert lmin2 < -1.0 and lower2 <= -N * N + 1e-9
