@@ -531,3 +531,31 @@ def test_generated_functions_match_oracle_stream(eng_mod, orc):
         close += np.max(np.abs(Xg[:, r] - x)) < 1e-6
         assert abs(prob.eval(0, Xg[:, r]) - out['f0'][r]) <= 1e-9 * (1 + abs(out['f0'][r]))
     assert close >= R // 2
+
+
+@pytest.mark.parametrize('n', [20, 32])
+def test_cd_phase2_exact_ties_take_the_reference_path(eng_mod, orc, n):
+    """The fast path of the pipelined kernel hands every decision close to a tie to a loop that follows
+    the reference's arithmetic literally.  Objective x'x with x_i^2 == 1: the vertex of every scalar
+    problem is exactly 0, the midpoint between the two feasible intervals -- EVERY visit is a tie, the
+    reference breaks it with np.random.choice (utilities.py:283-288), here with the keyed stream the
+    oracle shares.  Both block shapes (n a multiple of 16 or not)."""
+    funcs = [(np.eye(n), np.zeros(n), 0.0, None)]
+    for i in range(n):
+        P = np.zeros((n, n)); P[i, i] = 1.0
+        funcs.append((P, np.zeros(n), -1.0, '=='))
+    e = make(eng_mod, funcs)
+    assert e.separable
+    prob = orc.Problem(funcs)
+    R, seed, first = 7, 77, 2
+    rs = np.random.RandomState(n)
+    X0 = np.sign(rs.randn(n, R)) * (1.0 + 2e-3 * rs.rand(n, R))
+    e.upload(X0)
+    out = e.cd_run(phase1=False, num_iters=30, seed=seed, first_index=first)
+    X = e.download()
+    for r in range(R):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(first + r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=30, phase1=False, rng=rng)
+        assert rel(X[:, r], x) < 1e-12, (r, np.max(np.abs(X[:, r] - x)))
+        assert out['visits2'][r] == s2[1] and out['accepted2'][r] == s2[2], r
