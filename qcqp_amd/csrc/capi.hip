@@ -453,16 +453,8 @@ int cd_run_general(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol
     toc(c, 2);
     HIPCHK(c, hipGetLastError());
     if ((rc = launch_eval(c, false))) return rc;
-    std::vector<int> st((size_t)c->R), st1((size_t)c->R);
-    if (sweeps1) HIPCHK(c, hipMemcpyAsync(sweeps1, c->d_sweeps1, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    if (sweeps2) HIPCHK(c, hipMemcpyAsync(sweeps2, c->d_sweeps, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    if (visits2) HIPCHK(c, hipMemcpyAsync(visits2, c->d_visits, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    if (accepted2) HIPCHK(c, hipMemcpyAsync(accepted2, c->d_acc, (size_t)c->R * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    if (f0) HIPCHK(c, hipMemcpyAsync(f0, c->d_f0, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (maxviol) HIPCHK(c, hipMemcpyAsync(maxviol, c->d_mv, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st1.data(), c->d_status1, (size_t)c->R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int> st, st1;
+    if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, nullptr, f0, maxviol, st, st1))) return rc;
     for (int64_t r = 0; r < c->R; r++) {
         const int s1 = st1[(size_t)r], s2 = st[(size_t)r];
         if (s1 == -3) return fail(c, QCQPMI_EREFERENCE, "phase 1: a variable appears in no constraint (reference: ValueError: max() arg is an empty sequence, qcqp.py:117); restart %lld", (long long)r);

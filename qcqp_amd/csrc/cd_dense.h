@@ -730,23 +730,48 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
             else {
                 double new_viol = viol, ss = -a.tol, es = viol - a.viol_tol;
                 uint32_t it = 0;
+                // Only the last successful step decides the point and the keyed draws are independent of
+                // each other: a successful step leaves its segment list in LDS (failed steps write nothing)
+                // and the Philox draw happens once, after the bisection.  A list with an unbounded piece
+                // draws at once (the reference may raise there).
+                int ns_p = 0;
+                uint32_t it_p = 0;
+                bool pending = false;
                 while (es - ss > a.tol) {
                     const double sm = (ss + es) / 2.0;
                     const int ns = dn_feasible_set(W, D, lane, sm, &overflow);
-                    int got = 0;
+                    const uint32_t itc = it++;
+                    if (ns == 0) { ss = sm; continue; }
+                    bool unb = false;
+                    if (lane == 0)
+                        for (int j = 0; j < ns; j++) unb = unb || __builtin_isinf(W.seglo[j]) || __builtin_isinf(W.seghi[j]);
+                    if (__builtin_amdgcn_readfirstlane((int)unb)) {
+                        int got = 0;
+                        double xc = 0.0;
+                        if (lane == 0) {
+                            SegList C = SL;
+                            C.n = ns;
+                            DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)a.t, itc};
+                            got = general_minimise(0.0, 0.0, 0.0, C, dk, &xc);
+                        }
+                        got = __builtin_amdgcn_readfirstlane(got);
+                        xc = dn_bcast0(xc);
+                        if (got < 0) { status = got; live = false; on = false; pending = false; break; }
+                        xn = xc; pending = false;
+                    } else {
+                        ns_p = ns; it_p = itc; pending = true;
+                    }
+                    new_viol = sm; es = sm;
+                }
+                if (pending) {
                     double xc = 0.0;
                     if (lane == 0) {
                         SegList C = SL;
-                        C.n = ns;
-                        DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)a.t, it};
-                        got = general_minimise(0.0, 0.0, 0.0, C, dk, &xc);
+                        C.n = ns_p;
+                        DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)a.t, it_p};
+                        (void)general_minimise(0.0, 0.0, 0.0, C, dk, &xc);
                     }
-                    it++;
-                    got = __builtin_amdgcn_readfirstlane(got);
-                    xc = dn_bcast0(xc);
-                    if (got < 0) { status = got; live = false; on = false; break; }
-                    if (!got) ss = sm;
-                    else { xn = xc; new_viol = sm; es = sm; }
+                    xn = dn_bcast0(xc);
                 }
                 if (status == 0) {
                     if (new_viol < viol) { moved = true; upd = 0; accepted++; }
