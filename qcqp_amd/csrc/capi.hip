@@ -341,8 +341,12 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
         dim3 block512(512);
 #define QM_RS(XL, FA)                                                                               \
     do {                                                                                            \
-        auto k = (c->n % 16 == 0) ? (c->symcls ? cd_phase2_rs_kernel<XL, FA, true, true> : cd_phase2_rs_kernel<XL, FA, true, false>) \
-                                  : (c->symcls ? cd_phase2_rs_kernel<XL, FA, false, true> : cd_phase2_rs_kernel<XL, FA, false, false>); \
+        auto k = cd_phase2_rs_kernel<XL, FA, false, false, false>;                                  \
+        const bool full_ = (c->n % 16 == 0), sym_ = c->symcls, prof_ = a1.prof != nullptr;          \
+        if (prof_) k = full_ ? (sym_ ? cd_phase2_rs_kernel<XL, FA, true, true, true> : cd_phase2_rs_kernel<XL, FA, true, false, true>) \
+                             : (sym_ ? cd_phase2_rs_kernel<XL, FA, false, true, true> : cd_phase2_rs_kernel<XL, FA, false, false, true>); \
+        else k = full_ ? (sym_ ? cd_phase2_rs_kernel<XL, FA, true, true, false> : cd_phase2_rs_kernel<XL, FA, true, false, false>) \
+                       : (sym_ ? cd_phase2_rs_kernel<XL, FA, false, true, false> : cd_phase2_rs_kernel<XL, FA, false, false, false>); \
         HIPCHK(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds)); \
         tic(c, 2);                                                                                  \
         hipLaunchKernelGGL(k, grid, block512, rs_lds, c->stream, a1, dp.Apack, dp.Apack2, dp.P0, dp.q0, dp.rcp2d); \

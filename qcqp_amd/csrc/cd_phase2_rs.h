@@ -149,7 +149,9 @@ __device__ inline v4d_ rs_compute(v2d_ (&ar)[2 * RS_PFU], const double *__restri
 
 // FULL: n is a multiple of 16 (every block has 16 coordinates: no per-step bounds test in the chain)
 // SYM:  the constraint is p x_i^2 + r == 0 (no linear term): the feasible set is mirrored about 0 at every slack
-template <bool XLDS, int FAST, bool FULL, bool SYM>
+// PROF: in-kernel cycle counters (tools/phase_profile.py); compiled out of the production variant -- the
+//       counters cost 18 VGPRs and their branches cut the block loop into basic blocks
+template <bool XLDS, int FAST, bool FULL, bool SYM, bool PROF>
 __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const double *__restrict__ Apack,
                                                            const double *__restrict__ Apack2,
                                                            const double *__restrict__ P0,
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
         const int st = wave < 4 ? tid - 64 : tid - 128;   // 0..383: staging slot of this thread
         v2d_ arP[2 * RS_PFU];
         long long qc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
-#define QTICK(slot) if (a.prof && wave == 1) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); qc[slot] += now_ - tq; tq = now_; }
+#define QTICK(slot) if (PROF && a.prof && wave == 1) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); qc[slot] += now_ - tq; tq = now_; }
         // staging of the small operands of a block: diagonal block of P0 (256 entries over 192
         // threads) and q/2, 1/P_ii of its 16 coordinates (threads 0..15).  Loads are issued early,
         // the LDS stores come after the matrix work.
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
             store_part(acc, 0);
             stage_store(0);
         }
-        if (a.prof) tq = (long long)__builtin_amdgcn_s_memtime();
+        if (PROF && a.prof) tq = (long long)__builtin_amdgcn_s_memtime();
         // iteration g computes the product for block b(g+1) with hole b(g) from set S_, and
         // prefetches the fragments of iteration g+1 (block b(g+2), hole b(g+1)) into set T_.
 #define RS_MFMA_ITER(S_, T_)                                                          \
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
             RS_MFMA_ITER(arP, arP)
         }
 #undef RS_MFMA_ITER
-        if (a.prof && tid == 64)
+        if (PROF && a.prof && tid == 64)
             for (int k = 0; k < 8; k++) a.prof[tile * 16 + 8 + k] = qc[k];
 #undef QTICK
     } else {
@@ -292,8 +294,8 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
         }
         double afix[4] = {0.0, 0.0, 0.0, 0.0};   // A fragments of the next fix-up
         long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;
-#define PROF_TICK(slot) if (a.prof) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); pc[slot] += now_ - tp; tp = now_; }
-        if (a.prof) tp = (long long)__builtin_amdgcn_s_memtime();
+#define PROF_TICK(slot) if (PROF && a.prof) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); pc[slot] += now_ - tp; tp = now_; }
+        if (PROF && a.prof) tp = (long long)__builtin_amdgcn_s_memtime();
         for (int64_t g = 0;; g++) {
             const int b = (int)(g % NB);
             const int64_t t = g / NB;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                     }
                 } else {
                     // ---- generic loop (rare): the reference's arithmetic, state in LDS (Gsc, X rows)
-                    pc[6]++;
+                    if (PROF) pc[6]++;
                     for (int c = 0; c < cmax; c++) {
                         const int64_t i = 16 * (int64_t)b + c;
                         FeasSet<MAXC> C;
@@ -465,13 +467,13 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
             }
             const unsigned long long live = __builtin_amdgcn_ballot_w64(lane < 16 && !S.conv);
             if (lane == 0) *done = (live == 0ull) ? 1 : 0;
-            pc[5]++;
+            if (PROF) pc[5]++;
         }
         if (lane < 16 && gr < a.R) {
             a.visits[gr] = S.visits; a.accepted[gr] = S.accepted; a.sweeps[gr] = S.sweeps;
             a.status[gr] = S.status;
         }
-        if (a.prof && tid == 0)
+        if (PROF && a.prof && tid == 0)
             for (int k = 0; k < 8; k++) a.prof[tile * 16 + k] = pc[k];
 #undef PROF_TICK
     }
