@@ -33,7 +33,7 @@ def profiled_traffic():
             try:
                 d = json.load(open(os.path.join(REPO, 'profiles', name)))
                 if 'cd_phase2_hbm_bytes_per_launch' in d:
-                    best = (d['cd_phase2_hbm_bytes_per_launch'], name)
+                    best = (d['cd_phase2_hbm_bytes_per_launch'], name, d.get('cd_phase2_mfma_busy_frac'))
             except Exception:
                 pass
     return best
@@ -138,6 +138,10 @@ def main():
                          'frac': achieved / FP64_PEAK_TFLOPS,
                          'traffic': traffic[0] if traffic else None,
                          'traffic_source': ('profiles/' + traffic[1]) if traffic else None,
+                         # matrix-pipe occupancy of the same kernel (PMC SQ_VALU_MFMA_BUSY_CYCLES, all MFMAs issued)
+                         'mfma_busy': traffic[2] if traffic else None,
+                         # what this box sustains on pure fp64 MFMA loops (profiles/r01_fp64_mfma_sustained.md)
+                         'sustained_peak_measured': 47.0,
                          'algorithmic_flops_per_restart_sweep': 2.0 * n * n,
                          'kernel_ms_per_launch': p2_ms / max(args.steps, 1)},
         }

@@ -12,5 +12,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- $
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write --output-format csv -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/l2 -o l2 --output-format csv -- $CMD > $OUT/l2.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/mfma -o mfma --output-format csv -- $CMD > $OUT/mfma.log 2>&1
 grep '^{' $OUT/stats.log | tail -1 > $OUT/bench_under_profiler.json
 ls -R $OUT | head -40

@@ -71,6 +71,22 @@ for k in sorted(set(fetch) | set(write)):
         out['cd_phase2_fetch_kb_raw'] = fe
         out['cd_phase2_write_kb'] = wr
         out['cd_phase2_l2_hit_rate'] = h / (h + m) if h + m else None
+# pass 5: matrix-pipe occupancy.  SQ_VALU_MFMA_BUSY_CYCLES sums, over all 1024 SIMDs, the cycles the MFMA pipe is
+# busy (64 per v_mfma_f64_16x16x4_f64); GRBM_GUI_ACTIVE sums the active cycles of the 8 XCDs.
+mb, ga = pmc('mfma', 'SQ_VALU_MFMA_BUSY_CYCLES'), pmc('mfma', 'GRBM_GUI_ACTIVE')
+if mb:
+    lines.append('')
+    lines.append('| kernel | launches | SQ_VALU_MFMA_BUSY_CYCLES / launch | GRBM_GUI_ACTIVE / launch (8 XCDs) | MFMA pipe busy = BUSY / (1024 SIMDs x GUI_ACTIVE / 8) |')
+    lines.append('|---|---|---|---|---|')
+    for k in sorted(mb):
+        if mb[k][0] <= 0:
+            continue
+        b_ = mb[k][0] / max(mb[k][1], 1)
+        g_ = ga[k][0] / max(ga[k][1], 1)
+        frac = b_ / (1024.0 * g_ / 8.0) if g_ else 0.0
+        lines.append('| %s | %d | %.3e | %.3e | %.3f |' % (k, mb[k][1], b_, g_, frac))
+        if 'cd_phase2' in k:
+            out['cd_phase2_mfma_busy_frac'] = frac
 bj = os.path.join(src, 'bench_under_profiler.json')
 if os.path.exists(bj) and os.path.getsize(bj):
     out['bench_under_profiler'] = json.load(open(bj))
@@ -78,7 +94,8 @@ hdr = ['# rocprofv3 summary %s' % tag, '',
        'Command: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline` (tools/profile_round.sh).',
        'Pass 1 `--kernel-trace --stats`; passes 2-4 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc TCC_HIT_sum TCC_MISS_sum`',
        '(separate runs, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled (gfx950 reports half the bytes of',
-       'wide coalesced reads); WRITE_SIZE is taken as is (uncalibrated).', '']
+       'wide coalesced reads); WRITE_SIZE is taken as is (uncalibrated).  Pass 5 `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`:',
+       'fraction of the SIMD-cycles of the launch during which the matrix pipe is busy (all MFMAs issued, useful or not).', '']
 open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(hdr + lines) + '\n')
 json.dump(out, open(os.path.join(dst, tag + '_summary.json'), 'w'), indent=1, sort_keys=True)
 print('\n'.join(lines))
