@@ -123,6 +123,11 @@ int qcqpmi_cd_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double viol_to
  * (qcqp.py:261-278).  Outputs (R entries each, may be NULL): iterations of phase 1 / phase 2, objective
  * and max violation of the returned points. */
 int qcqpmi_admm_set_eig(qcqpmi_ctx *ctx, const double *lmb, const double *Q);
+/* The same cache computed ON THE DEVICE (f.eigh = LA.eigh(P), utilities.py:160-162, for every constraint at once:
+ * rocSOLVER batched dsyevd on the resident dense matrices) -- for problems whose constraints couple coordinates.
+ * Eigenvectors of degenerate eigenvalues span the same spaces as LAPACK's but are a different basis: iterates
+ * agree with qcqpmi_admm_set_eig to rounding, not bit for bit. */
+int qcqpmi_admm_setup(qcqpmi_ctx *ctx);
 int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, double viol_lim,
                     double rho, const double *Minv, int64_t *iters1, int64_t *iters2, double *f0,
                     double *maxviol);

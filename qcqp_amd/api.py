@@ -244,6 +244,12 @@ class QCQP(object):
             else:
                 rho = 1. / form.m
             rho *= 50.
+        if not getattr(self, '_eig_uploaded', False) and kwargs.get('device_eigh', False):
+            # opt-in: f.eigh for every constraint on the device (rocSOLVER batched dsyevd); needs the dense
+            # constraint matrices resident (coupled constraints).  The first use in a process loads the
+            # 0.9 GB librocsolver.so.
+            self.engine.admm_setup()
+            self._eig_uploaded = True
         if not getattr(self, '_eig_uploaded', False):
             lm = np.zeros((form.m, form.n))
             Q = np.zeros((form.m, form.n, form.n))
