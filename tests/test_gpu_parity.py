@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle and the golden
 vectors captured from the reference.  Run with `-m gpu` on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -273,6 +275,8 @@ def test_admm_population_vs_oracle(eng_mod, orc):
         assert abs(out['f0'][r] - prob.eval(0, xa)) <= 1e-6 * (1 + abs(out['f0'][r]))
 
 
+@pytest.mark.skipif(not os.environ.get('QCQP_TEST_ROCSOLVER'),
+                    reason='loads the 0.9 GB librocsolver.so: 1-5 minutes of page-in on a fresh box; set QCQP_TEST_ROCSOLVER=1')
 def test_admm_device_setup_matches_host_eigh(eng_mod, orc):
     """qcqpmi_admm_setup: the per-constraint eigendecompositions on the device (rocSOLVER, batched) instead of
     host LAPACK.  Rank-2 beamforming constraints have an (n-2)-dimensional null space: any orthonormal basis of it
