@@ -132,6 +132,12 @@ int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, 
                     double rho, const double *Minv, int64_t *iters1, int64_t *iters2, double *f0,
                     double *maxviol);
 
+/* Y = (sum_k w_k P_k) X for the resident population (w: m+1 weights, objective first; Y: R x n like
+ * qcqpmi_pop_download).  Building block of the general SDP-relaxation solver (qcqp_amd/sdr.py: the gradient of
+ * the Burer-Monteiro augmented Lagrangian is 2 S V with S = C + sum_k y_k M_k); one streaming pass over all
+ * matrices + one GEMM.  Needs the packed dense matrices (problems whose constraints couple coordinates). */
+int qcqpmi_pop_weighted_product(qcqpmi_ctx *ctx, const double *w, double *Y);
+
 /* solve_sdr (qcqp.py:72-97) for the UNIT-DIAGONAL family -- constraints x_i^2 = d_i, i.e. Boolean least
  * squares, MAXCUT, partitioning; the host scales d to 1:
  *     minimise <C, X>  s.t.  X_ii = 1, X PSD,   C symmetric N x N (N = n + 1, homogenised, row-major)

@@ -161,9 +161,13 @@ class QCQP(object):
                 # solve_sdr (qcqp.py:72-97): own solver for the unit-diagonal family, on the device
                 from . import sdr as _sdr
                 sol = _sdr.solve_sdr(self.engine, self.qcqp_form, seed=0 if seed is None else seed)
+                if sol is None and not self.engine.separable:
+                    # any QCQP the dense path holds: Burer-Monteiro + augmented Lagrangian, matrices on the device
+                    sol = _sdr.solve_sdr_general(self.engine, self.qcqp_form, seed=0 if seed is None else seed)
                 if sol is None:
-                    raise Exception("SDR suggest: the built-in SDP solver covers problems whose constraints are "
-                                    "x_i^2 == d_i (Boolean least squares, MAXCUT, partitioning); for other "
+                    raise Exception("SDR suggest: the built-in SDP solvers cover problems whose constraints are "
+                                    "x_i^2 == d_i (Boolean least squares, MAXCUT, partitioning) and problems whose "
+                                    "constraints couple coordinates (dense path); for other separable "
                                     "families pass suggest(SDR, X=...) or set qcqp.sdr_sol / qcqp.sdr_bound first.")
                 self.sdr_sol, bound, self.sdr_info = sol
                 self.sdr_bound = -bound if self.maximize_flag else bound    # qcqp.py:392-393

@@ -926,6 +926,49 @@ int qcqpmi_pop_eval(qcqpmi_ctx *c, double *f0, double *maxviol, double *F) {
     return 0;
 }
 
+int qcqpmi_pop_weighted_product(qcqpmi_ctx *c, const double *w, double *Y) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!w || !Y) return fail(c, QCQPMI_EINVAL, "pop_weighted_product: w / Y missing");
+    if (!c->dn_Gpack) return fail(c, QCQPMI_EUNSUPPORTED, "pop_weighted_product needs the packed dense matrices (constraints that couple coordinates)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const DenseProblem D = dense_problem(c);
+    const int64_t n16 = c->n16, ntiles = c->Rpad / 16;
+    double *dw = nullptr, *dS = nullptr, *dY = nullptr, *dz = nullptr;
+    if ((rc = dev_alloc(c, &dw, (size_t)D.m1, false))) return rc;
+    if (!rc) rc = dev_alloc(c, &dS, (size_t)n16 * n16, false);
+    if (!rc) rc = dev_alloc(c, &dY, (size_t)c->Rpad * n16, false);
+    if (!rc) rc = dev_alloc(c, &dz, (size_t)n16);   // zero offset vector of the affine map
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(dw, w, (size_t)D.m1 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(dense_wsum_pack_kernel, dim3((unsigned)((n16 * n16 + 255) / 256)), dim3(256), 0, c->stream, D, (const double *)dw, dS);
+            DenseProdArgs pa;
+            pa.D = D; pa.D.Gpack = dS; pa.D.q = dz; pa.D.m1 = 1; pa.D.m1p = 64;
+            pa.X = c->X; pa.ntiles = (int)ntiles; pa.b = 0; pa.zs = 1; pa.G = dY; pa.F = nullptr; pa.Rpad = c->Rpad;
+            pa.tile_on = nullptr; pa.hole = -1; pa.ch_only = -1; pa.zplane = 0;
+            auto kg = dense_products_kernel<3>;
+            e = hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(kg, dim3((unsigned)((D.NB + DP_FG - 1) / DP_FG), (unsigned)((ntiles + DP_TG - 1) / DP_TG), 1),
+                                   dim3(256), DP_LDS_BYTES, c->stream, pa);
+                const int64_t total = c->R * c->n;
+                hipLaunchKernelGGL(from_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                                   (const double *)dY, c->d_stage, c->n, c->n16, c->R);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(Y, c->d_stage, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    void *ptrs[] = {dw, dS, dY, dz};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "pop_weighted_product: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int qcqpmi_eval_batch(qcqpmi_ctx *c, const double *X, int64_t S, double *f0, double *maxviol, double *F) {
     int rc = qcqpmi_pop_upload(c, X, S);
     if (rc) return rc;

@@ -346,6 +346,26 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
     }
 }
 
+// S = sum_k w_k P_k in the fragment layout of ONE matrix ([b][kk][lane], the objective's Apack layout): one
+// streaming pass over all matrices (HBM-bound: (m+1) n16^2 8 bytes), used by the general SDP solver, whose
+// gradient is 2 S V
+__global__ __launch_bounds__(256) void dense_wsum_pack_kernel(DenseProblem D, const double *__restrict__ w,
+                                                              double *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (b * KS + kk) * 64 + lane
+    if (idx >= D.n16 * D.n16) return;
+    const int64_t per_b = (int64_t)D.KS * 64;
+    const int64_t b = idx / per_b, rem = idx % per_b;
+    const double *src = D.Gpack + (b * D.m1) * per_b + rem;
+    double s0 = 0.0, s1 = 0.0;
+    int k = 0;
+    for (; k + 1 < D.m1; k += 2) {
+        s0 = __builtin_fma(w[k], src[(int64_t)k * per_b], s0);
+        s1 = __builtin_fma(w[k + 1], src[(int64_t)(k + 1) * per_b], s1);
+    }
+    if (k < D.m1) s0 = __builtin_fma(w[k], src[(int64_t)k * per_b], s0);
+    out[idx] = s0 + s1;
+}
+
 // linear terms  lin[k][gr] = q_k' x_gr  (2 m1 n flops per candidate: noise next to the quadratic forms)
 __global__ __launch_bounds__(256) void dense_linear_kernel(DenseProblem D, const double *__restrict__ X, int64_t Rpad,
                                                            double *__restrict__ lin) {

@@ -168,6 +168,14 @@ class Engine(object):
                                          _ip(out['iters2']), _dp(out['f0']), _dp(out['maxviol'])))
         return out
 
+    def weighted_product(self, w):
+        """(sum_k w_k P_k) X for the resident population; w has m + 1 entries (objective first).  Returns (n, R)."""
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        assert w.size == self.m + 1
+        out = np.empty((self.pop_size, self.n))
+        self._chk(self.L.qcqpmi_pop_weighted_product(self.h, _dp(w), _dp(out)))
+        return np.ascontiguousarray(out.T)
+
     # ------------------------------------------------------------ SDP relaxation
     def sdr_solve_unitdiag(self, Cm, V0=None, max_sweeps=2000, tol=1e-10, seed=0):
         """min <C, X> s.t. diag(X) = 1, X PSD (mixing method on the device).  Returns V (N x 64, unit

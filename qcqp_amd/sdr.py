@@ -89,3 +89,118 @@ def solve_sdr(engine, form, max_sweeps=5000, tol=1e-11, seed=0):
     # is fixed by the optimisation itself)
     bound = float(hist[-1])
     return X, bound, dict(V=V, C=C, hist=hist, sweeps=sweeps, scale=sc)
+
+
+# ------------------------------------------------------------------------- general QCQPs
+def _functions(form):
+    fs = [form.f0] + list(form.fs)
+    Q = np.array([np.asarray(f.qarray, dtype=np.float64).ravel() for f in fs])      # (m+1, n)
+    r = np.array([f.r for f in fs])
+    eq = np.array([f.relop == '==' for f in fs])
+    return Q, r, eq
+
+
+def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400, feas_tol=1e-6, seed=0, verbose=False):
+    """SDP relaxation of ANY QCQP the dense path holds (constraints that couple coordinates), in the
+    Burer-Monteiro form X = V V' (V: (n+1) x r, r(r+1)/2 > m+1) with an augmented Lagrangian on the
+    constraints  <M_k, X> (<=, ==) 0,  X_nn = 1   (solve_sdr, qcqp.py:72-97).  The heavy linear algebra runs
+    on the device through the engine: the constraint values are quadratic forms of the r columns of V
+    (two batched evaluations, +V and -V, separate the quadratic and the linear parts of the homogeneous
+    forms) and the gradient is 2 S V with S = sum_k w_k M_k (qcqpmi_pop_weighted_product: one pass over all
+    matrices + one GEMM).  The host runs L-BFGS on the (n+1) r entries of V and the multiplier updates.
+    Returns (X, bound, info); info['y'] are the multipliers (info['dual_value'] = -y_N is a lower bound of the
+    SDP value whenever C + sum y_k M_k + y_N E_NN is PSD -- dual_certificate_general checks that on the host)."""
+    from scipy.optimize import minimize
+    n, m = form.n, form.m
+    Q, rr, eq = _functions(form)
+    if rank is None:
+        rank = int(np.ceil(np.sqrt(2.0 * (m + 2)))) + 1
+    rank = int(min(max(rank, 2), 64))
+    # row scaling of the constraints (the multipliers are un-scaled at the end)
+    sc = np.ones(m + 1)
+    sc[1:] = 1.0 / (1.0 + np.abs(rr[1:]) + np.linalg.norm(Q[1:], axis=1) / np.sqrt(n))
+    ineq = ~eq
+    ineq[0] = False
+    eqc = eq.copy()
+    eqc[0] = False
+    rs = np.random.RandomState(seed)
+    V = 0.1 * rs.randn(n + 1, rank)
+    V[n, :] = 0.0
+    V[n, 0] = 1.0
+    y = np.zeros(m + 1)      # y[0] unused
+    yN = 0.0
+    sigma = float(sigma0)
+    evals = [0]
+
+    def values(Vm):
+        Vx, t = Vm[:n, :], Vm[n, :]
+        Fp = engine.eval_batch(Vx, want_F=True)[2]
+        Fm = engine.eval_batch(-Vx, want_F=True)[2]
+        evals[0] += 1
+        quad = 0.5 * (Fp + Fm) - rr[:, None]
+        lin = 0.5 * (Fp - Fm)
+        h = quad.sum(axis=1) + lin.dot(t) + rr * t.dot(t)
+        return h
+
+    def fun_grad(v):
+        Vm = v.reshape(n + 1, rank)
+        Vx, t = Vm[:n, :], Vm[n, :]
+        h = values(Vm) * sc
+        tt = t.dot(t) - 1.0
+        w = np.zeros(m + 1)
+        w[0] = 1.0
+        w[eqc] = y[eqc] + sigma * h[eqc]
+        w[ineq] = np.maximum(0.0, y[ineq] + sigma * h[ineq])
+        wN = yN + sigma * tt
+        L = h[0] + np.sum(y[eqc] * h[eqc] + 0.5 * sigma * h[eqc] ** 2) \
+            + np.sum((w[ineq] ** 2 - y[ineq] ** 2) / (2.0 * sigma)) + yN * tt + 0.5 * sigma * tt * tt
+        ws = w * sc
+        engine.upload(Vx)
+        SVx = engine.weighted_product(ws)                       # (sum_k ws_k P_k) Vx
+        qh = 0.5 * ws.dot(Q)                                    # sum_k ws_k q_k / 2
+        G = np.empty_like(Vm)
+        G[:n, :] = 2.0 * (SVx + np.outer(qh, t))
+        G[n, :] = 2.0 * (qh.dot(Vx) + (ws.dot(rr) + wN) * t)
+        return L, G.ravel()
+
+    hist = []
+    for it in range(outer):
+        res = minimize(fun_grad, V.ravel(), jac=True, method='L-BFGS-B', options=dict(maxiter=inner, maxfun=2 * inner, gtol=1e-9, ftol=1e-15))
+        V = res.x.reshape(n + 1, rank)
+        h = values(V) * sc
+        tt = V[n, :].dot(V[n, :]) - 1.0
+        infeas = max(np.max(np.abs(h[eqc])) if eqc.any() else 0.0, np.max(np.maximum(h[ineq], 0.0)) if ineq.any() else 0.0, abs(tt))
+        y[eqc] = y[eqc] + sigma * h[eqc]
+        y[ineq] = np.maximum(0.0, y[ineq] + sigma * h[ineq])
+        yN = yN + sigma * tt
+        hist.append((float(h[0]), float(infeas), sigma, int(res.nit)))
+        if verbose:
+            print('outer %2d: <C,X> %.8g infeas %.2e sigma %.1e inner its %d' % (it, h[0], infeas, sigma, res.nit))
+        if infeas < feas_tol and it > 0 and abs(hist[-1][0] - hist[-2][0]) <= 1e-7 * (1.0 + abs(h[0])):
+            break
+        if it > 0 and infeas > 0.25 * hist[-2][1]:
+            sigma = min(sigma * 5.0, 1e8)
+    X = V.dot(V.T)
+    X = X / X[n, n]
+    bound = float(values(V)[0] / V[n, :].dot(V[n, :]))
+    return X, bound, dict(V=V, y=y * sc, yN=yN, hist=hist, evals=evals[0], rank=rank, dual_value=-yN)
+
+
+def dual_certificate_general(form, y, yN):
+    """lambda_min of S = C + sum_k y_k M_k + y_N E_NN (homogeneous forms, utilities.py:66-67) on the host;
+    with S PSD and y_k >= 0 on the inequalities, -y_N is a lower bound of the SDP (hence of the QCQP)."""
+    n = form.n
+    fs = [form.f0] + list(form.fs)
+    S = np.zeros((n + 1, n + 1))
+    w = np.append(1.0, y[1:])
+    for wk, f in zip(w, fs):
+        if wk == 0.0:
+            continue
+        P = _dense(f.P)
+        q = np.asarray(f.qarray, dtype=np.float64).ravel()
+        S[:n, :n] += wk * 0.5 * (P + P.T)
+        S[:n, n] += 0.5 * wk * q
+        S[n, :n] += 0.5 * wk * q
+        S[n, n] += wk * f.r
+    S[n, n] += yN
+    return float(np.linalg.eigvalsh(S)[0]), S
