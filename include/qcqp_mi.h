@@ -137,6 +137,10 @@ int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, 
  * the Burer-Monteiro augmented Lagrangian is 2 S V with S = C + sum_k y_k M_k); one streaming pass over all
  * matrices + one GEMM.  Needs the packed dense matrices (problems whose constraints couple coordinates). */
 int qcqpmi_pop_weighted_product(qcqpmi_ctx *ctx, const double *w, double *Y);
+/* Quadratic and linear parts of every function for the resident population, kept apart:
+ * quad[k][r] = x_r' P_k x_r + r_k,  lin[k][r] = q_k' x_r   ((m+1) x R each, row-major).  Same kernels as the
+ * evaluation of QuadraticFunction.eval (utilities.py:49-50); the SDP solver needs the parts of the homogeneous forms. */
+int qcqpmi_pop_eval_parts(qcqpmi_ctx *ctx, double *quad, double *lin);
 
 /* solve_sdr (qcqp.py:72-97) for the UNIT-DIAGONAL family -- constraints x_i^2 = d_i, i.e. Boolean least
  * squares, MAXCUT, partitioning; the host scales d to 1:

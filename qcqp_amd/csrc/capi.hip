@@ -116,6 +116,9 @@ struct qcqpmi_ctx {
     // outputs of a run packed into one device buffer, copied with ONE transfer into pinned host memory
     char *d_out = nullptr, *h_out = nullptr;
     int64_t out_cap = 0;
+    int eval_zs = 1;   // planes of the last dense evaluation
+    double *d_wS = nullptr, *d_wY = nullptr, *d_ww = nullptr, *d_wz = nullptr;   // qcqpmi_pop_weighted_product work buffers
+    int64_t wY_cap = 0;
     double *d_planes = nullptr;   // partial planes of x'P0x from the GEMM evaluation
     int64_t planes_cap = 0;
     double *d_gP = nullptr;   // dense constraint matrices [m][n][n] (problems whose constraints couple coordinates)
@@ -226,6 +229,7 @@ void toc(qcqpmi_ctx *c, int which) {
 
 bool dense_on(const qcqpmi_ctx *c);
 int launch_eval_dense(qcqpmi_ctx *c, bool with_Ft);
+int eval_parts_dense(qcqpmi_ctx *c);
 
 // per-restart results of a coordinate-descent run -> host: one pack kernel, one copy into pinned memory,
 // one synchronisation (nine pageable copies cost ~0.3 ms of staging kernels per call)
@@ -518,7 +522,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes, c->d_out};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz};
     if (c->h_out) (void)hipHostFree(c->h_out);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
@@ -934,11 +938,19 @@ int qcqpmi_pop_weighted_product(qcqpmi_ctx *c, const double *w, double *Y) {
     HIPCHK(c, hipSetDevice(c->device));
     const DenseProblem D = dense_problem(c);
     const int64_t n16 = c->n16, ntiles = c->Rpad / 16;
-    double *dw = nullptr, *dS = nullptr, *dY = nullptr, *dz = nullptr;
-    if ((rc = dev_alloc(c, &dw, (size_t)D.m1, false))) return rc;
-    if (!rc) rc = dev_alloc(c, &dS, (size_t)n16 * n16, false);
-    if (!rc) rc = dev_alloc(c, &dY, (size_t)c->Rpad * n16, false);
-    if (!rc) rc = dev_alloc(c, &dz, (size_t)n16);   // zero offset vector of the affine map
+    if (!c->d_wS) {
+        if ((rc = dev_alloc(c, &c->d_ww, (size_t)D.m1, false))) return rc;
+        if ((rc = dev_alloc(c, &c->d_wS, (size_t)n16 * n16, false))) return rc;
+        if ((rc = dev_alloc(c, &c->d_wz, (size_t)n16))) return rc;   // zero offset vector of the affine map
+    }
+    if (c->Rpad * n16 > c->wY_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_wY) (void)hipFree(c->d_wY);
+        c->d_wY = nullptr;
+        if ((rc = dev_alloc(c, &c->d_wY, (size_t)c->Rpad * n16, false))) return rc;
+        c->wY_cap = c->Rpad * n16;
+    }
+    double *dw = c->d_ww, *dS = c->d_wS, *dY = c->d_wY, *dz = c->d_wz;
     hipError_t e = hipSuccess;
     if (!rc) {
         e = hipMemcpyAsync(dw, w, (size_t)D.m1 * sizeof(double), hipMemcpyHostToDevice, c->stream);
@@ -962,10 +974,26 @@ int qcqpmi_pop_weighted_product(qcqpmi_ctx *c, const double *w, double *Y) {
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
-    void *ptrs[] = {dw, dS, dY, dz};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
     if (rc) return rc;
     if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "pop_weighted_product: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int qcqpmi_pop_eval_parts(qcqpmi_ctx *c, double *quad, double *lin) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!quad || !lin) return fail(c, QCQPMI_EINVAL, "pop_eval_parts: outputs missing");
+    if (!c->dn_Gpack) return fail(c, QCQPMI_EUNSUPPORTED, "pop_eval_parts needs the packed dense matrices (constraints that couple coordinates)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = eval_parts_dense(c))) return rc;
+    const int64_t m1 = c->m + 1;
+    const double *dlin = c->d_F + (int64_t)c->eval_zs * m1 * c->Rpad;
+    HIPCHK(c, hipMemcpy2DAsync(quad, (size_t)c->R * sizeof(double), c->d_F, (size_t)c->Rpad * sizeof(double),
+                               (size_t)c->R * sizeof(double), (size_t)m1, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(lin, (size_t)c->R * sizeof(double), dlin, (size_t)c->Rpad * sizeof(double),
+                               (size_t)c->R * sizeof(double), (size_t)m1, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->evaluated = false;    // plane 0 no longer holds the full function values
     return 0;
 }
 

@@ -383,6 +383,15 @@ __global__ __launch_bounds__(256) void dense_linear_kernel(DenseProblem D, const
     lin[(int64_t)k * Rpad + tile * 16 + r] = (s0 + s1) + (s2 + s3);
 }
 
+// partial planes of the quadratic forms -> plane 0 (fixed order), without the linear terms
+__global__ void dense_sum_planes_kernel(double *__restrict__ F, int zs, int m1, int64_t Rpad) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)m1 * Rpad) return;
+    double f = F[idx];
+    for (int z = 1; z < zs; z++) f += F[(int64_t)z * m1 * Rpad + idx];
+    F[idx] = f;
+}
+
 // f0 and the maximum violation of every candidate from the table of function values; also the
 // restart-major copy Ft[gr][k] the chain kernel tracks
 __global__ void dense_viol_kernel(double *__restrict__ F, int zs, const double *__restrict__ lin, const int *__restrict__ relop, int m1, int m1p,

@@ -168,6 +168,14 @@ class Engine(object):
                                          _ip(out['iters2']), _dp(out['f0']), _dp(out['maxviol'])))
         return out
 
+    def eval_parts(self):
+        """(quad, lin): quad[k, r] = x_r' P_k x_r + r_k and lin[k, r] = q_k' x_r for the resident population."""
+        R = self.pop_size
+        quad = np.empty((self.m + 1, R))
+        lin = np.empty((self.m + 1, R))
+        self._chk(self.L.qcqpmi_pop_eval_parts(self.h, _dp(quad), _dp(lin)))
+        return quad, lin
+
     def weighted_product(self, w):
         """(sum_k w_k P_k) X for the resident population; w has m + 1 entries (objective first).  Returns (n, R)."""
         w = np.ascontiguousarray(w, dtype=np.float64)

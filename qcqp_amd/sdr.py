@@ -105,8 +105,7 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
     Burer-Monteiro form X = V V' (V: (n+1) x r, r(r+1)/2 > m+1) with an augmented Lagrangian on the
     constraints  <M_k, X> (<=, ==) 0,  X_nn = 1   (solve_sdr, qcqp.py:72-97).  The heavy linear algebra runs
     on the device through the engine: the constraint values are quadratic forms of the r columns of V
-    (two batched evaluations, +V and -V, separate the quadratic and the linear parts of the homogeneous
-    forms) and the gradient is 2 S V with S = sum_k w_k M_k (qcqpmi_pop_weighted_product: one pass over all
+    (one batched evaluation with the quadratic and the linear parts of the homogeneous forms kept apart) and the gradient is 2 S V with S = sum_k w_k M_k (qcqpmi_pop_weighted_product: one pass over all
     matrices + one GEMM).  The host runs L-BFGS on the (n+1) r entries of V and the multiplier updates.
     Returns (X, bound, info); info['y'] are the multipliers (info['dual_value'] = -y_N is a lower bound of the
     SDP value whenever C + sum y_k M_k + y_N E_NN is PSD -- dual_certificate_general checks that on the host)."""
@@ -134,12 +133,10 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
 
     def values(Vm):
         Vx, t = Vm[:n, :], Vm[n, :]
-        Fp = engine.eval_batch(Vx, want_F=True)[2]
-        Fm = engine.eval_batch(-Vx, want_F=True)[2]
+        engine.upload(Vx)
+        quad, lin = engine.eval_parts()          # x'P_k x + r_k and q_k'x per column, one pass on the device
         evals[0] += 1
-        quad = 0.5 * (Fp + Fm) - rr[:, None]
-        lin = 0.5 * (Fp - Fm)
-        h = quad.sum(axis=1) + lin.dot(t) + rr * t.dot(t)
+        h = (quad - rr[:, None]).sum(axis=1) + lin.dot(t) + rr * t.dot(t)
         return h
 
     def fun_grad(v):
@@ -155,8 +152,7 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
         L = h[0] + np.sum(y[eqc] * h[eqc] + 0.5 * sigma * h[eqc] ** 2) \
             + np.sum((w[ineq] ** 2 - y[ineq] ** 2) / (2.0 * sigma)) + yN * tt + 0.5 * sigma * tt * tt
         ws = w * sc
-        engine.upload(Vx)
-        SVx = engine.weighted_product(ws)                       # (sum_k ws_k P_k) Vx
+        SVx = engine.weighted_product(ws)                       # population = Vx (uploaded by values())                       # (sum_k ws_k P_k) Vx
         qh = 0.5 * ws.dot(Q)                                    # sum_k ws_k q_k / 2
         G = np.empty_like(Vm)
         G[:n, :] = 2.0 * (SVx + np.outer(qh, t))
