@@ -148,8 +148,10 @@ class QCQP(object):
                 self.engine.randn(R, seed=0 if seed is None else seed)
         elif method == s.SPECTRAL:
             if self.spectral_sol is None:
-                raise Exception("SPECTRAL suggest needs the spectral relaxation solution: no SDP solver "
-                                "is available; set qcqp.spectral_sol / qcqp.spectral_bound first.")
+                # solve_spectral (qcqp.py:41-70): aggregated constraints, solved by the engine's own SDP solver
+                from . import sdr as _sdr
+                self.spectral_sol, bound, self.spectral_info = _sdr.solve_spectral(self.qcqp_form, seed=0 if seed is None else seed)
+                self.spectral_bound = -bound if self.maximize_flag else bound      # qcqp.py:386-387
             self.engine.upload(np.asarray(self.spectral_sol, dtype=np.float64).ravel())
         elif method == s.SDR:
             if 'X' in kwargs:

@@ -200,3 +200,41 @@ def dual_certificate_general(form, y, yN):
         S[n, n] += wk * f.r
     S[n, n] += yN
     return float(np.linalg.eigvalsh(S)[0]), S
+
+
+# ------------------------------------------------------------------------- spectral relaxation
+def solve_spectral(form, device=0, seed=0):
+    """solve_spectral (qcqp.py:41-70): the relaxation with ALL inequality constraints summed into one and all
+    equality constraints summed into one,
+        minimise <W0, X>  s.t.  <W1, X> <= 0,  <W2, X> == 0,  X_nn = 1,  X PSD,
+    solved by the general solver above on an auxiliary three-function problem; returns
+    (sqrt(lambda_max) * v[:-1], value) exactly like the reference builds its point from the top eigenpair of X."""
+    from .engine import Engine
+    from .form import QCQPForm
+    n = form.n
+    P0 = _dense(form.f0.P)
+    funcs = [(0.5 * (P0 + P0.T), np.asarray(form.f0.qarray, dtype=np.float64).ravel(), form.f0.r, None)]
+    for relop in ('<=', '=='):
+        P = np.zeros((n, n)); q = np.zeros(n); r = 0.0
+        any_ = False
+        for f in form.fs:
+            if f.relop != relop:
+                continue
+            any_ = True
+            Pk = _dense(f.P)
+            P += 0.5 * (Pk + Pk.T); q += np.asarray(f.qarray, dtype=np.float64).ravel(); r += f.r
+        if any_:
+            funcs.append((P, q, r, relop))
+    aux = QCQPForm.from_arrays(funcs)
+    e = Engine(aux, device=device)
+    try:
+        if e.separable:
+            raise Exception("spectral relaxation: the aggregated constraints touch a single coordinate "
+                            "(one-variable problem); nothing to relax")
+        e.L.qcqpmi_debug_profile(e.h, 32 << 4, None)      # the dense path also for n <= 64
+        X, value, info = solve_sdr_general(e, aux, seed=seed)
+    finally:
+        e.close()
+    w, v = np.linalg.eigh(X)
+    x = np.sqrt(max(w[-1], 0.0)) * v[:-1, -1]
+    return x, value, dict(X=X, sdr=info, aux=aux)

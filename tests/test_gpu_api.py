@@ -233,3 +233,31 @@ def test_sdr_general_solver_certified_and_consistent_with_mixing():
     assert abs(b2 - b0) <= 1e-5 * (1 + abs(b0)), (b2, b0)
     assert abs(info2['y'][-1]) < 1e-6                    # the inactive constraint has a zero multiplier
     assert np.max(np.abs(np.diag(X2)[:n] - 1.0)) < 1e-5
+
+
+def test_suggest_spectral_relaxation():
+    """suggest(SPECTRAL) (qcqp.py:41-70, 383-388): for the Boolean family the relaxation is the sphere-constrained
+    problem  min x'P0x + q0'x + r0  s.t.  ||x||^2 = n  (all equalities summed) -- a trust-region subproblem with a
+    rank-one SDP solution: the returned point satisfies its KKT conditions  (P0 + mu I) x = -q0/2,  P0 + mu I PSD,
+    and the value is a lower bound of the SDR bound and of the optimum."""
+    from qcqp_amd import QCQP, SPECTRAL, SDR, problems
+    from qcqp_amd.api import Problem
+    funcs, _, _ = problems.boolean_least_squares(10, 15, seed=1)
+    P0, q0, r0 = np.asarray(funcs[0][0]), np.asarray(funcs[0][1]), funcs[0][2]
+    n = 10
+    q = QCQP(Problem.from_minimize_form(funcs))
+    f, v = q.suggest(SPECTRAL)
+    x = np.asarray(q.spectral_sol)
+    fx = x.dot(P0.dot(x)) + q0.dot(x) + r0
+    assert abs(abs(x.dot(x)) - n) < 1e-4 * n                       # on the sphere (sign of the eigenvector is free)
+    Xs = q.spectral_info['X']
+    assert np.linalg.eigvalsh(Xs)[-2] < 1e-4 * np.linalg.eigvalsh(Xs)[-1]   # rank one
+    xs = Xs[:n, n]                                                   # the relaxation's point with the right sign
+    g = 2.0 * P0.dot(xs) + q0
+    mu = -g.dot(xs) / (2.0 * xs.dot(xs))
+    assert np.linalg.norm(g + 2.0 * mu * xs) <= 1e-3 * (1 + np.linalg.norm(g))
+    assert np.linalg.eigvalsh(P0 + mu * np.eye(n))[0] > -1e-4
+    assert abs(q.spectral_bound - (xs.dot(P0.dot(xs)) + q0.dot(xs) + r0)) <= 1e-4 * (1 + abs(q.spectral_bound))
+    q.suggest(SDR)
+    assert q.spectral_bound <= q.sdr_bound + 1e-5 <= 35.55097 + 1e-3   # spectral <= SDR <= optimum
+    assert f == pytest.approx(fx, rel=1e-9) or f == pytest.approx(x.dot(P0.dot(x)) + q0.dot(x) + r0, rel=1e-9)
