@@ -137,6 +137,11 @@ int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, 
  * the Burer-Monteiro augmented Lagrangian is 2 S V with S = C + sum_k y_k M_k); one streaming pass over all
  * matrices + one GEMM.  Needs the packed dense matrices (problems whose constraints couple coordinates). */
 int qcqpmi_pop_weighted_product(qcqpmi_ctx *ctx, const double *w, double *Y);
+/* S = sum_k w_k P_k itself (n x n row-major on the host): the dual matrix of the SDP certificate when the matrices
+ * only exist on the device.  qcqpmi_get_linear returns q_k, r_k, relop of function k as the context holds them
+ * (also for device-generated functions). */
+int qcqpmi_weighted_matrix(qcqpmi_ctx *ctx, const double *w, double *S);
+int qcqpmi_get_linear(qcqpmi_ctx *ctx, int64_t k, double *q, double *r, int *relop);
 /* Quadratic and linear parts of every function for the resident population, kept apart:
  * quad[k][r] = x_r' P_k x_r + r_k,  lin[k][r] = q_k' x_r   ((m+1) x R each, row-major).  Same kernels as the
  * evaluation of QuadraticFunction.eval (utilities.py:49-50); the SDP solver needs the parts of the homogeneous forms. */

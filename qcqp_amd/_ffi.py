@@ -24,6 +24,8 @@ PROTOTYPES = [
     ('qcqpmi_set_quad', C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_dp, c_ip, c_ip, C.c_int64, c_dp,
                                   C.c_double, C.c_int]),
     ('qcqpmi_set_quad_generated', C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
+    ('qcqpmi_weighted_matrix', C.c_int, [C.c_void_p, c_dp, c_dp]),
+    ('qcqpmi_get_linear', C.c_int, [C.c_void_p, C.c_int64, c_dp, c_dp, C.POINTER(C.c_int)]),
     ('qcqpmi_pop_eval_parts', C.c_int, [C.c_void_p, c_dp, c_dp]),
     ('qcqpmi_pop_weighted_product', C.c_int, [C.c_void_p, c_dp, c_dp]),
     ('qcqpmi_sdr_solve_unitdiag', C.c_int, [C.c_void_p, c_dp, C.c_int64, c_dp, C.c_int, C.c_double, c_dp, C.POINTER(C.c_int)]),

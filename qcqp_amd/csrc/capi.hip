@@ -979,6 +979,46 @@ int qcqpmi_pop_weighted_product(qcqpmi_ctx *c, const double *w, double *Y) {
     return 0;
 }
 
+int qcqpmi_get_linear(qcqpmi_ctx *c, int64_t k, double *q, double *r, int *relop) {
+    if (!c) return QCQPMI_EINVAL;
+    if (k < 0 || k > c->m || !c->quads[(size_t)k].set) return fail(c, QCQPMI_EINVAL, "get_linear: bad k");
+    const HostQuad &h = c->quads[(size_t)k];
+    if (q) memcpy(q, h.q.data(), (size_t)c->n * sizeof(double));
+    if (r) *r = h.r;
+    if (relop) *relop = h.relop;
+    return 0;
+}
+
+int qcqpmi_weighted_matrix(qcqpmi_ctx *c, const double *w, double *S) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!w || !S) return fail(c, QCQPMI_EINVAL, "weighted_matrix: w / S missing");
+    if (!c->dn_Gpack) return fail(c, QCQPMI_EUNSUPPORTED, "weighted_matrix needs the packed dense matrices");
+    HIPCHK(c, hipSetDevice(c->device));
+    const DenseProblem D = dense_problem(c);
+    const int64_t n = c->n, n16 = c->n16;
+    double *dw = nullptr, *dS = nullptr, *dU = nullptr;
+    rc = dev_alloc(c, &dw, (size_t)D.m1, false);
+    if (!rc) rc = dev_alloc(c, &dS, (size_t)n16 * n16, false);
+    if (!rc) rc = dev_alloc(c, &dU, (size_t)n * n, false);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(dw, w, (size_t)D.m1 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(dense_wsum_pack_kernel, dim3((unsigned)((n16 * n16 + 255) / 256)), dim3(256), 0, c->stream, D, (const double *)dw, dS);
+            hipLaunchKernelGGL(dense_unpack_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, c->stream, (const double *)dS, dU, n, (int)(n16 / 4));
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(S, dU, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    void *ptrs[] = {dw, dS, dU};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "weighted_matrix: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int qcqpmi_pop_eval_parts(qcqpmi_ctx *c, double *quad, double *lin) {
     int rc = check_ready(c, true);
     if (rc) return rc;

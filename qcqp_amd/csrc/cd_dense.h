@@ -366,6 +366,16 @@ __global__ __launch_bounds__(256) void dense_wsum_pack_kernel(DenseProblem D, co
     out[idx] = s0 + s1;
 }
 
+// one matrix in fragment layout [b][kk][lane] -> row-major n x n
+__global__ void dense_unpack_kernel(const double *__restrict__ Spack, double *__restrict__ out, int64_t n, int KS) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t row = idx / n, col = idx % n;
+    const int64_t b = row >> 4, kk = col >> 2;
+    const int l = (int)(((col & 3) << 4) | (row & 15));
+    out[idx] = Spack[(b * KS + kk) * 64 + l];
+}
+
 // linear terms  lin[k][gr] = q_k' x_gr  (2 m1 n flops per candidate: noise next to the quadratic forms)
 __global__ __launch_bounds__(256) void dense_linear_kernel(DenseProblem D, const double *__restrict__ X, int64_t Rpad,
                                                            double *__restrict__ lin) {

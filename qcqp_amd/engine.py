@@ -168,6 +168,23 @@ class Engine(object):
                                          _ip(out['iters2']), _dp(out['f0']), _dp(out['maxviol'])))
         return out
 
+    def weighted_matrix(self, w):
+        """sum_k w_k P_k (n x n) assembled on the device and downloaded."""
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        S = np.empty((self.n, self.n))
+        self._chk(self.L.qcqpmi_weighted_matrix(self.h, _dp(w), _dp(S)))
+        return S
+
+    def linear_terms(self):
+        """(Q (m+1, n), r (m+1,), relops) as the context holds them (also for device-generated functions)."""
+        Q = np.empty((self.m + 1, self.n)); r = np.empty(self.m + 1); rel = []
+        rr = C.c_double(0.0); ro = C.c_int(0)
+        for k in range(self.m + 1):
+            row = np.empty(self.n)
+            self._chk(self.L.qcqpmi_get_linear(self.h, k, _dp(row), C.byref(rr), C.byref(ro)))
+            Q[k] = row; r[k] = rr.value; rel.append({0: None, 1: '<=', 2: '=='}[ro.value])
+        return Q, r, rel
+
     def eval_parts(self):
         """(quad, lin): quad[k, r] = x_r' P_k x_r + r_k and lin[k, r] = q_k' x_r for the resident population."""
         R = self.pop_size

@@ -92,7 +92,10 @@ def solve_sdr(engine, form, max_sweeps=5000, tol=1e-11, seed=0):
 
 
 # ------------------------------------------------------------------------- general QCQPs
-def _functions(form):
+def _functions(form, engine=None):
+    if not hasattr(form, 'f0'):           # GeneratedForm: the functions only exist inside the context
+        Q, r, rel = engine.linear_terms()
+        return Q, r, np.array([x == '==' for x in rel])
     fs = [form.f0] + list(form.fs)
     Q = np.array([np.asarray(f.qarray, dtype=np.float64).ravel() for f in fs])      # (m+1, n)
     r = np.array([f.r for f in fs])
@@ -111,7 +114,7 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
     SDP value whenever C + sum y_k M_k + y_N E_NN is PSD -- dual_certificate_general checks that on the host)."""
     from scipy.optimize import minimize
     n, m = form.n, form.m
-    Q, rr, eq = _functions(form)
+    Q, rr, eq = _functions(form, engine)
     if rank is None:
         rank = int(np.ceil(np.sqrt(2.0 * (m + 2)))) + 1
     rank = int(min(max(rank, 2), 64))
@@ -180,6 +183,20 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
     X = X / X[n, n]
     bound = float(values(V)[0] / V[n, :].dot(V[n, :]))
     return X, bound, dict(V=V, y=y * sc, yN=yN, hist=hist, evals=evals[0], rank=rank, dual_value=-yN)
+
+
+def dual_certificate_device(engine, y, yN):
+    """The same check when the matrices only exist on the device: S_P = sum w_k P_k comes from the engine."""
+    Q, rr, _rel = engine.linear_terms()
+    n = engine.n
+    w = np.append(1.0, y[1:])
+    S = np.zeros((n + 1, n + 1))
+    SP = engine.weighted_matrix(w)
+    S[:n, :n] = 0.5 * (SP + SP.T)
+    qh = 0.5 * w.dot(Q)
+    S[:n, n] = qh; S[n, :n] = qh
+    S[n, n] = w.dot(rr) + yN
+    return float(np.linalg.eigvalsh(S)[0]), S
 
 
 def dual_certificate_general(form, y, yN):
