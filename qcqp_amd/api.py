@@ -91,7 +91,14 @@ def flatten_vars(xs, n):
 
 class QCQP(object):
     def __init__(self, prob, device=0):
-        if isinstance(prob, QCQPForm):
+        if hasattr(prob, 'specs') and not hasattr(prob, 'qcqp_form'):
+            # problems.GeneratedForm: the functions are synthesised on the device and exist nowhere else
+            form = prob
+            prob = Problem.__new__(Problem)
+            prob.qcqp_form = form
+            prob.objective = _Objective('minimize')
+            prob._vars = [Variable(form.n, 1)]
+        elif isinstance(prob, QCQPForm):
             form = prob
             prob = Problem.__new__(Problem)
             prob.qcqp_form = form

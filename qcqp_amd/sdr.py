@@ -78,6 +78,8 @@ def dual_certificate(C, V):
 def solve_sdr(engine, form, max_sweeps=5000, tol=1e-11, seed=0):
     """Returns (X, bound, info) like the reference's solve_sdr returns (X, bound): X is the lifted
     (n+1) x (n+1) solution in the ORIGINAL variables, bound = <M0, X> (minimise form)."""
+    if not hasattr(form, 'fs'):          # GeneratedForm: dense by construction
+        return None
     d = unit_diagonal_family(form)
     if d is None:
         return None

@@ -261,3 +261,19 @@ def test_suggest_spectral_relaxation():
     q.suggest(SDR)
     assert q.spectral_bound <= q.sdr_bound + 1e-5 <= 35.55097 + 1e-3   # spectral <= SDR <= optimum
     assert f == pytest.approx(fx, rel=1e-9) or f == pytest.approx(x.dot(P0.dot(x)) + q0.dot(x) + r0, rel=1e-9)
+
+
+def test_api_on_device_generated_problem():
+    """The drop-in API on a problem that only exists on the device (problems.GeneratedForm, the cfg5 family):
+    suggest(SDR) solves the relaxation with the general solver (linear terms come back from the context),
+    samples, improve(COORD_DESCENT) -- and the result respects the certified bound."""
+    from qcqp_amd import QCQP, SDR, COORD_DESCENT, problems, sdr
+    form = problems.dense_indefinite_generated(40, 6, seed=21)
+    q = QCQP(form)
+    f, v = q.suggest(SDR, num_samples=64, seed=3)
+    lmin, S = sdr.dual_certificate_device(q.engine, q.sdr_info['y'], q.sdr_info['yN'])
+    assert lmin > -1e-6 * (1 + np.abs(S).max())
+    assert abs(q.sdr_bound - q.sdr_info['dual_value']) <= 1e-5 * (1 + abs(q.sdr_bound))
+    f2, v2 = q.improve(COORD_DESCENT, num_iters=20, seed=1)
+    assert v2 < 1e-2 and f2 >= q.sdr_bound - 1e-2 * (1 + abs(q.sdr_bound))
+    assert q.prob.variables()[0].value.shape == (40, 1)
