@@ -165,8 +165,13 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
         return L, G.ravel()
 
     hist = []
+    prev_infeas = None
     for it in range(outer):
-        res = minimize(fun_grad, V.ravel(), jac=True, method='L-BFGS-B', options=dict(maxiter=inner, maxfun=2 * inner, gtol=1e-9, ftol=1e-15))
+        # inexact inner solves: no point in polishing the Lagrangian far below the current infeasibility
+        rough = prev_infeas is not None and prev_infeas > 1e-4
+        ftol = 1e-9 if (prev_infeas is None or rough) else 1e-15
+        res = minimize(fun_grad, V.ravel(), jac=True, method='L-BFGS-B',
+                       options=dict(maxiter=inner, maxfun=2 * inner, gtol=1e-9, ftol=ftol, maxcor=20))
         V = res.x.reshape(n + 1, rank)
         h = values(V) * sc
         tt = V[n, :].dot(V[n, :]) - 1.0
@@ -175,6 +180,7 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
         y[ineq] = np.maximum(0.0, y[ineq] + sigma * h[ineq])
         yN = yN + sigma * tt
         hist.append((float(h[0]), float(infeas), sigma, int(res.nit)))
+        prev_infeas = infeas
         if verbose:
             print('outer %2d: <C,X> %.8g infeas %.2e sigma %.1e inner its %d' % (it, h[0], infeas, sigma, res.nit))
         if infeas < feas_tol and it > 0 and abs(hist[-1][0] - hist[-2][0]) <= 1e-7 * (1.0 + abs(h[0])):
