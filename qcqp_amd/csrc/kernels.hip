@@ -299,8 +299,26 @@ __global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
                 FeasSet<MAXC> Cp;
                 uint32_t itp = 0;
                 bool pending = false;
+                // Boolean-type constraint p x^2 + r == 0 (p > tol, no linear term): |f| <= s is the band
+                // a <= |x| <= b with a = sqrt(D2)/(2p), b = sqrt(D1)/(2p), D1 = 4p(s - r), D2 = -4p(r + s)
+                // (utilities.py:209-231 with q = 0).  The set is non-empty iff D1 > 0 and (D2 < 0 or D2 < D1)
+                // -- square root and division are monotone, touching / zero-width pieces vanish in the sweep --
+                // so the bisection only needs the two discriminants; the set itself is built once, for the
+                // last successful slack.
+                const bool band = mf == 1 && cq[0] == 0.0 && crel[0] == RELOP_EQ && cp[0] > 1e-4;
+                double sp = 0.0;
                 while (es - ss > a.tol) {
                     double s = (ss + es) / 2.0;
+                    if (band) {
+                        const uint32_t itb = it++;
+                        const double D1 = 0.0 - 4.0 * cp[0] * (cr[0] - s);     // q*q - 4 p rs, as the reference forms it
+                        const double D2 = 0.0 - 4.0 * (-cp[0]) * (-cr[0] - s);
+                        const bool nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
+                        if (!nonempty) { ss = s; continue; }
+                        sp = s; itp = itb; pending = true;
+                        new_viol = s; es = s;
+                        continue;
+                    }
                     FeasSet<MAXC> C;
                     if (mf == 1) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], s, C);
                     else feasible_set<MAXC>(cp, cq, cr, crel, mf, s, C);
@@ -320,6 +338,7 @@ __global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
                     }
                     new_viol = s; es = s;
                 }
+                if (pending && band) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], sp, Cp);
                 if (pending) {
                     DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t, itp};
                     double xn;
