@@ -598,3 +598,28 @@ def test_cd_phase2_exact_ties_take_the_reference_path(eng_mod, orc, n):
         x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=30, phase1=False, rng=rng)
         assert rel(X[:, r], x) < 1e-12, (r, np.max(np.abs(X[:, r] - x)))
         assert out['visits2'][r] == s2[1] and out['accepted2'][r] == s2[2], r
+
+
+@pytest.mark.parametrize('n,m,R,iters,p1', [(8, 3, 1, 5, True), (16, 2, 3, 5, True), (17, 4, 16, 8, True),
+                                            (33, 5, 17, 6, False), (40, 3, 33, 0, True), (24, 6, 5, 1, True),
+                                            (65, 2, 48, 3, True)])
+def test_dense_path_edge_shapes(eng_mod, orc, n, m, R, iters, p1):
+    """Ragged and degenerate shapes through the dense path (one block only, n not a multiple of 16, a single
+    restart, R not a multiple of 16, zero or one sweep, phase 1 skipped): points against the oracle's
+    trajectories, reported values against fresh oracle evaluations."""
+    from qcqp_amd import problems
+    funcs, _, _ = problems.dense_indefinite(n, m, seed=n + m)
+    e = make(eng_mod, funcs)
+    e.L.qcqpmi_debug_profile(e.h, DENSE_PATH, None)
+    prob = orc.Problem(funcs)
+    X0 = 0.5 * np.random.RandomState(n).randn(n, R)
+    e.upload(X0)
+    out = e.cd_run(phase1=p1, num_iters=iters, seed=9, first_index=4)
+    X = e.download()
+    for r in range(R):
+        rng = orc.Rng(orc.RNG_KEYED, 9)
+        rng.set_restart(4 + r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, phase1=p1, rng=rng)
+        assert np.max(np.abs(X[:, r] - x)) < 1e-3, r             # O(tol) at most (threshold flips), usually 1e-12
+        assert abs(prob.eval(0, X[:, r]) - out['f0'][r]) <= 1e-9 * (1 + abs(out['f0'][r]))
+        assert abs(prob.max_violation(X[:, r]) - out['maxviol'][r]) < 1e-9
