@@ -243,4 +243,13 @@ __global__ __launch_bounds__(256) void admm_book_kernel(AdmmBook b) {
     }
 }
 
+// S = sum_k C_k over the m batched products, fixed order
+__global__ void admm_sum_k_kernel(const double *__restrict__ Cb, double *__restrict__ S, int m, int64_t tot) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= tot) return;
+    double s = Cb[idx];
+    for (int k = 1; k < m; k++) s += Cb[(int64_t)k * tot + idx];
+    S[idx] = s;
+}
+
 }  // namespace qcqpmi
