@@ -42,10 +42,24 @@ struct AdmmArgs {
     double sec_tol;       // 1e-6 (utilities.py:149)
 };
 
+// wave-wide sum on DPP (row_shr prefix sums inside the rows of 16 lanes, row_bcast across them; lanes without
+// a source add 0), total broadcast from lane 63 -- a shuffle butterfly costs 12 ds_bpermute per double
+template <int CTRL, int ROW_MASK>
+__device__ inline double admm_dpp0(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);      // +0.0 where there is no source lane
+}
+
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += admm_dpp0<0x111, 0xf>(v);   // row_shr:1
+    v += admm_dpp0<0x112, 0xf>(v);   // row_shr:2
+    v += admm_dpp0<0x114, 0xf>(v);   // row_shr:4
+    v += admm_dpp0<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row's sum
+    v += admm_dpp0<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+    v += admm_dpp0<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 // one wave per (constraint k, restart r); EPL = elements per lane (n <= 64 EPL)
@@ -77,6 +91,12 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
         fz_a += L[e] * (Zq[e] * Zq[e]); fz_b += Qh[e] * Zq[e];
         fv_a += L[e] * (V[e] * V[e]);   fv_b += Qh[e] * V[e];
     }
+    // element slots e whose eigenvalues are zero in every lane (low-rank constraints: all but the ends of the
+    // spectrum): there 2 (1 + nu lam) == 2 exactly and the division in phi is a multiplication by 0.5
+    unsigned nzmask = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; e++)
+        if (__builtin_amdgcn_ballot_w64(L[e] != 0.0) != 0ull) nzmask |= 1u << e;
     // violation of z itself (QuadraticFunction.violation, utilities.py:56-62) in eigen form
     const double fz = wave_sum(fz_a) + wave_sum(fz_b) + rk;
     if (lane == 0) {
@@ -95,7 +115,8 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
             double pa = 0.0, pb = 0.0;
 #pragma unroll
             for (int e = 0; e < EPL; e++) {
-                const double xh = -(nu * Qh[e] - 2.0 * V[e]) / (2.0 * (1.0 + nu * L[e]));
+                const double num = -(nu * Qh[e] - 2.0 * V[e]);
+                const double xh = ((nzmask >> e) & 1u) ? num / (2.0 * (1.0 + nu * L[e])) : num * 0.5;   // wave-uniform
                 X[e] = xh;
                 pa += L[e] * (xh * xh);
                 pb += Qh[e] * xh;
