@@ -62,6 +62,16 @@ __device__ inline double wave_sum(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// num / den through the hardware reciprocal + two Newton steps (relative error ~1e-16; the exact IEEE division
+// expands to ~30 instructions and the secular function costs 16 of them per lane and bisection step).  The
+// multiplier is only located to 1e-6 (utilities.py:149), so last-bit differences of phi are immaterial.
+__device__ inline double admm_div(double num, double den) {
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    return num * r;
+}
+
 // one wave per (constraint k, restart r); EPL = elements per lane (n <= 64 EPL)
 template <int EPL>
 __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
 #pragma unroll
             for (int e = 0; e < EPL; e++) {
                 const double num = -(nu * Qh[e] - 2.0 * V[e]);
-                const double xh = ((nzmask >> e) & 1u) ? num / (2.0 * (1.0 + nu * L[e])) : num * 0.5;   // wave-uniform
+                const double xh = ((nzmask >> e) & 1u) ? admm_div(num, 2.0 * (1.0 + nu * L[e])) : num * 0.5;   // wave-uniform
                 X[e] = xh;
                 pa += L[e] * (xh * xh);
                 pb += Qh[e] * xh;
