@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
         ts[p] = t < a.ntiles ? t : a.ntiles - 1;
     }
     const int kf0 = f0 + 4 * wm, tl0 = tg0 + 4 * wn;   // this wave's functions / tiles
+    const int vt = (a.ntiles - tl0) < 4 ? ((a.ntiles - tl0) > 0 ? a.ntiles - tl0 : 0) : 4;   // valid tile slots of this wave
     double fa[4][4];
 #pragma unroll
     for (int u = 0; u < 4; u++)
@@ -238,10 +239,12 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
 #pragma unroll
                 for (int ks = 0; ks < DP_KC; ks++)
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int t = 0; t < 4; t++) {
+                        if (t >= vt) continue;   // wave-uniform: tile slot beyond the population (small populations)
 #pragma unroll
-                        for (int t = 0; t < 4; t++)
+                        for (int u = 0; u < 4; u++)
                             acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][u], bv[ks][t], acc[u][t], 0, 0, 0);
+                    }
             } else {
                 // the quadratic-form accumulators need 32 more registers: operands two k-steps at a time
 #pragma unroll
@@ -254,10 +257,12 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
 #pragma unroll
                     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-                        for (int u = 0; u < 4; u++)
+                        for (int t = 0; t < 4; t++) {
+                            if (t >= vt) continue;   // wave-uniform
 #pragma unroll
-                            for (int t = 0; t < 4; t++)
+                            for (int u = 0; u < 4; u++)
                                 acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][u], bv[ks][t], acc[u][t], 0, 0, 0);
+                        }
                 }
             }
             __syncthreads();
