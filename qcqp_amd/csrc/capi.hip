@@ -326,7 +326,8 @@ int launch_eval(qcqpmi_ctx *c, bool want_F) {
 }
 
 template <int MAXC>
-int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
+int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool *used_rs = nullptr) {
+    if (used_rs) *used_rs = false;
     dim3 grid((unsigned)(c->Rpad / 16)), block(256);
     if (phase1) {
         tic(c, 1);
@@ -362,6 +363,7 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds) {
         else QM_RS(false, 2);
 #undef QM_RS
         HIPCHK(c, hipGetLastError());
+        if (used_rs) *used_rs = true;
         return 0;
     }
     // dynamic LDS: [X tile] + partial tiles + G + diagonal block + slack + feasible-set table
@@ -429,7 +431,7 @@ int cd_run_general(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol
     a.P = c->dp; a.X = c->X; a.R = c->R; a.f0cur = c->d_f0; a.slack = c->d_mv;
     a.num_iters = num_iters; a.viol_tol = viol_tol; a.tol = tol; a.seed = seed; a.first_index = first_index;
     a.visits = c->d_visits; a.accepted = c->d_acc; a.sweeps = c->d_sweeps; a.status = c->d_status;
-    a.flag = c->d_flag; a.prof = nullptr; a.dbg = 0;
+    a.flag = c->d_flag; a.prof = nullptr; a.dbg = 0; a.f0out = nullptr; a.mvout = nullptr;
     g.gP = c->d_gP; g.Rpad = c->Rpad;
     g.exact_t0 = (c->n <= 64 && !(c->dbg & 16)) ? 1 : 0;   // small problems: the reference's own arithmetic for t0
     dim3 grid((unsigned)(c->Rpad / 16)), block(256);
@@ -1064,7 +1066,7 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
     a.num_iters = num_iters; a.viol_tol = viol_tol; a.tol = tol; a.seed = seed; a.first_index = first_index;
     a.visits = c->d_visits; a.accepted = c->d_acc; a.sweeps = c->d_sweeps; a.status = c->d_status;
     a.flag = c->d_flag;
-    a.prof = nullptr;
+    a.prof = nullptr; a.f0out = nullptr; a.mvout = nullptr;
     a.dbg = c->dbg;
     if (c->profile) {
         if (c->d_prof) { (void)hipFree(c->d_prof); c->d_prof = nullptr; }
@@ -1089,9 +1091,13 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
     hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((c->Rpad + 255) / 256)), dim3(256), 0, c->stream, c->d_mv,
                        c->d_status1, c->d_flag, c->R, c->Rpad, viol_tol);
     HIPCHK(c, hipGetLastError());
-    rc = (c->maxc <= 1) ? launch_cd<1>(c, a, false, used_lds) : launch_cd<4>(c, a, false, used_lds);
+    // the pipelined kernel leaves objective and max violation of the restarts it ran in place (tracked objective,
+    // element-wise violations of the final tile): no evaluation pass afterwards
+    bool used_rs = false;
+    a.f0out = c->d_f0; a.mvout = c->d_mv;
+    rc = (c->maxc <= 1) ? launch_cd<1>(c, a, false, used_lds, &used_rs) : launch_cd<4>(c, a, false, used_lds, &used_rs);
     if (rc) return rc;
-    if ((rc = launch_eval(c, false))) return rc;
+    if (!used_rs && (rc = launch_eval(c, false))) return rc;
     std::vector<int> st, st1;
     if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
     for (int64_t r = 0; r < c->R; r++) {

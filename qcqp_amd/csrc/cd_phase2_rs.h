@@ -403,10 +403,9 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                     const bool moved = actn && fabs(dlt) > a.tol;
                     const double delta = moved ? dlt : 0.0;
                     xb[c] = moved ? pick : xi;                    // in place: committed to LDS only if no redo
-                    // f(pick) - f(xi) = delta (t2 delta + t1),  t1 = 2 (g2 - t2 xi)
-                    //                 = delta (t2 (delta - 2 xi) + 2 g2)
-                    const double hh = __builtin_fma(-2.0, xi, delta);
-                    fcur = __builtin_fma(delta, __builtin_fma(t2, hh, g2) + g2, fcur);
+                    // f(x + delta e_i) - f(x) = delta (2 (P x)_i + q_i + P_ii delta) = delta (t2 delta + 2 g2):
+                    // g2 = G_i + q_i / 2 already contains P_ii x_i
+                    fcur = __builtin_fma(delta, __builtin_fma(t2, delta, g2 + g2), fcur);
                     if (FULL) {
                         // pinned in place (a plain expression is sunk to the end of the block by the
                         // scheduler, keeping 16 compare masks alive = SGPR spills)
@@ -472,12 +471,37 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
         if (lane < 16 && gr < a.R) {
             a.visits[gr] = S.visits; a.accepted[gr] = S.accepted; a.sweeps[gr] = S.sweeps;
             a.status[gr] = S.status;
+            if (a.f0out && a.flag[gr]) a.f0out[gr] = S.fcur;   // tracked exactly through every accepted move
         }
         if (PROF && a.prof && tid == 0)
             for (int k = 0; k < 8; k++) a.prof[tile * 16 + k] = pc[k];
 #undef PROF_TICK
     }
     __syncthreads();
+    if (a.mvout) {
+        // max violation of the final points, same expression as eval_kernel: (p x + q) x + r of the one
+        // constraint every coordinate carries (single class, one constraint per coordinate)
+        const int e0 = P.cptr[P.krep[0]];
+        const double cp = P.cp[e0], cq = P.cq[e0], cr = P.cr[e0];
+        const int rel = P.crel[e0];
+        const int r = tid & 15, slot = tid >> 4;
+        double v = -QM_INF;
+        for (int64_t i = slot; i < P.n; i += 32) {
+            const double x = Xs[i * 16 + r];
+            const double f = (cp * x + cq) * x + cr;
+            const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+            v = w > v ? w : v;
+        }
+        double *red = part2;                 // 512 doubles of the partial-tile area, free by now
+        red[tid] = v;
+        __syncthreads();
+        if (tid < 16) {
+            const int64_t g = tile * 16 + tid;
+            double m = -QM_INF;
+            for (int s2 = 0; s2 < 32; s2++) { const double w = red[s2 * 16 + tid]; m = w > m ? w : m; }
+            if (g < a.R && a.flag[g]) a.mvout[g] = m;
+        }
+    }
     if (XLDS)
         for (int64_t idx = tid; idx < n16 * 16; idx += 512) Xg[idx] = Xl[idx];
 }

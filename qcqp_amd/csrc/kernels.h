@@ -71,6 +71,8 @@ struct CdArgs {
     uint8_t *flag;          // [Rpad] in: run this restart (phase 2) / out: phase-1 feasible
     long long *prof;        // optional [tiles][8] cycle counters of wave 0 (debug), or nullptr
     int dbg;                // debug switches for timing experiments (results invalid when != 0)
+    double *f0out;          // optional [Rpad]: phase 2 writes the tracked objective of the restarts it ran ...
+    double *mvout;          // ... and their max violation at the final point (saves the evaluation pass afterwards)
 };
 
 }  // namespace qcqpmi

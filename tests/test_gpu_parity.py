@@ -203,7 +203,10 @@ def test_full_size_headline_config(eng_mod, orc):
     assert out['maxviol'][ran].max() < 1e-2
     assert np.all(np.abs(X[:, ran] ** 2 - 1.0) < 1e-2)
     f0, mv = e.eval()
-    assert np.array_equal(f0, out['f0']) and np.array_equal(mv, out['maxviol'])
+    # the pipelined kernel reports the objective it tracked through every accepted move (no evaluation pass
+    # afterwards): equal to a fresh evaluation up to the rounding of ~1e4 updates; violations are recomputed
+    # from the final tile with the evaluation kernel's own expression: bit-identical
+    assert np.max(np.abs(f0 - out['f0']) / (1.0 + np.abs(f0))) < 1e-11 and np.array_equal(mv, out['maxviol'])
     # oracle trajectories
     prob = orc.Problem(funcs)
     stuck = int(np.flatnonzero(~ran)[0]) if (~ran).any() else 4095
