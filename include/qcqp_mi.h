@@ -113,6 +113,13 @@ int qcqpmi_cd_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double viol_to
                   uint64_t seed, uint64_t first_index, int64_t *sweeps1, int64_t *sweeps2,
                   int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
                   double *maxviol);
+/* Per-restart status codes of the last qcqpmi_cd_run (R ints each; 0 = fine).  A restart on which the
+ * reference would raise -- -1: np.random.uniform on an unbounded interval (utilities.py:267), -2: NameError in
+ * OneVarQuadraticFunction.eval (utilities.py:119), -3: max() of an empty list (qcqp.py:117), -4: feasible set
+ * with more segments than the kernel holds -- is reported here, its f0 / maxviol are +inf (it never wins
+ * qcqpmi_select_best) and the other restarts are unaffected.  qcqpmi_cd_run itself returns
+ * QCQPMI_EREFERENCE / QCQPMI_EUNSUPPORTED only when EVERY restart failed (R = 1: the reference's behaviour). */
+int qcqpmi_cd_status(qcqpmi_ctx *ctx, int *status1, int *status2);
 
 /* ---- improve(ADMM) on the resident population (improve_admm qcqp.py:254-285; admm_phase1 :195-212;
  * admm_phase2 :215-251; onecons_qcqp utilities.py:149-196).  The host supplies what the reference

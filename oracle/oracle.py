@@ -86,6 +86,7 @@ def lib():
                                        C.c_void_p, _ip]
         L.orc_improve_cd.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_double, C.c_double,
                                      C.c_int, C.c_void_p, _ip, _ip]
+        L.orc_cd_phase2_incremental.argtypes = [C.c_void_p, _dp, _dp, C.c_int64, C.c_double, C.c_void_p, _ip]
         L.orc_onecons.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, C.c_double, _dp]
         L.orc_admm_phase1.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, C.c_int64, _ip]
         L.orc_admm_phase2.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp, _dp, C.c_double,
@@ -216,6 +217,19 @@ class Problem:
 
     def cd_phase2(self, x, num_iters=1000, viol_tol=1e-2, tol=1e-4, rng=None):
         return self._cd('orc_cd_phase2', x, num_iters, viol_tol, tol, rng)
+
+    def cd_phase2_incremental(self, x, num_iters=1000, tol=1e-4, rng=None):
+        """Optimised CPU baseline of phase 2 (incremental gradient, qcqp.py:152-178 semantics); separable
+        constraints only.  Same one-variable solver as cd_phase2, O(n) per accepted move."""
+        if getattr(self, '_P0d', None) is None:
+            self._P0d = np.ascontiguousarray(self.funcs[0][0].toarray(), dtype=np.float64)
+        x = _vec(x).copy()
+        stats = np.zeros(3, dtype=np.int64)
+        rng = rng or Rng(RNG_MT, 0, from_numpy_global=True)
+        rc = lib().orc_cd_phase2_incremental(self.h, _d(self._P0d), _d(x), num_iters, tol, rng.h, _i(stats))
+        if rc:
+            raise RuntimeError('oracle orc_cd_phase2_incremental failed rc=%d' % rc)
+        return x, stats
 
     def _cd(self, fn, x, num_iters, viol_tol, tol, rng):
         x = _vec(x).copy()

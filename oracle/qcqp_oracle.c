@@ -558,6 +558,95 @@ int orc_cd_phase2(const orc_prob *p, double *x, int64_t num_iters, double viol_t
     return rc;
 }
 
+/* Optimised CPU baseline of phase 2 (bench.py's second, fairer cpu_baseline): the same algorithm and the same
+ * one-variable solver as orc_cd_phase2 (qcqp.py:152-178), but with the bookkeeping a CPU programmer would write
+ * instead of the reference's per-call structure: g = P0 x and f0(x) are maintained incrementally (O(n) per ACCEPTED
+ * move through column i of the symmetric P0, O(1) per visit), and each coordinate's constraint list is built once.
+ * Requires separable constraints (every constraint touches exactly one coordinate); returns -5 otherwise.
+ * P0d: dense row-major n x n copy of f0.P.  Trajectories agree with orc_cd_phase2 up to rounding of t1 / t0. */
+int orc_cd_phase2_incremental(const orc_prob *p, const double *P0d, double *x, int64_t num_iters, double tol,
+                              orc_rng *g, int64_t *stats) {
+    const int64_t n = p->n, m = p->m;
+    /* coordinate -> its constraints (order preserved) */
+    int64_t *coord = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m > 0 ? m : 1));
+    int64_t *cnt = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+    for (int64_t k = 1; k <= m; k++) {
+        const quad_t *f = &p->f[k];
+        int64_t c = -1;
+        int ok = 1;
+        for (int64_t i = 0; i < n && ok; i++) {
+            for (int64_t jj = f->ptr[i]; jj < f->ptr[i + 1]; jj++) {
+                if (f->val[jj] == 0.0) continue;
+                if (f->idx[jj] != i || (c >= 0 && c != i)) { ok = 0; break; }
+                c = i;
+            }
+            if (f->q[i] != 0.0) { if (c >= 0 && c != i) ok = 0; c = i; }
+        }
+        if (!ok || c < 0) { free(coord); free(cnt); return -5; }
+        coord[k - 1] = c;
+        cnt[c + 1]++;
+    }
+    for (int64_t i = 0; i < n; i++) cnt[i + 1] += cnt[i];
+    int64_t *list = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m > 0 ? m : 1));
+    int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) fill[i] = cnt[i];
+    for (int64_t k = 1; k <= m; k++) list[fill[coord[k - 1]]++] = k;
+    int64_t maxc = 1;
+    for (int64_t i = 0; i < n; i++) if (cnt[i + 1] - cnt[i] > maxc) maxc = cnt[i + 1] - cnt[i];
+    double *fs3 = (double *)malloc(sizeof(double) * 3 * (size_t)maxc);
+    int *relops = (int *)malloc(sizeof(int) * (size_t)maxc);
+    double *gv = (double *)malloc(sizeof(double) * (size_t)n);
+    const double *q0 = p->f[0].q;
+    const double viol = orc_max_violation(p, x);
+    double fcur = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        double acc = 0.0;
+        const double *row = P0d + i * n;
+        for (int64_t j = 0; j < n; j++) acc += row[j] * x[j];
+        gv[i] = acc;
+        fcur += (acc + q0[i]) * x[i];
+    }
+    fcur += p->f[0].r;
+    int64_t update_counter = 0, sweeps = 0, visits = 0, accepted = 0;
+    int converged = 0, rc = 0;
+    for (int64_t t = 0; t < num_iters && !converged && rc == 0; t++) {
+        sweeps++;
+        for (int64_t i = 0; i < n; i++) {
+            visits++;
+            const double xi = x[i], t2 = P0d[i * n + i];
+            const double t1 = 2.0 * (gv[i] - t2 * xi) + q0[i];
+            const double t0 = fcur - xi * (t2 * xi + t1);
+            int64_t mf = 0;
+            for (int64_t e = cnt[i]; e < cnt[i + 1]; e++) {
+                const quad_t *f = &p->f[list[e]];
+                double pk = 0.0;
+                for (int64_t jj = f->ptr[i]; jj < f->ptr[i + 1]; jj++) if (f->idx[jj] == i) pk += f->val[jj];
+                if (pk != 0.0 || f->q[i] != 0.0) {
+                    fs3[3 * mf] = pk; fs3[3 * mf + 1] = f->q[i]; fs3[3 * mf + 2] = f->r;
+                    relops[mf++] = f->relop;
+                }
+            }
+            double new_xi;
+            rng_ctx(g, (uint32_t)i, (uint32_t)t | 0x80000000u, 0);
+            int got = orc_onevar_qcqp(t2, t1, t0, fs3, relops, mf, viol, g, &new_xi, NULL, 0, NULL);
+            if (got < 0) { rc = got; break; }
+            if (got && fabs(new_xi - xi) > tol) {
+                const double d = new_xi - xi;
+                fcur += d * (t2 * d + 2.0 * gv[i] + q0[i]);
+                const double *col = P0d + i * n;      /* symmetric: column i = row i */
+                for (int64_t j = 0; j < n; j++) gv[j] += col[j] * d;
+                x[i] = new_xi; update_counter = 0; accepted++;
+            } else {
+                update_counter++;
+                if (update_counter == n) { converged = 1; break; }
+            }
+        }
+    }
+    if (stats) { stats[0] = sweeps; stats[1] = visits; stats[2] = accepted; }
+    free(coord); free(cnt); free(list); free(fill); free(fs3); free(relops); free(gv);
+    return rc;
+}
+
 int orc_improve_cd(const orc_prob *p, double *x, int64_t num_iters, double viol_tol,
                    double tol, int phase1, orc_rng *g, int64_t *stats1, int64_t *stats2) {
     int rc = 0;

@@ -139,6 +139,7 @@ struct qcqpmi_ctx {
     bool profile = false;
     int dbg = 0;
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
+    std::vector<int> last_st1, last_st2;   // per-restart status codes of the last coordinate-descent run (qcqpmi_cd_status)
 };
 
 namespace {
@@ -279,6 +280,39 @@ int fetch_cd_outputs(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, int64_t 
     memcpy(st1.data(), h + 6 * n8 + (size_t)R * 4, (size_t)R * 4);
     if (ran_phase2) memcpy(ran_phase2, h + 7 * n8, (size_t)R);
     return 0;
+}
+
+// Per-restart status policy of a coordinate-descent run.  A restart on which the reference would raise
+// (code != 0) is a FAILED restart, not a failed population: its objective / max violation become +inf (host
+// outputs and the device copies select_best reads), the codes stay readable through qcqpmi_cd_status.  The call
+// itself fails -- with the reference's message -- only when every restart failed (in particular R == 1, the
+// reference's single-point behaviour).
+int cd_apply_status(qcqpmi_ctx *c, const std::vector<int> &st, const std::vector<int> &st1, double *f0, double *maxviol,
+                    int seg_cap) {
+    const int64_t R = c->R;
+    c->last_st1 = st1; c->last_st2 = st;
+    int64_t nfail = 0, first = -1;
+    for (int64_t r = 0; r < R; r++)
+        if (st1[(size_t)r] || st[(size_t)r]) { if (first < 0) first = r; nfail++; }
+    if (nfail == 0) return 0;
+    if (nfail < R) {
+        const double inf = INFINITY;
+        for (int64_t r = 0; r < R; r++) {
+            if (!(st1[(size_t)r] || st[(size_t)r])) continue;
+            if (f0) f0[r] = inf;
+            if (maxviol) maxviol[r] = inf;
+            HIPCHK(c, hipMemcpyAsync(c->d_f0 + r, &inf, sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_mv + r, &inf, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const int64_t r = first;
+    const int s1 = st1[(size_t)r], s2 = st[(size_t)r];
+    if (s1 == -3) return fail(c, QCQPMI_EREFERENCE, "phase 1: a variable appears in no constraint (reference: ValueError: max() arg is an empty sequence, qcqp.py:117); restart %lld", (long long)r);
+    if (s1 == -4 || s2 == -4) return fail(c, QCQPMI_EUNSUPPORTED, "feasible set with more than %d segments; restart %lld", seg_cap, (long long)r);
+    if (s1) return fail(c, QCQPMI_EREFERENCE, "phase 1: unbounded feasible interval with zero objective (reference: OverflowError in np.random.uniform, utilities.py:267); restart %lld", (long long)r);
+    return fail(c, QCQPMI_EREFERENCE, "phase 2: the reference raises on restart %lld (code %d: unbounded interval with zero objective / NameError in OneVarQuadraticFunction.eval)", (long long)r, s2);
 }
 
 int launch_eval(qcqpmi_ctx *c, bool want_F) {
@@ -465,13 +499,7 @@ int cd_run_general(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol
     if ((rc = launch_eval(c, false))) return rc;
     std::vector<int> st, st1;
     if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, nullptr, f0, maxviol, st, st1))) return rc;
-    for (int64_t r = 0; r < c->R; r++) {
-        const int s1 = st1[(size_t)r], s2 = st[(size_t)r];
-        if (s1 == -3) return fail(c, QCQPMI_EREFERENCE, "phase 1: a variable appears in no constraint (reference: ValueError: max() arg is an empty sequence, qcqp.py:117); restart %lld", (long long)r);
-        if (s1 == -4 || s2 == -4) return fail(c, QCQPMI_EUNSUPPORTED, "feasible set with more than %d segments; restart %lld", GEN_CAP, (long long)r);
-        if (s1) return fail(c, QCQPMI_EREFERENCE, "phase 1: unbounded feasible interval with zero objective (reference: OverflowError in np.random.uniform, utilities.py:267); restart %lld", (long long)r);
-        if (s2) return fail(c, QCQPMI_EREFERENCE, "phase 2: the reference raises on restart %lld (code %d)", (long long)r, s2);
-    }
+    if ((rc = cd_apply_status(c, st, st1, f0, maxviol, GEN_CAP))) return rc;
     return 0;
 }
 
@@ -560,6 +588,36 @@ int qcqpmi_set_quad(qcqpmi_ctx *c, int64_t k, int format, const double *vals, co
             }
     } else {
         return fail(c, QCQPMI_EINVAL, "set_quad: unknown format %d", format);
+    }
+    // P must be symmetric (include/qcqp_mi.h): get_onevar_func (utilities.py:99-105) and the in-block
+    // Gauss-Seidel fold read P[k, j] where the mathematics has P[j, k].  The reference symmetrises in
+    // get_qcqp_form (utilities.py:333, 345); raw arrays are checked here instead of being trusted.
+    if (format == QCQPMI_FMT_DENSE) {
+        for (int64_t i = 0; i < n; i++)
+            for (int64_t j = i + 1; j < n; j++)
+                if (vals[i * n + j] != vals[j * n + i])
+                    return fail(c, QCQPMI_EINVAL, "set_quad: P of function %lld is not symmetric (entry %lld,%lld); pass (P + P^T)/2",
+                                (long long)k, (long long)i, (long long)j);
+    } else {
+        std::vector<std::pair<int64_t, double>> ent(h.cv.size());
+        for (size_t e = 0; e < h.cv.size(); e++) ent[e] = {(int64_t)h.ci[e] * n + h.cj[e], h.cv[e]};
+        std::sort(ent.begin(), ent.end(), [](const std::pair<int64_t, double> &a, const std::pair<int64_t, double> &b) { return a.first < b.first; });
+        size_t w = 0;
+        for (size_t e = 0; e < ent.size(); e++) {   // duplicates add up (COO semantics)
+            if (w > 0 && ent[w - 1].first == ent[e].first) ent[w - 1].second += ent[e].second;
+            else ent[w++] = ent[e];
+        }
+        ent.resize(w);
+        for (const auto &en : ent) {
+            const int64_t i = en.first / n, j = en.first % n;
+            if (i == j) continue;
+            const int64_t tk = j * n + i;
+            auto it = std::lower_bound(ent.begin(), ent.end(), tk, [](const std::pair<int64_t, double> &a, int64_t key) { return a.first < key; });
+            const double tv = (it != ent.end() && it->first == tk) ? it->second : 0.0;
+            if (tv != en.second)
+                return fail(c, QCQPMI_EINVAL, "set_quad: P of function %lld is not symmetric (entry %lld,%lld); pass (P + P^T)/2",
+                            (long long)k, (long long)i, (long long)j);
+        }
     }
     h.q.assign(q, q + n);
     h.r = r; h.relop = relop; h.set = true;
@@ -1100,14 +1158,16 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
     if (!used_rs && (rc = launch_eval(c, false))) return rc;
     std::vector<int> st, st1;
     if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
-    for (int64_t r = 0; r < c->R; r++) {
-        if (st1[(size_t)r] == -3)
-            return fail(c, QCQPMI_EREFERENCE, "phase 1: a variable appears in no constraint (reference: ValueError: max() arg is an empty sequence, qcqp.py:117); restart %lld", (long long)r);
-        if (st1[(size_t)r])
-            return fail(c, QCQPMI_EREFERENCE, "phase 1: unbounded feasible interval with zero objective (reference: OverflowError in np.random.uniform, utilities.py:267); restart %lld", (long long)r);
-        if (st[(size_t)r])
-            return fail(c, QCQPMI_EREFERENCE, "phase 2: the reference raises on restart %lld (code %d: unbounded interval with zero objective / NameError in OneVarQuadraticFunction.eval)", (long long)r, st[(size_t)r]);
-    }
+    if ((rc = cd_apply_status(c, st, st1, f0, maxviol, 0))) return rc;
+    return 0;
+}
+
+int qcqpmi_cd_status(qcqpmi_ctx *c, int *status1, int *status2) {
+    if (!c) return QCQPMI_EINVAL;
+    if ((int64_t)c->last_st1.size() != c->R || (int64_t)c->last_st2.size() != c->R)
+        return fail(c, QCQPMI_ESTATE, "cd_status: no coordinate-descent run on the resident population");
+    if (status1) memcpy(status1, c->last_st1.data(), (size_t)c->R * sizeof(int));
+    if (status2) memcpy(status2, c->last_st2.data(), (size_t)c->R * sizeof(int));
     return 0;
 }
 

@@ -341,9 +341,13 @@ __global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
                 if (pending && band) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], sp, Cp);
                 if (pending) {
                     DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t, itp};
-                    double xn;
-                    (void)onevar_minimise<MAXC>(0.0, 0.0, 0.0, Cp, dk, &xn);
-                    new_xi = xn;
+                    double xn = xi;
+                    const int got = onevar_minimise<MAXC>(0.0, 0.0, 0.0, Cp, dk, &xn);
+                    // the band test decides non-emptiness on the discriminants; the set rebuilt from rounded
+                    // end points can collapse to nothing: then the step is infeasible at this slack, as in
+                    // the reference (onevar_qcqp returns None -> the move is not made)
+                    if (got == 1) new_xi = xn;
+                    else { new_viol = viol; if (got < 0) my_status = got; }
                 }
                 if (new_viol < viol) { xi = new_xi; Xs[i * 16 + r] = xi; upd = 1; my_acc++; }
                 // violation of the constraints on x_i after the update (feeds qcqp.py:142)
@@ -384,168 +388,7 @@ __global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
     if (slot == 0 && live) a.sweeps[gr] = sweeps_done;
 }
 
-// -------------------------------------------------------------------- coordinate descent phase 2
-
-// Blocked Gauss-Seidel.  For a block of 16 coordinates I_b the products G = P0[I_b,:] X are one
-// 16 x n16 by n16 x 16 fp64 MFMA contraction (K split over the 4 waves); the 16 coordinates are
-// then visited in order by lanes 0..15 of wave 0 (lane = restart), each new x_i being folded into
-// the remaining rows of the block through the 16x16 diagonal block of P0.  The one-variable
-// feasible sets of separable constraints do not depend on the other coordinates, so they are
-// computed for the whole block by all 256 threads before the sequential part.
-#if 0  // first version, superseded by cd_phase2.h (kept until the new kernel is parity-green)
-template <int MAXC, bool XLDS>
-__global__ __launch_bounds__(256) void cd_phase2_kernel(CdArgs a) {
-    extern __shared__ double smem[];
-    const DevProblem &P = a.P;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t tile = blockIdx.x;
-    double *Xg = a.X + tile * P.n16 * 16;
-    // dynamic LDS carve-up
-    double *sp = smem;
-    double *Xl = sp; if (XLDS) sp += P.n16 * 16;
-    double *part = sp; sp += 4 * 256;
-    double *Dblk = sp; sp += 256;
-    double *ivlo = sp; sp += (MAXC + 1) * 256;
-    double *ivhi = sp; sp += (MAXC + 1) * 256;
-    double *slk = sp; sp += 16;
-    int *ivn = (int *)sp; sp += 128;
-    int *done = (int *)sp;
-
-    double *Xs = XLDS ? Xl : Xg;
-    if (XLDS) {
-        for (int64_t idx = tid; idx < P.n16 * 16; idx += 256) Xl[idx] = Xg[idx];
-    }
-    if (tid < 16) {
-        int64_t g = tile * 16 + tid;
-        slk[tid] = (g < a.R) ? a.slack[g] : 0.0;
-    }
-    if (tid == 0) *done = 0;
-    // per-restart chain state (wave 0, lanes 0..15)
-    const int64_t gr = tile * 16 + (lane & 15);
-    double fcur = 0.0;
-    int64_t upd_counter = 0, visits = 0, accepted = 0, sweeps = 0;
-    bool conv = true;
-    int status = 0;
-    if (wave == 0 && lane < 16 && gr < a.R) {
-        conv = a.flag[gr] ? false : true;
-        fcur = a.f0cur[gr];
-    }
-    __syncthreads();
-
-    const int kper = (int)(P.KS / 4);  // KS = n16/4 is a multiple of 4
-    bool all_done = false;
-    long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;
-#define PROF_TICK(slot)                                                    \
-    if (a.prof) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); pc[slot] += now_ - tp; tp = now_; }
-    if (a.prof) tp = (long long)__builtin_amdgcn_s_memtime();
-    for (int64_t t = 0; t < a.num_iters && !all_done; t++) {
-        if (wave == 0 && lane < 16 && !conv) sweeps++;
-        for (int64_t b = 0; b < P.NB; b++) {
-            // ---- G partials on the matrix cores
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            acc = block_rows_times_X(P.Apack + b * P.KS * 64, Xs, wave * kper, (wave + 1) * kper,
-                                     lane, acc);
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-                part[wave * 256 + ((lane >> 4) + 4 * v) * 16 + (lane & 15)] = acc[v];
-            PROF_TICK(0)
-            // ---- per (coordinate c, restart r): feasible set at the restart's slack
-            {
-                const int c = tid >> 4, r = tid & 15;
-                const int64_t i = 16 * b + c;
-                Dblk[tid] = P.P0[i * P.n16 + 16 * b + r];
-                FeasSet<MAXC> C;
-                C.n = 0;
-                if (i < P.n) {
-                    const int e0 = P.cptr[i], mf = P.cptr[i + 1] - e0;
-                    double cp[MAXC], cq[MAXC], cr[MAXC];
-                    int crel[MAXC];
-#pragma unroll
-                    for (int k = 0; k < MAXC; k++) {
-                        bool ok = k < mf;
-                        cp[k] = ok ? P.cp[e0 + k] : 0.0; cq[k] = ok ? P.cq[e0 + k] : 0.0;
-                        cr[k] = ok ? P.cr[e0 + k] : 0.0; crel[k] = ok ? P.crel[e0 + k] : RELOP_LE;
-                    }
-                    feasible_set<MAXC>(cp, cq, cr, crel, mf, slk[r], C);
-                }
-                ivn[tid] = C.n;
-#pragma unroll
-                for (int j = 0; j <= MAXC; j++) { ivlo[j * 256 + tid] = C.lo[j]; ivhi[j * 256 + tid] = C.hi[j]; }
-            }
-            PROF_TICK(1)
-            __syncthreads();
-            PROF_TICK(2)
-            // ---- sequential part: lane = restart
-            if (wave == 0) {
-                if (lane < 16) {
-                    const int r = lane;
-                    double xb[16], gb[16];
-#pragma unroll
-                    for (int c = 0; c < 16; c++) {
-                        xb[c] = Xs[(16 * b + c) * 16 + r];
-                        gb[c] = part[c * 16 + r] + part[256 + c * 16 + r] + part[512 + c * 16 + r] +
-                                part[768 + c * 16 + r];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 16; c++) {
-                        const int64_t i = 16 * b + c;
-                        if (i < P.n && !conv) {
-                            const double t2 = Dblk[c * 16 + c];
-                            const double xi = xb[c];
-                            const double t1 = 2.0 * (gb[c] - t2 * xi) + P.q0[i];
-                            const double t0 = fcur - xi * (t2 * xi + t1);
-                            FeasSet<MAXC> C;
-                            C.n = ivn[c * 16 + r];
-#pragma unroll
-                            for (int j = 0; j <= MAXC; j++) { C.lo[j] = ivlo[j * 256 + c * 16 + r]; C.hi[j] = ivhi[j * 256 + c * 16 + r]; }
-                            DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i,
-                                       (uint32_t)t | 0x80000000u, 0u};
-                            double xn = xi;
-                            int got = onevar_minimise<MAXC>(t2, t1, t0, C, dk, &xn);
-                            visits++;
-                            if (got < 0) { status = got; conv = true; }
-                            else if (got && fabs(xn - xi) > a.tol) {
-                                const double delta = xn - xi;
-                                xb[c] = xn;
-                                fcur = t0 + xn * (t2 * xn + t1);
-                                upd_counter = 0;
-                                accepted++;
-#pragma unroll
-                                for (int c2 = c + 1; c2 < 16; c2++) gb[c2] += Dblk[c2 * 16 + c] * delta;
-                            } else {
-                                upd_counter++;
-                                if (upd_counter == P.n) conv = true;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 16; c++) Xs[(16 * b + c) * 16 + r] = xb[c];
-                }
-                // all restarts of the tile converged?
-                unsigned long long live = __ballot(lane < 16 && !conv);
-                if (lane == 0) *done = (live == 0ull) ? 1 : 0;
-            }
-            PROF_TICK(3)
-            __syncthreads();
-            PROF_TICK(4)
-            pc[5]++;
-            if (*done) { all_done = true; break; }
-        }
-    }
-    __syncthreads();
-    if (XLDS) {
-        for (int64_t idx = tid; idx < P.n16 * 16; idx += 256) Xg[idx] = Xl[idx];
-    }
-    if (wave == 0 && lane < 16 && gr < a.R) {
-        a.visits[gr] = visits; a.accepted[gr] = accepted; a.sweeps[gr] = sweeps;
-        a.status[gr] = status;
-    }
-    if (a.prof && tid == 0)
-        for (int k = 0; k < 8; k++) a.prof[tile * 8 + k] = pc[k];
-#undef PROF_TICK
-}
-
-#endif
+// coordinate descent phase 2: cd_phase2.h (general kernel), cd_phase2_rs.h (role-split pipelined kernel)
 
 }  // namespace qcqpmi
 #include "cd_phase2.h"

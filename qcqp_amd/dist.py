@@ -3,18 +3,33 @@
 There is no data-path collective: every rank holds a replica of the problem and runs its own
 slice of the restarts; the only exchange is the final "pick the global best" step
 (QCQPForm.better ordering, utilities.py:135-146), done natively by RCCL inside the C library
-(qcqpmi_comm_select_best).  The RCCL unique id is the only thing that has to travel between the
-processes beforehand; that bootstrap uses torch.distributed's gloo store when the job was
-launched by torch.distributed.run (plumbing only -- no tensor of the hot path touches torch).
+(qcqpmi_comm_select_best).  The 128-byte RCCL unique id is the only thing that has to travel
+between the processes beforehand.  That bootstrap is a tiny file rendezvous in a per-job
+directory on the node's local file system (one node = one file system; no torch, no sockets):
+every message is a file written atomically (tmp + rename), readers poll for it.
+
+Two ways to get N ranks:
+  * a launcher sets RANK / LOCAL_RANK / WORLD_SIZE (`python -m torch.distributed.run ...` does) and
+    every process calls `env_world()`;
+  * `spawn_local_ranks(N, argv)` from a plain `python bench.py --gpus N`: the calling process becomes
+    rank 0 and N-1 children are started with the same command line.
 """
 import os
+import pickle
+import subprocess
+import sys
+import tempfile
+import time
+import uuid
 
 import numpy as np
 
+RDZV_ENV = 'QCQP_AMD_RDZV'
+
 
 def env_world():
-    """(rank, local_rank, world) from the launcher's environment (torch.distributed.run)."""
-    return (int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)),
+    """(rank, local_rank, world) from the launcher's environment."""
+    return (int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', 0))),
             int(os.environ.get('WORLD_SIZE', 1)))
 
 
@@ -28,13 +43,13 @@ def shard_range(total, rank, world):
 def better_key(f0, maxviol, index, tol=1e-4):
     """Total order equivalent to folding QCQPForm.better over candidates, ties -> lowest index."""
     v = float(maxviol)
-    bucket = int(v / tol) if v == v else 1 << 62
+    bucket = int(v / tol) if (v == v and v != float('inf')) else 1 << 62
     return (bucket, float(f0), int(index))
 
 
 def select_best_host(f0, maxviol, tol=1e-4, index_offset=0):
     """Reference implementation of the selection rule on host arrays (used by tests and by the
-    gloo transport of the CPU-only multi-process tests)."""
+    file transport of the CPU-only multi-process tests)."""
     best = None
     for i, (f, v) in enumerate(zip(f0, maxviol)):
         k = better_key(f, v, index_offset + i, tol)
@@ -43,47 +58,134 @@ def select_best_host(f0, maxviol, tol=1e-4, index_offset=0):
     return best
 
 
-class GlooBootstrap(object):
-    """torch.distributed (gloo) used ONLY to move small Python objects between ranks."""
+def _job_key():
+    """Directory name every rank of one job agrees on without talking to each other."""
+    key = os.environ.get(RDZV_ENV)
+    if key:
+        return key
+    # launched by an external launcher: all workers share the launcher's pid and rendezvous endpoint
+    return 'ext_%s_%s_%s_%d' % (os.environ.get('MASTER_ADDR', 'local'), os.environ.get('MASTER_PORT', '0'),
+                                os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())
 
-    def __init__(self):
-        import torch.distributed as td
-        self.td = td
-        if not td.is_initialized():
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            td.init_process_group(backend='gloo')
-        self.rank, self.world = td.get_rank(), td.get_world_size()
+
+class FileRendezvous(object):
+    """Moves small Python objects between the ranks of one node through atomically renamed files."""
+
+    def __init__(self, rank=None, world=None, key=None, timeout=600.0):
+        r, _, w = env_world()
+        self.rank = r if rank is None else int(rank)
+        self.world = w if world is None else int(world)
+        self.timeout = float(timeout)
+        self.dir = os.path.join(tempfile.gettempdir(), 'qcqp_amd_rdzv', key or _job_key())
+        os.makedirs(self.dir, exist_ok=True)
+        self.seq = 0
+
+    def _put(self, name, obj):
+        path = os.path.join(self.dir, name)
+        tmp = '%s.tmp.%d' % (path, os.getpid())
+        with open(tmp, 'wb') as f:
+            pickle.dump(obj, f, protocol=2)
+        os.rename(tmp, path)
+
+    def _get(self, name):
+        path = os.path.join(self.dir, name)
+        t0 = time.time()
+        delay = 0.0005
+        while not os.path.exists(path):
+            if time.time() - t0 > self.timeout:
+                raise RuntimeError('rendezvous timeout waiting for %s (rank %d of %d)' % (path, self.rank, self.world))
+            time.sleep(delay)
+            delay = min(delay * 1.5, 0.05)
+        with open(path, 'rb') as f:
+            return pickle.load(f)
 
     def broadcast_bytes(self, payload, src=0):
-        obj = [payload if self.rank == src else None]
-        self.td.broadcast_object_list(obj, src=src)
-        return obj[0]
+        self.seq += 1
+        name = 'b%06d' % self.seq
+        if self.rank == src:
+            self._put(name, payload)
+            return payload
+        return self._get(name)
 
     def allgather(self, obj):
-        out = [None] * self.world
-        self.td.all_gather_object(out, obj)
-        return out
+        self.seq += 1
+        self._put('g%06d.%d' % (self.seq, self.rank), obj)
+        return [self._get('g%06d.%d' % (self.seq, r)) for r in range(self.world)]
 
     def barrier(self):
-        self.td.barrier()
+        self.allgather(None)
+
+    def close(self):
+        """Last collective of a job: everybody arrives, then rank 0 removes the directory."""
+        try:
+            self.barrier()
+            if self.rank == 0:
+                time.sleep(0.05)
+                for name in os.listdir(self.dir):
+                    try:
+                        os.remove(os.path.join(self.dir, name))
+                    except OSError:
+                        pass
+                os.rmdir(self.dir)
+        except Exception:
+            pass
+
+
+def spawn_local_ranks(world, argv=None, quiet=True):
+    """Plain `python script.py --gpus N` (no launcher): start ranks 1..N-1 as children running the same
+    command line, make the caller rank 0.  Returns the list of child processes (empty when a launcher
+    already provided the world, or world == 1)."""
+    world = int(world)
+    if world <= 1 or 'WORLD_SIZE' in os.environ:
+        return []
+    key = 'job_%s' % uuid.uuid4().hex
+    os.environ[RDZV_ENV] = key
+    os.environ['WORLD_SIZE'] = str(world)
+    os.environ['RANK'] = '0'
+    os.environ['LOCAL_RANK'] = '0'
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    argv = list(sys.argv if argv is None else argv)
+    kids = []
+    for r in range(1, world):
+        env = dict(os.environ)
+        env['RANK'] = str(r)
+        env['LOCAL_RANK'] = str(r)
+        kids.append(subprocess.Popen([sys.executable] + argv, env=env,
+                                     stdout=subprocess.DEVNULL if quiet else None))
+    return kids
+
+
+def wait_children(kids, timeout=600.0):
+    """Reap the children of spawn_local_ranks; returns the worst exit code."""
+    worst = 0
+    t0 = time.time()
+    for p in kids:
+        try:
+            rc = p.wait(timeout=max(1.0, timeout - (time.time() - t0)))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = -9
+        worst = worst or rc
+    return worst
 
 
 def init_rccl(engine, rank, world, bootstrap=None):
-    """Create the RCCL communicator of `engine` (native, inside libqcqp_mi.so)."""
+    """Create the RCCL communicator of `engine` (native, inside libqcqp_mi.so).  Returns the
+    rendezvous object (None for a single rank)."""
     if world == 1:
         uid = engine.comm_unique_id()
     else:
-        bootstrap = bootstrap or GlooBootstrap()
+        bootstrap = bootstrap or FileRendezvous(rank, world)
         uid = engine.comm_unique_id().tobytes() if rank == 0 else None
         uid = np.frombuffer(bootstrap.broadcast_bytes(uid, 0), dtype=np.uint8).copy()
     engine.comm_init(rank, world, uid)
     return bootstrap
 
 
-def global_best_gloo(bootstrap, local_key, local_x):
+def global_best_host(bootstrap, local_key, local_x):
     """CPU transport of the final exchange (tests only): all-gather the keys, take the minimum,
     winner's x is broadcast.  Mirrors qcqpmi_comm_select_best."""
-    keys = bootstrap.allgather(local_key)
+    keys = bootstrap.allgather(tuple(local_key))
     win = min(range(len(keys)), key=lambda w: keys[w])
     x = bootstrap.broadcast_bytes(np.asarray(local_x, dtype=np.float64).tobytes()
                                   if bootstrap.rank == win else None, win)

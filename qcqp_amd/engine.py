@@ -66,8 +66,10 @@ class Engine(object):
 
     def _set_quad(self, k, f):
         q = np.ascontiguousarray(f.qarray, dtype=np.float64)
+        # (P + P^T)/2 like get_qcqp_form (utilities.py:333, 345): exact no-op for symmetric input; the C ABI
+        # rejects a non-symmetric matrix (the one-variable coefficients assume symmetry, utilities.py:99-105)
         if sp.issparse(f.P):
-            P = sp.csr_matrix(f.P)
+            P = sp.csr_matrix((f.P + f.P.T) / 2.)
             P.sum_duplicates()
             P.sort_indices()
             ptr = np.ascontiguousarray(P.indptr, dtype=np.int64)
@@ -76,7 +78,8 @@ class Engine(object):
             rc = self.L.qcqpmi_set_quad(self.h, k, 1, _dp(val), _ip(idx), _ip(ptr), len(val), _dp(q),
                                         float(f.r), RELOP_CODE[f.relop])
         else:
-            P = np.ascontiguousarray(f.P, dtype=np.float64)
+            P = np.asarray(f.P, dtype=np.float64)
+            P = np.ascontiguousarray((P + P.T) / 2.)
             rc = self.L.qcqpmi_set_quad(self.h, k, 0, _dp(P), None, None, 0, _dp(q), float(f.r),
                                         RELOP_CODE[f.relop])
         self._chk(rc)
@@ -143,6 +146,11 @@ class Engine(object):
                                        float(tol), int(seed), int(first_index), _ip(out['sweeps1']),
                                        _ip(out['sweeps2']), _ip(out['visits2']), _ip(out['accepted2']),
                                        _bp(out['ran_phase2']), _dp(out['f0']), _dp(out['maxviol'])))
+        st1 = np.zeros(R, dtype=np.int32)
+        st2 = np.zeros(R, dtype=np.int32)
+        self._chk(self.L.qcqpmi_cd_status(self.h, st1.ctypes.data_as(C.POINTER(C.c_int)),
+                                          st2.ctypes.data_as(C.POINTER(C.c_int))))
+        out['status1'], out['status2'] = st1, st2     # != 0: the reference would raise on this restart (f0 = inf)
         return out
 
     # ----------------------------------------------------------------------- ADMM

@@ -108,8 +108,32 @@ sys.path.insert(0, %(repo)r)
 import numpy as np
 from qcqp_amd import dist, problems
 from oracle import oracle as orc
+kids = dist.spawn_local_ranks(int(os.environ.get('TEST_SELF_SPAWN', '1')))   # no-op under a launcher
 rank, local, world = dist.env_world()
-boot = dist.GlooBootstrap()
+
+
+class GlooTransport(object):
+    # same three calls as dist.FileRendezvous, on torch.distributed's gloo backend (test-side only)
+    def __init__(self):
+        import torch.distributed as td
+        self.td = td
+        td.init_process_group(backend='gloo')
+        self.rank, self.world = td.get_rank(), td.get_world_size()
+    def broadcast_bytes(self, payload, src=0):
+        obj = [payload if self.rank == src else None]
+        self.td.broadcast_object_list(obj, src=src)
+        return obj[0]
+    def allgather(self, obj):
+        out = [None] * self.world
+        self.td.all_gather_object(out, obj)
+        return out
+    def barrier(self):
+        self.td.barrier()
+    def close(self):
+        self.td.barrier()
+
+
+boot = GlooTransport() if os.environ.get('TEST_TRANSPORT') == 'gloo' else dist.FileRendezvous(rank, world)
 funcs, _, _ = problems.boolean_least_squares(12, 16, seed=5)
 prob = orc.Problem(funcs)
 R = 10                                  # global restarts, sharded by index
@@ -123,25 +147,18 @@ for r in range(cnt):
 out = np.stack(out, axis=1)
 f0, mv = prob.eval_batch(out)
 key = dist.select_best_host(f0, mv, 1e-4, index_offset=first)
-gkey, gx = dist.global_best_gloo(boot, key, out[:, key[2] - first])
-np.save(os.path.join(%(tmp)r, 'rank%%d.npy' %% rank), np.concatenate([[gkey[0], gkey[1], gkey[2]], gx]))
-boot.barrier()
+gkey, gx = dist.global_best_host(boot, key, out[:, key[2] - first])
+np.save(os.path.join(%(tmp)r, 'rank%%d.npy' %% rank), np.concatenate([[gkey[0], gkey[1], gkey[2], world], gx]))
+boot.close()
+sys.exit(dist.wait_children(kids))
 '''
 
 
-def test_two_process_gloo_selection(tmp_path, orc):
-    """world_size 2 on CPU: restarts sharded by global index, the final exchange picks the same
-    global best on both ranks, identical to the single-process answer."""
+def _check_two_rank_result(tmp_path, orc):
     from qcqp_amd import dist, problems
-    script = tmp_path / 'worker.py'
-    script.write_text(WORKER % dict(repo=REPO, tmp=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29577', str(script)]
-    subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     r0 = np.load(tmp_path / 'rank0.npy')
     r1 = np.load(tmp_path / 'rank1.npy')
-    assert np.array_equal(r0, r1)
+    assert np.array_equal(r0, r1) and int(r0[3]) == 2
     # single-process reference
     funcs, _, _ = problems.boolean_least_squares(12, 16, seed=5)
     prob = orc.Problem(funcs)
@@ -155,7 +172,46 @@ def test_two_process_gloo_selection(tmp_path, orc):
     f0, mv = prob.eval_batch(xs)
     key = dist.select_best_host(f0, mv, 1e-4)
     assert int(r0[2]) == key[2] and r0[1] == key[1]
-    assert np.array_equal(r0[3:], xs[:, key[2]])
+    assert np.array_equal(r0[4:], xs[:, key[2]])
+
+
+@pytest.mark.parametrize('transport', ['file', 'gloo'])
+def test_two_process_launcher_selection(tmp_path, orc, transport):
+    '''world_size 2 on CPU under torch.distributed.run (the driver's launcher): restarts sharded by global
+    index, the final exchange picks the same global best on both ranks, identical to the single-process
+    answer.  transport=file is the product's own rendezvous (qcqp_amd.dist.FileRendezvous, torch-free);
+    transport=gloo runs the same exchange on torch.distributed's gloo backend.'''
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % dict(repo=REPO, tmp=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', TEST_TRANSPORT=transport)
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29577' if transport == 'file' else '29578', str(script)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    _check_two_rank_result(tmp_path, orc)
+
+
+def test_two_process_self_spawn_selection(tmp_path, orc):
+    '''Plain `python worker.py` with no launcher: rank 0 spawns rank 1 itself (dist.spawn_local_ranks, the
+    path `python bench.py --gpus N` takes) and both meet through the file rendezvous.'''
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % dict(repo=REPO, tmp=str(tmp_path)))
+    env = dict(os.environ, TEST_SELF_SPAWN='2')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'QCQP_AMD_RDZV'):
+        env.pop(k, None)
+    subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=600, stdout=subprocess.PIPE,
+                   stderr=subprocess.STDOUT)
+    _check_two_rank_result(tmp_path, orc)
+
+
+def test_product_package_does_not_import_torch():
+    '''The north star: no PyTorch anywhere in the product (torch stays test/launcher-side plumbing).'''
+    import re
+    pkg = os.path.join(REPO, 'qcqp_amd')
+    for name in os.listdir(pkg):
+        if name.endswith('.py'):
+            src = open(os.path.join(pkg, name)).read()
+            assert not re.search(r'^\s*(import|from)\s+torch', src, re.M), name
 
 
 # ------------------------------------------------------------------ host logic of the SDP relaxation

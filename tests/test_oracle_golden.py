@@ -1,9 +1,11 @@
 """Pins the CPU oracle (oracle/) to golden vectors captured from the reference itself
 (tests/golden/*.npz, generator tools/gen_golden.py).  CPU-only."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import funcs_from_npz, load_golden, RELSTR
+from conftest import REPO, funcs_from_npz, load_golden, RELSTR
 
 SMALL = ['bls10', 'bls32', 'maxcut12', 'dense16', 'beam10']
 
@@ -165,3 +167,33 @@ def test_g9_sdr_tail(orc, name):
         assert np.max(np.abs(x - z['xs'][:, t])) < 1e-12
         assert abs(f - z['fv'][t, 0]) <= 1e-12 * (1 + abs(f))
         assert abs(v - z['fv'][t, 1]) <= 1e-12 * (1 + abs(v))
+
+
+def test_oracle_under_sanitizers():
+    """the CPU restatement runs clean under AddressSanitizer + UBSan (`make -C oracle asan`
+    builds oracle/selftest.c against the oracle with -fsanitize=address,undefined)."""
+    import subprocess
+    odir = os.path.join(REPO, 'oracle')
+    subprocess.check_call(['make', '-C', odir, 'asan'], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(odir, 'oracle_selftest_asan')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout.decode()[-2000:]
+    assert b'oracle selftest ok' in out.stdout
+
+
+def test_incremental_cpu_baseline_matches_restatement(orc):
+    """bench.py's optimised CPU baseline (incremental gradient) follows the faithful restatement's phase 2
+    (same one-variable solver, different bookkeeping): same points to rounding, same visit / accept counts."""
+    from qcqp_amd import problems
+    for n, m_rows, seed in ((24, 16, 1), (64, 40, 2), (96, 30, 3)):
+        funcs, _, _ = problems.boolean_least_squares(n, m_rows, seed=seed)
+        prob = orc.Problem(funcs)
+        for r in range(3):
+            rng = orc.Rng(orc.RNG_KEYED, 5)
+            rng.set_restart(r)
+            x0 = orc.keyed_normal_matrix(5, n, 1, first_index=r)[:, 0]
+            x1, _ = prob.cd_phase1(x0, num_iters=50, rng=rng)
+            xa, sa = prob.cd_phase2(x1, rng=rng)
+            xb, sb = prob.cd_phase2_incremental(x1, rng=rng)
+            assert np.max(np.abs(xa - xb)) < 1e-9
+            assert sa[1] == sb[1] and sa[2] == sb[2]
