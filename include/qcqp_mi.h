@@ -121,6 +121,19 @@ int qcqpmi_cd_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double viol_to
  * QCQPMI_EREFERENCE / QCQPMI_EUNSUPPORTED only when EVERY restart failed (R = 1: the reference's behaviour). */
 int qcqpmi_cd_status(qcqpmi_ctx *ctx, int *status1, int *status2);
 
+/* ---- unit operators: the reference's module-level helpers for a batch of independent cases, evaluated on the
+ * device by the same code the coordinate-descent kernels inline (no context needed).
+ *   get_feasible_intervals(f, s)  utilities.py:198-232:  pqrs = count x (p, q, r, s), relop per case;
+ *        out = count x (n, lo0, hi0, lo1, hi1), at most two intervals (+-inf as IEEE infinities).
+ *   onevar_qcqp(f0, fs, s)        utilities.py:241-288:  f0 = count x (p, q, r); fs = count x 4 x (p, q, r, relop as a
+ *        number); nf[i] <= 4 constraints in use; status 1 = a point in x[i], 0 = None, < 0 = the reference raises
+ *        (-1 OverflowError in np.random.uniform, -2 NameError in OneVarQuadraticFunction.eval); ties and the
+ *        zero-objective draw (utilities.py:266-267, 288) use the keyed Philox stream (seed; case index).
+ *        C_out (optional) = count x 5 x (lo, hi): the feasible set after the end-point sweep, nC_out its size. */
+int qcqpmi_feasible_intervals_batch(int device, int64_t count, const double *pqrs, const int *relop, double *out);
+int qcqpmi_onevar_qcqp_batch(int device, int64_t count, const double *f0, const double *fs, const int *nf,
+                             const double *s, uint64_t seed, double *x, int *status, double *C_out, int *nC_out);
+
 /* ---- improve(ADMM) on the resident population (improve_admm qcqp.py:254-285; admm_phase1 :195-212;
  * admm_phase2 :215-251; onecons_qcqp utilities.py:149-196).  The host supplies what the reference
  * obtains from LAPACK / SuperLU: the eigendecomposition of every constraint matrix (lmb: m x n,

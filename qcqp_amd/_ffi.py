@@ -41,6 +41,9 @@ PROTOTYPES = [
     ('qcqpmi_cd_run', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_uint64,
                                 C.c_uint64, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp]),
     ('qcqpmi_cd_status', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ('qcqpmi_feasible_intervals_batch', C.c_int, [C.c_int, C.c_int64, c_dp, C.POINTER(C.c_int), c_dp]),
+    ('qcqpmi_onevar_qcqp_batch', C.c_int, [C.c_int, C.c_int64, c_dp, c_dp, C.POINTER(C.c_int), c_dp, C.c_uint64, c_dp,
+                                           C.POINTER(C.c_int), c_dp, C.POINTER(C.c_int)]),
     ('qcqpmi_admm_set_eig', C.c_int, [C.c_void_p, c_dp, c_dp]),
     ('qcqpmi_admm_setup', C.c_int, [C.c_void_p]),
     ('qcqpmi_admm_run', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double, c_dp,

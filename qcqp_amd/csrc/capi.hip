@@ -1321,3 +1321,4 @@ int qcqpmi_comm_select_best(qcqpmi_ctx *c, double tol, int64_t index_offset, int
 }  // extern "C"
 
 #include "capi_admm.inc"
+#include "capi_units.inc"

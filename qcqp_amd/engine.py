@@ -161,8 +161,10 @@ class Engine(object):
         assert lmb.shape == (self.m, self.n) and Q.shape == (self.m, self.n, self.n)
         self._chk(self.L.qcqpmi_admm_set_eig(self.h, _dp(lmb), _dp(Q)))
 
-    def admm_setup(self):
-        """Eigenpairs of every constraint matrix computed on the device (rocSOLVER), in place of admm_set_eig."""
+    def admm_setup(self, method='rocsolver'):
+        """Eigenpairs of every constraint matrix computed on the device, in place of admm_set_eig.
+        method='rocsolver': batched dsyevd on the dense matrices (any rank)."""
+        assert method == 'rocsolver'
         self._chk(self.L.qcqpmi_admm_setup(self.h))
 
     def admm_run(self, rho, Minv, phase1=True, num_iters=1000, tol=1e-2, viol_lim=1e4):

@@ -1,0 +1,234 @@
+"""GPU parity tests at the sizes where the dispatch changes: the LDS-tiled MFMA sampler / evaluator
+(BASELINE.json configs[2] at full size), the dense-constraint path with and without K-split, the unit
+operators of the C ABI against the reference's golden vectors (G3 / G4), the rocSOLVER setup path.
+Run with `-m gpu` on an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import RELSTR, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng_mod():
+    from qcqp_amd import engine
+    assert engine.device_count() >= 1, 'no HIP device visible'
+    return engine
+
+
+def make(eng_mod, funcs):
+    from qcqp_amd.form import QCQPForm
+    return eng_mod.Engine(QCQPForm.from_arrays(funcs))
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b)) / (1.0 + np.abs(np.asarray(b))))
+
+
+# ------------------------------------------------------------------ SDR sampling: the GEMM path
+@pytest.mark.parametrize('n,S', [(200, 256), (500, 384), (2000, 256)])
+def test_sdr_sample_gemm_path(eng_mod, orc, n, S):
+    """x = mu + F xi through dense_products_kernel<3> (taken when n >= 113 and S >= 128; the n = 10 test of
+    test_gpu_parity.py goes through affine_tiles_kernel): given normals and the device's keyed Philox
+    normals, against the plain NumPy product (qcqp.py:396 with the factor hoisted)."""
+    from qcqp_amd import problems
+    funcs, _, _ = problems.maxcut(n, 0.5, seed=4)
+    e = make(eng_mod, funcs)
+    rs = np.random.RandomState(n)
+    F = rs.randn(n, n) / np.sqrt(n)
+    mu = rs.randn(n)
+    Xi = rs.randn(n, S)
+    e.sdr_sample(mu, F, S, Xi=Xi)
+    X = e.download()
+    ref = mu[:, None] + F.dot(Xi)
+    assert np.max(np.abs(X - ref)) < 1e-12 * (1 + np.max(np.abs(ref)))
+    e.sdr_sample(mu, F, S, seed=11, first_index=77)
+    Xd = e.download()
+    Xi2 = orc.keyed_normal_matrix(11, n, S, first_index=77)
+    ref2 = mu[:, None] + F.dot(Xi2)
+    assert np.max(np.abs(Xd - ref2)) < 1e-11 * (1 + np.max(np.abs(ref2)))
+
+
+def test_config3_maxcut_full_size(eng_mod, orc):
+    """BASELINE.json configs[2] at full size: MAXCUT on G(2000, 0.5), 8192 Goemans-Williamson samples
+    x ~ N(0, X*) with X* = V V^T a unit-diagonal PSD matrix (rank 40, the shape an SDP solution has),
+    sampled and evaluated on the device.  Objective and max violation of 40 columns against the oracle
+    (1e-12), sample covariance against X*, sharding invariance (samples 1024..2047 drawn alone with their
+    global index offset are bit-identical: what rank 1 of 8 computes)."""
+    from qcqp_amd import problems
+    n, S, rk = 2000, 8192, 40
+    funcs, _, _ = problems.maxcut(n, 0.5, seed=1)
+    e = make(eng_mod, funcs)
+    rs = np.random.RandomState(5)
+    V = rs.randn(n, rk)
+    V /= np.linalg.norm(V, axis=1)[:, None]
+    F = np.zeros((n, n))
+    F[:, :rk] = V                      # x = F xi has covariance V V^T
+    mu = np.zeros(n)
+    e.sdr_sample(mu, F, S, seed=2024, first_index=0)
+    f0, mv = e.eval()
+    X = e.download()
+    # the sampler against the oracle's keyed normals on a slice of columns
+    cols = np.r_[0:16, 1024:1040, 8184:8192]
+    Xi = np.stack([orc.keyed_normal_matrix(2024, n, 1, first_index=int(s))[:, 0] for s in cols], axis=1)
+    assert np.max(np.abs(X[:, cols] - V.dot(Xi[:rk]))) < 1e-11
+    # evaluation (qcqp.py:399-401) of those columns against the oracle
+    prob = orc.Problem(funcs)
+    g0, gv = prob.eval_batch(X[:, cols])
+    assert rel(f0[cols], g0) < 1e-12 and rel(mv[cols], gv) < 1e-12
+    # distribution: sample covariance of 8192 draws vs X* (standard error ~ 1/sqrt(S) = 0.011 per entry)
+    sub = np.arange(0, n, 40)
+    Cs = X[sub].dot(X[sub].T) / S
+    assert np.max(np.abs(Cs - V[sub].dot(V[sub].T))) < 0.08
+    assert abs(np.mean(X)) < 5e-3
+    # sharding invariance: the share of rank 1 of 8
+    e.sdr_sample(mu, F, 1024, seed=2024, first_index=1024)
+    Xs = e.download()
+    assert np.array_equal(Xs, X[:, 1024:2048])
+    f1, m1 = e.eval()
+    assert np.array_equal(f1, f0[1024:2048]) and np.array_equal(m1, mv[1024:2048])
+
+
+# ------------------------------------------------------------------ dense path at dispatch-changing sizes
+@pytest.mark.parametrize('R', [48, 4096])
+def test_dense_path_scale_dispatch_vs_oracle(eng_mod, orc, R):
+    """BASELINE.json configs[4] family (dense indefinite constraints) at n = 256, m = 130: R = 48 takes the
+    K-split products (grid.z = 7 partial planes + the fix-up plane) with G staged in LDS; R = 4096 takes one
+    plane and the occupancy-bound chain.  Both overlap the chain of block b with the products of block b + 1 on
+    a second stream (hole + fix-up launch).  Sampled restarts against the oracle's trajectories (same keyed
+    stream), every restart's reported values against a fresh evaluation."""
+    from qcqp_amd import problems
+    n, m, iters, seed, first = 256, 130, 2, 13, 5
+    funcs, _, _ = problems.dense_indefinite(n, m, seed=11)
+    e = make(eng_mod, funcs)
+    prob = orc.Problem(funcs)
+    X0 = 1.5 * np.random.RandomState(3).randn(n, R)
+    e.upload(X0)
+    out = e.cd_run(phase1=True, num_iters=iters, seed=seed, first_index=first)
+    X = e.download()
+    f0, mv = e.eval()
+    assert rel(out['f0'], f0) < 1e-9 and np.max(np.abs(out['maxviol'] - mv)) < 1e-9
+    sample = [0, 1, R // 2, R - 1]
+    close = 0
+    for r in sample:
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(first + r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+        d = np.max(np.abs(X[:, r] - x))
+        assert d < 1e-3, (r, d)      # a move of size tol +- rounding accepted on one side only: O(tol), never more
+        close += d < 1e-6 * (1 + np.max(np.abs(x)))
+        assert out['sweeps1'][r] == s1[0], r
+        fo = prob.eval(0, X[:, r])
+        assert abs(fo - out['f0'][r]) <= 1e-9 * (1 + abs(fo)), r
+        assert abs(prob.max_violation(X[:, r]) - out['maxviol'][r]) < 1e-9, r
+    assert close >= len(sample) - 1, close
+
+
+# ------------------------------------------------------------------ unit operators vs the reference's goldens
+def test_g3_feasible_intervals_on_device(eng_mod):
+    """get_feasible_intervals (utilities.py:198-232) evaluated by the device function of onevar.h on the 4 800
+    golden cases captured from the reference: bit-exact end points (same IEEE operations in the same order)."""
+    from qcqp_amd import _ffi
+    z = load_golden('g3_intervals')
+    cases, out = z['cases'], z['out']
+    N = len(cases)
+    pqrs = np.ascontiguousarray(cases[:, :4])
+    relop = np.ascontiguousarray(cases[:, 4].astype(np.int32))
+    res = np.zeros((N, 5))
+    rc = _ffi.lib().qcqpmi_feasible_intervals_batch(0, N, pqrs.ctypes.data_as(_ffi.c_dp),
+                                                     relop.ctypes.data_as(C.POINTER(C.c_int)), res.ctypes.data_as(_ffi.c_dp))
+    assert rc == 0
+    for i in range(N):
+        cnt = int(out[i, 0])
+        assert int(res[i, 0]) == cnt, (i, cases[i])
+        for j in range(cnt):
+            assert res[i, 1 + 2 * j] == out[i, 1 + 2 * j] and res[i, 2 + 2 * j] == out[i, 2 + 2 * j], (i, cases[i])
+
+
+def test_g4_onevar_qcqp_on_device(eng_mod, orc):
+    """onevar_qcqp (utilities.py:241-288) on the device against the reference's 176 golden cases (every quirk of
+    SURVEY.md appendix A): None / raise / point classification always; the point itself bit-exactly whenever the
+    reference drew nothing from the RNG; for cases decided by a draw (zero objective, exact ties) the device's
+    keyed draw must land in the feasible set the oracle computes."""
+    from qcqp_amd import _ffi
+    z = load_golden('g4_onevar_qcqp')
+    N = len(z['s'])
+    f0 = np.ascontiguousarray(z['f0'])
+    fs = np.ascontiguousarray(z['fs'])
+    nf = np.ascontiguousarray(z['nf'].astype(np.int32))
+    s = np.ascontiguousarray(z['s'])
+    x = np.zeros(N)
+    st = np.zeros(N, dtype=np.int32)
+    Cout = np.zeros((N, 5, 2))
+    nC = np.zeros(N, dtype=np.int32)
+    ip = C.POINTER(C.c_int)
+    rc = _ffi.lib().qcqpmi_onevar_qcqp_batch(0, N, f0.ctypes.data_as(_ffi.c_dp), fs.ctypes.data_as(_ffi.c_dp),
+                                              nf.ctypes.data_as(ip), s.ctypes.data_as(_ffi.c_dp), 123, x.ctypes.data_as(_ffi.c_dp),
+                                              st.ctypes.data_as(ip), Cout.ctypes.data_as(_ffi.c_dp), nC.ctypes.data_as(ip))
+    assert rc == 0
+    exact = 0
+    for i in range(N):
+        if z['err'][i]:
+            assert st[i] < 0, i
+            continue
+        if z['isnone'][i]:
+            assert st[i] == 0, (i, st[i], x[i])
+            continue
+        assert st[i] == 1, (i, st[i])
+        p0, q0 = z['f0'][i, 0], z['f0'][i, 1]
+        if p0 == 0 and q0 == 0:
+            # zero objective: uniform draw from a random interval (utilities.py:266-267); any point of the set is valid
+            assert any(Cout[i, j, 0] <= x[i] <= Cout[i, j, 1] for j in range(nC[i])), (i, x[i])
+        elif x[i] == z['x'][i]:
+            exact += 1
+        else:
+            # only an exact tie between end points may differ (np.random.choice(bestxs), utilities.py:288)
+            fv = lambda t: p0 * t * t + q0 * t
+            assert z['draws'][i] > 0 and fv(x[i]) == fv(z['x'][i]), (i, x[i], z['x'][i])
+            assert any(x[i] in (Cout[i, j, 0], Cout[i, j, 1]) for j in range(nC[i])), i
+    assert exact >= 60
+
+
+# ------------------------------------------------------------------ device-side ADMM setup (rocSOLVER)
+@pytest.fixture(scope='module')
+def rocsolver_loaded():
+    """librocsolver.so is 0.9 GB: page it in once per session (up to a few minutes on a fresh box)."""
+    C.CDLL('/opt/rocm/lib/librocsolver.so', mode=C.RTLD_GLOBAL)
+    return True
+
+
+def test_admm_device_eigh_rocsolver(eng_mod, orc, rocsolver_loaded):
+    """qcqpmi_admm_setup: f.eigh of every constraint on the device (rocSOLVER batched dsyevd) instead of host
+    LAPACK.  Rank-2 beamforming constraints have an (n-2)-dimensional null space: any orthonormal basis of it is
+    a valid set of eigenvectors and the projections do not depend on the choice -- results agree with the
+    host-eigh run and with the oracle to the accuracy the bisection (1e-6 on every multiplier) leaves after 80
+    iterations."""
+    from qcqp_amd import problems
+    funcs, _, _ = problems.beamforming(12, 4, 3, seed=2)
+    prob = orc.Problem(funcs)
+    n, m = prob.n, prob.m
+    rho = float(np.sqrt(m))
+    P0 = np.asarray(funcs[0][0])
+    Minv = np.linalg.inv(2. * (P0 + rho * m * np.eye(n)))
+    R = 9
+    X0 = np.random.RandomState(4).randn(n, R)
+    res = []
+    for device in (False, True):
+        e = make(eng_mod, funcs)
+        if device:
+            e.admm_setup(method='rocsolver')
+        else:
+            lm, Q = prob.eig()
+            e.admm_set_eig(lm, Q)
+        e.upload(X0)
+        out = e.admm_run(rho, Minv, phase1=True, num_iters=80)
+        res.append((e.download(), out))
+    (Xh, oh), (Xd, od) = res
+    assert rel(Xd, Xh) < 2e-3
+    assert rel(od['f0'], oh['f0']) < 1e-3 and np.max(np.abs(od['maxviol'] - oh['maxviol'])) < 1e-3
+    for r in range(3):
+        xa = prob.improve_admm(X0[:, r], num_iters=80, rho=rho)
+        assert rel(Xd[:, r], xa) < 2e-3, r
