@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QCQPMI_ABI_VERSION 1
+#define QCQPMI_ABI_VERSION 2
 
 enum {
     QCQPMI_OK = 0,
@@ -140,14 +140,30 @@ int qcqpmi_onevar_qcqp_batch(int device, int64_t count, const double *f0, const 
  * Q: m x n x n, NumPy eigh layout: Q[k][:, j] = eigenvector j; cached on the context like f.eigh,
  * utilities.py:160-162) and, for phase 2, Minv = (2 (P0 + rho m I))^-1 (n x n) in place of the
  * SuperLU factorisation of qcqp.py:224-227.  rho must already be validated / chosen by the caller
- * (qcqp.py:261-278).  Outputs (R entries each, may be NULL): iterations of phase 1 / phase 2, objective
- * and max violation of the returned points. */
+ * (qcqp.py:261-278).  Minv may be NULL when P0 is diagonal (the inverse is formed on the device).  Outputs (R entries
+ * each, may be NULL): iterations of phase 1 / phase 2, objective and max violation of the returned points. */
 int qcqpmi_admm_set_eig(qcqpmi_ctx *ctx, const double *lmb, const double *Q);
 /* The same cache computed ON THE DEVICE (f.eigh = LA.eigh(P), utilities.py:160-162, for every constraint at once:
  * rocSOLVER batched dsyevd on the resident dense matrices) -- for problems whose constraints couple coordinates.
  * Eigenvectors of degenerate eigenvalues span the same spaces as LAPACK's but are a different basis: iterates
  * agree with qcqpmi_admm_set_eig to rounding, not bit for bit. */
 int qcqpmi_admm_setup(qcqpmi_ctx *ctx);
+/* REDUCED bases for low-rank constraints (beamforming: rank 2).  onecons_qcqp (utilities.py:149-196) moves a point only
+ * inside span(B_k), B_k = [eigenvectors of the nonzero eigenvalues of P_k, the unit vector along the part of q_k outside
+ * them (eigenvalue 0)]: with lam (m x rp), Bv (m x rp x n, basis vector j of constraint k contiguous, orthonormal, zero
+ * padded) and qhat = B_k^T q_k (m x rp) the ADMM iteration runs on (m rp) x n operators instead of (m n) x n --
+ * algebraically the same iteration (duals live in span(B_k)).  The multiplier bracket comes from the nonzero
+ * eigenvalues given here, not from LAPACK's round-off eigenvalues of the null space: results agree
+ * with the full-basis path to the accuracy of the reference's own bisection (1e-6 on every multiplier). */
+int qcqpmi_admm_set_basis(qcqpmi_ctx *ctx, int64_t rp, const double *lam, const double *Bv, const double *qhat);
+/* out[k] = P_k Vin_k for every constraint k (n x p blocks, row-major; shared != 0: one Vin for all): the two passes over
+ * the resident dense constraint matrices that a randomised range finder needs (Y = P Omega, Z = P Q) -- the device-side
+ * part of building the reduced bases above without an O(n^3) eigendecomposition per constraint. */
+int qcqpmi_admm_apply_constraints(qcqpmi_ctx *ctx, int p, const double *Vin, int shared, double *out);
+/* onecons_qcqp(z, f_k) (utilities.py:149-196) for every resident point z, k = 1..m, with the installed eigenpairs /
+ * basis: out = R x n projections (host layout of qcqpmi_pop_download); the population is not changed.  (The reference's
+ * own test examples/tests/one_constraint_qcqp.py exercises exactly this function.) */
+int qcqpmi_admm_onecons(qcqpmi_ctx *ctx, int64_t k, double *out);
 int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, double viol_lim,
                     double rho, const double *Minv, int64_t *iters1, int64_t *iters2, double *f0,
                     double *maxviol);

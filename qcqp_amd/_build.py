@@ -7,7 +7,7 @@ REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libqcqp_mi.so')
 SOURCES = ['capi.hip', 'capi_admm.inc', 'capi_units.inc', 'kernels.hip', 'kernels.h', 'onevar.h', 'philox.h', 'cd_phase2.h',
-           'cd_phase2_rs.h', 'admm.h', 'cd_general.h', 'cd_dense.h', 'capi_dense.inc', 'sdr_solve.h']
+           'cd_phase2_rs.h', 'cd_phase2_q.h', 'admm.h', 'gemm_pk.h', 'cd_general.h', 'cd_dense.h', 'capi_dense.inc', 'sdr_solve.h']
 
 
 def needs_build():

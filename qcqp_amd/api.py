@@ -13,11 +13,17 @@ What is new (all optional, defaults reproduce the reference's one-point behaviou
 cvxpy is not needed (and not installed here): problems are given as ``qcqp_amd.Problem`` built from
 raw ``(P, q, r, relop)`` arrays -- the data ``get_qcqp_form`` (utilities.py:318-347) would extract.
 """
+import logging
+
 import numpy as np
 
 from . import settings as s
 from .engine import Engine
 from .form import QCQPForm
+
+# module logger (the reference configures the ROOT logger at import, qcqp.py:39, and logs per iteration; this engine
+# never touches the root logger and reports per-run statistics instead: QCQP.last_stats and INFO records here)
+log = logging.getLogger('qcqp_amd')
 
 
 class Variable(object):
@@ -105,8 +111,9 @@ class QCQP(object):
             prob.objective = _Objective('minimize')
             prob._vars = [Variable(form.n, 1)]
         if not hasattr(prob, 'qcqp_form'):
-            raise Exception("QCQP needs a qcqp_amd.Problem (raw (P, q, r, relop) arrays); extracting "
-                            "coefficients from a cvxpy problem is not implemented in this engine.")
+            # a cvxpy problem (cvxpy >= 1.0; the reference needs cvxpy 0.4's QuadCoeffExtractor): get_qcqp_form
+            from .cvxpy_adapter import problem_from_cvxpy
+            prob = problem_from_cvxpy(prob)
         self.prob = prob
         self.qcqp_form = prob.qcqp_form
         self.n = self.qcqp_form.n
@@ -167,19 +174,36 @@ class QCQP(object):
                 if hasattr(self, 'mu'):
                     del self.mu
             if self.sdr_sol is None:
-                # solve_sdr (qcqp.py:72-97): own solver for the unit-diagonal family, on the device
+                # solve_sdr (qcqp.py:72-97): own solvers, heavy products on the device; every solve is certified
+                # (dual slack PSD, feasibility, iteration limit) like the reference checks the solver status (qcqp.py:94-95)
                 from . import sdr as _sdr
-                sol = _sdr.solve_sdr(self.engine, self.qcqp_form, seed=0 if seed is None else seed)
+                sd = 0 if seed is None else seed
+                sol = _sdr.solve_sdr(self.engine, self.qcqp_form, seed=sd)       # x_i^2 == d_i: mixing method, rigorous bound
                 if sol is None and not self.engine.separable:
                     # any QCQP the dense path holds: Burer-Monteiro + augmented Lagrangian, matrices on the device
-                    sol = _sdr.solve_sdr_general(self.engine, self.qcqp_form, seed=0 if seed is None else seed)
+                    X, primal, info = _sdr.solve_sdr_general(self.engine, self.qcqp_form, seed=sd)
+                    if self.n <= 4096:
+                        lmin, S = _sdr.dual_certificate_device(self.engine, info['y'], info['yN'])
+                        _sdr.certify(info, lmin, 1.0 + float(np.max(np.abs(S))), 'solve_sdr (general)')
+                    else:
+                        info['converged'] = None      # slack matrix too large to check on the host
+                    # the dual value -y_N is the bound when the slack is PSD; otherwise only the primal value exists
+                    sol = (X, info['dual_value'] if info.get('converged') else primal, info)
                 if sol is None:
-                    raise Exception("SDR suggest: the built-in SDP solvers cover problems whose constraints are "
-                                    "x_i^2 == d_i (Boolean least squares, MAXCUT, partitioning) and problems whose "
-                                    "constraints couple coordinates (dense path); for other separable "
-                                    "families pass suggest(SDR, X=...) or set qcqp.sdr_sol / qcqp.sdr_bound first.")
+                    fam = _sdr.separable_family(self.qcqp_form)
+                    if fam is not None:
+                        # boxes, discs, annuli, bounds on single coordinates: elementwise constraint operators
+                        X, primal, info = _sdr.solve_sdr_separable(self.engine, self.qcqp_form, seed=sd)
+                        lmin, S = _sdr.dual_slack_separable(self.qcqp_form, fam, info['y'], info['yN'])
+                        _sdr.certify(info, lmin, 1.0 + float(np.max(np.abs(S))), 'solve_sdr (separable)')
+                        sol = (X, info['dual_value'] if info['converged'] else primal, info)
+                if sol is None:
+                    raise Exception("SDR suggest: no built-in SDP solver applies to this problem; pass "
+                                    "suggest(SDR, X=...) or set qcqp.sdr_sol / qcqp.sdr_bound first.")
                 self.sdr_sol, bound, self.sdr_info = sol
                 self.sdr_bound = -bound if self.maximize_flag else bound    # qcqp.py:392-393
+                log.info('solve_sdr: bound %.8g (primal %.8g, converged %s)', bound, self.sdr_info.get('primal', bound),
+                         self.sdr_info.get('converged'))
             if not hasattr(self, 'mu'):
                 X = np.asarray(self.sdr_sol, dtype=np.float64)
                 self.mu = np.asarray(X[:-1, -1]).flatten()
@@ -219,7 +243,12 @@ class QCQP(object):
                 seed = int(np.random.randint(0, 2 ** 31 - 1))
             out = self.engine.cd_run(phase1=phase1, num_iters=num_iters, viol_tol=viol_tol, tol=tol,
                                      seed=seed)
-            self.last_stats = out
+            self.last_stats = dict(out, method=method, num_restarts=len(out['f0']),
+                                   failed_restarts=int(np.count_nonzero(out['status1']) + np.count_nonzero(out['status2'] * (out['status1'] == 0))))
+            log.info('coord_descent: %d restarts, phase-1 sweeps %.2f (max %d), phase-2 sweeps %.2f (max %.1f), accepted '
+                     'updates %.1f, passed the violation gate %d, failed %d', len(out['f0']), out['sweeps1'].mean(),
+                     int(out['sweeps1'].max()), out['visits2'].mean() / self.n, out['visits2'].max() / float(self.n),
+                     out['accepted2'].mean(), int(out['ran_phase2'].sum()), self.last_stats['failed_restarts'])
             return self._publish(out['f0'], out['maxviol'])
         elif method == s.ADMM:
             return self._improve_admm(*args, **kwargs)
@@ -278,7 +307,10 @@ class QCQP(object):
             form.z_solver = np.linalg.inv(2. * (P0 + rho * form.m * np.eye(form.n)))   # qcqp.py:224-227
         out = self.engine.admm_run(rho, form.z_solver, phase1=phase1, num_iters=num_iters, tol=tol,
                                    viol_lim=viol_lim)
-        self.last_stats = out
+        self.last_stats = dict(out, method=s.ADMM, num_restarts=len(out['f0']), rho=rho)
+        log.info('admm: %d restarts, rho %.4g, phase-1 iterations %.1f (max %d), phase-2 iterations %.1f (max %d)',
+                 len(out['f0']), rho, out['iters1'].mean(), int(out['iters1'].max()), out['iters2'].mean(),
+                 int(out['iters2'].max()))
         return self._publish(out['f0'], out['maxviol'])
 
     def improve(self, method, *args, **kwargs):
@@ -291,5 +323,11 @@ class QCQP(object):
         if any([x is None or x.value is None for x in self.prob.variables()]):
             self.suggest()
         for method in methods:
-            f, v = self._improve(method, *args, **kwargs)
+            try:
+                f, v = self._improve(method, *args, **kwargs)
+            except Exception:
+                # the engine's population may have been advanced by the failed call: it no longer mirrors the
+                # variables, the next call starts again from what the variables hold
+                self._resident = False
+                raise
         return (f, v)

@@ -1,23 +1,31 @@
-// Consensus ADMM improve (qcqp.py:195-285) for a whole population, in the eigenbasis of each
-// constraint.
+// Consensus ADMM improve (qcqp.py:195-285) for a whole population, in the eigenbasis of each constraint.
 //
-// The reference keeps, per restart, one copy x_k and one dual u_k of the n-vector for each of the
-// m constraints and per iteration calls onecons_qcqp(z + u_k, f_k) (utilities.py:149-196): rotate
-// into the eigenbasis of P_k (Q_k^T v), solve the secular equation by bisection, rotate back
-// (Q_k xhat).  Here the state lives IN the eigenbasis: uh_k = Q_k^T u_k.  Per iteration
-//     ZQ = [Q_1^T; ...; Q_m^T] Z                  one dgemm, (m n) x n by n x R
-//     per (k, r): vhat = ZQ_k + uh_k; xhat_k = secular(vhat);  uh_k += ZQ_k - xhat_k
-//                 D_k = xhat_k - uh_k                            admm_secular_kernel (hand-written)
-//     S = sum_k x_k - sum_k u_k = [Q_1 ... Q_m] D   one dgemm, n x (m n) by (m n) x R
-//     z = S / m   (phase 1)      z = (2 (P0 + rho m I))^-1 (2 rho S - q0)   (phase 2)
-// which is algebraically the reference's iteration (Q_k orthogonal) without ever materialising
-// x_k or u_k.  The two big products are PLAIN GEMMs and go to rocBLAS; everything with the
-// algorithm's control flow (early exit of feasible inequality constraints, bracket, bisection to
-// 1e-6 on the multiplier, violations, the `better` bookkeeping) is in the kernels below.
+// The reference keeps, per restart, one copy x_k and one dual u_k of the n-vector for each of the m constraints and
+// per iteration calls onecons_qcqp(z + u_k, f_k) (utilities.py:149-196): rotate into the eigenbasis of P_k (Q_k^T v),
+// solve the secular equation by bisection, rotate back (Q_k xhat).  Here the state lives IN the eigenbasis:
+// uh_k = Q_k^T u_k.  Per iteration, for all restarts at once,
+//     ZQ = [Q_1^T; ...; Q_m^T] Z                       gemm_pk_kernel   ((m n) x n by n x R)
+//     per (k, r): vhat = ZQ_k + uh_k; xhat_k = secular(vhat);  uh_k += ZQ_k - xhat_k;  D_k = xhat_k - uh_k
+//                                                      admm_secular_kernel
+//     S = sum_k x_k - sum_k u_k = [Q_1 ... Q_m] D      gemm_pk_kernel   (n x (m n) by (m n) x R, K split over grid.z)
+//     z = S / m  (phase 1)      z = (2 (P0 + rho m I))^-1 (2 rho S - q0)  (phase 2)      admm_zupdate_kernel (+ one gemm)
+//     f0(z), violations, stop rules, `better`         admm_f0_kernel, admm_book_kernel
+// which is algebraically the reference's iteration (Q_k orthogonal) without ever materialising x_k or u_k.  Every
+// product runs on the engine's own fp64 MFMA GEMM (gemm_pk.h): no vendor BLAS on the iteration path.
 //
-// Layout: column-major, one column per restart: Z is n x R (ld n), ZQ / UH are (m n) x R (ld m n),
-// block k of a column is contiguous -> one wave owns one (constraint, restart) pair and streams its
-// n-vector with fully coalesced loads; its share stays in registers across the bisection.
+// LOW-RANK constraints (beamforming: P_k = +-(a a' + b b'), rank 2).  onecons_qcqp moves v = z + u_k only inside
+// span(B_k), B_k = [eigenvectors of the nonzero eigenvalues, the part of q_k outside them]: for lambda_j = 0 and
+// qhat_j = 0 the eigenbasis formula gives xhat_j = vhat_j.  Hence u_k = B_k w_k stays in that span, w_k (rp numbers
+// instead of n) is the whole dual state, and with vhat = B_k^T z + w_k
+//     w_k <- vhat - xhat,        S = m z + sum_k B_k (2 xhat_k - vhat_k - B_k^T z)
+// -- exactly the same iteration with (m rp) x n operators instead of (m n) x n: 0.34 GFLOP per restart-iteration
+// at BASELINE configs[3] become 5 MFLOP.  The secular equation is then solved on the rp (<= 8) coordinates by one
+// thread per (constraint, restart): admm_secular_small_kernel.
+//
+// Layout: everything tile-major like the population (kernels.h): Z [tile][n16][16]; the "hat" arrays ZQ / UH
+// [tile][Mh16][16] with row h = k * rows_k + j (rows_k = n in the full basis, rp in a low-rank basis).  A wave owns one
+// (constraint, restart) pair and keeps its share of the n coordinates in registers across the bisection; its loads
+// are strided by 16 doubles, the 16 restarts of a tile run on neighbouring waves and share the cache lines.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,18 +35,22 @@ namespace qcqpmi {
 
 struct AdmmArgs {
     int64_t n, m, R;
-    const double *lam;    // [m][n] eigenvalues (numpy eigh order)
-    const double *qhat;   // [m][n] Q_k^T q_k
+    int64_t rows_k;       // hat rows per constraint (n or rp)
+    int64_t Mh16;         // m * rows_k padded to a multiple of 16
+    const double *lam;    // [m][rows_k] eigenvalues (numpy eigh order / basis order)
+    const double *qhat;   // [m][rows_k] B_k^T q_k
     const double *rk;     // [m]
     const int *relop;     // [m]
     const double *slo;    // [m] bracket start  max_{lam>0} -1/lam  (or -inf)
     const double *ehi;    // [m] bracket end    min_{lam<0} -1/lam  (or +inf)
-    double *ZQ;           // in: Q_k^T z ; out: D_k = xhat_k - uh_k(new)
-    double *UH;           // in/out
+    double *ZQ;           // in: B_k^T z ; out: the operand of the consensus product
+    double *UH;           // in/out: dual in the basis
     const uint8_t *act;   // [R] restart still iterating
     unsigned long long *mvbits;  // [R] max violation of z over the constraints, as ordered bits
     int first_iter;       // 1: xs = x0, us = 0: the duals are zero and UH is not read
     int viol_only;        // 1: only the violations of z are wanted (no update)
+    int lowrank;          // 1: reduced basis (operand 2 xhat - vhat - zq, dual vhat - xhat)
+    int project_only;     // 1: unit operator onecons_qcqp: out = xhat (no dual, no update)
     double sec_tol;       // 1e-6 (utilities.py:149)
 };
 
@@ -72,17 +84,25 @@ __device__ inline double admm_div(double num, double den) {
     return num * r;
 }
 
-// one wave per (constraint k, restart r); EPL = elements per lane (n <= 64 EPL)
+// tile-major address of hat row h of restart r
+__device__ inline int64_t admm_hat_index(const AdmmArgs &a, int64_t r, int64_t h) {
+    return ((r >> 4) * a.Mh16 + h) * 16 + (r & 15);
+}
+
+// one wave per (constraint k, restart r); EPL = elements per lane (rows_k <= 64 EPL)
 template <int EPL>
 __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (widx >= a.m * a.R) return;
-    const int64_t r = widx / a.m, k = widx % a.m;   // consecutive waves: consecutive constraints of a restart
-    if (!a.act[r]) return;
-    const int64_t n = a.n;
-    double *zq = a.ZQ + (r * a.m + k) * n;
-    double *uh = a.UH + (r * a.m + k) * n;
+    // consecutive waves: the 16 restarts of a tile for one constraint (they share every cache line they touch)
+    const int64_t tile = widx / (16 * a.m), rem = widx % (16 * a.m);
+    const int64_t k = rem / 16, r = tile * 16 + (rem % 16);
+    if (r >= a.R || !a.act[r]) return;
+    const int64_t n = a.rows_k;
+    const int64_t base = admm_hat_index(a, r, k * n);
+    double *zq = a.ZQ + base;
+    double *uh = a.UH + base;
     const double *lm = a.lam + k * n, *qh = a.qhat + k * n;
     const double rk = a.rk[k];
     const int relop = a.relop[k];
@@ -95,8 +115,8 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
         const bool ok = j < n;
         L[e] = ok ? lm[j] : 0.0;
         Qh[e] = ok ? qh[j] : 0.0;
-        Zq[e] = ok ? zq[j] : 0.0;
-        const double u = (ok && !a.first_iter) ? uh[j] : 0.0;
+        Zq[e] = ok ? zq[j * 16] : 0.0;
+        const double u = (ok && !a.first_iter && !a.project_only) ? uh[j * 16] : 0.0;
         V[e] = Zq[e] + u;
         fz_a += L[e] * (Zq[e] * Zq[e]); fz_b += Qh[e] * Zq[e];
         fv_a += L[e] * (V[e] * V[e]);   fv_b += Qh[e] * V[e];
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
         if (__builtin_amdgcn_ballot_w64(L[e] != 0.0) != 0ull) nzmask |= 1u << e;
     // violation of z itself (QuadraticFunction.violation, utilities.py:56-62) in eigen form
     const double fz = wave_sum(fz_a) + wave_sum(fz_b) + rk;
-    if (lane == 0) {
+    if (lane == 0 && a.mvbits) {
         const double viol = (relop == RELOP_EQ) ? fabs(fz) : (fz > 0.0 ? fz : 0.0);
         atomicMax(&a.mvbits[r], (unsigned long long)__double_as_longlong(viol));   // viol >= 0: bit order = value order
     }
@@ -147,30 +167,91 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
         }
         (void)phi((s + e_) / 2.0);
     }
-    // dual update in the eigenbasis and the operand of the consensus product
+    // dual update in the basis and the operand of the consensus product
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
         const int64_t j = lane + 64 * e;
         if (j < n) {
-            const double u_old = a.first_iter ? 0.0 : uh[j];
+            if (a.project_only) { zq[j * 16] = X[e]; continue; }
+            const double u_old = a.first_iter ? 0.0 : uh[j * 16];
             const double u_new = u_old + (Zq[e] - X[e]);   // us[i] += z - xs[i]
-            uh[j] = u_new;
-            zq[j] = X[e] - u_new;                           // x_k - u_k
+            uh[j * 16] = u_new;
+            zq[j * 16] = a.lowrank ? (2.0 * X[e] - V[e] - Zq[e]) : (X[e] - u_new);   // x_k - u_k (minus z in a reduced basis)
         }
     }
 }
 
-// ---- small element-wise / per-restart kernels -------------------------------------------------
-
-// z = S / m for active restarts (admm_phase1, qcqp.py:205)
-__global__ void admm_z_phase1_kernel(double *Z, const double *S, const uint8_t *act, int64_t n, int64_t R,
-                                     double md) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * R) return;
-    if (act[idx / n]) Z[idx] = S[idx] / md;
+// The same for a reduced basis of RP <= 8 coordinates: one THREAD per (constraint, restart).
+template <int RP>
+__global__ __launch_bounds__(256) void admm_secular_small_kernel(AdmmArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // consecutive threads: the 16 restarts of a tile, then the next constraint (coalesced 128-byte rows)
+    const int64_t tile = idx / (16 * a.m), rem = idx % (16 * a.m);
+    const int64_t k = rem / 16, r = tile * 16 + (rem % 16);
+    if (idx >= ((a.R + 15) / 16) * 16 * a.m || r >= a.R || !a.act[r]) return;
+    const int64_t base = admm_hat_index(a, r, k * RP);
+    double *zq = a.ZQ + base;
+    double *uh = a.UH + base;
+    const double *lm = a.lam + k * RP, *qh = a.qhat + k * RP;
+    const double rk = a.rk[k];
+    const int relop = a.relop[k];
+    double L[RP], Qh[RP], V[RP], Zq[RP], X[RP];
+    double fz = 0.0, fv = 0.0;
+#pragma unroll
+    for (int e = 0; e < RP; e++) {
+        L[e] = lm[e]; Qh[e] = qh[e];
+        Zq[e] = zq[e * 16];
+        const double u = (!a.first_iter && !a.project_only) ? uh[e * 16] : 0.0;
+        V[e] = Zq[e] + u;
+        fz += L[e] * (Zq[e] * Zq[e]) + Qh[e] * Zq[e];
+        fv += L[e] * (V[e] * V[e]) + Qh[e] * V[e];
+    }
+    fz += rk; fv += rk;
+    if (a.mvbits) {
+        const double viol = (relop == RELOP_EQ) ? fabs(fz) : (fz > 0.0 ? fz : 0.0);
+        atomicMax(&a.mvbits[r], (unsigned long long)__double_as_longlong(viol));
+    }
+    if (a.viol_only) return;
+    if (relop == RELOP_LE && fv <= 0.0) {
+#pragma unroll
+        for (int e = 0; e < RP; e++) X[e] = V[e];
+    } else {
+        auto phi = [&](double nu) {
+            double p = 0.0;
+#pragma unroll
+            for (int e = 0; e < RP; e++) {
+                const double num = -(nu * Qh[e] - 2.0 * V[e]);
+                const double xh = (L[e] != 0.0) ? admm_div(num, 2.0 * (1.0 + nu * L[e])) : num * 0.5;
+                X[e] = xh;
+                p += L[e] * (xh * xh) + Qh[e] * xh;
+            }
+            return p + rk;
+        };
+        double s = a.slo[k], e_ = a.ehi[k];
+        int guard = 0;
+        if (s == -QM_INF) { s = -1.0; while (phi(s) <= 0.0 && guard++ < 2000) s *= 2.0; }
+        if (e_ == QM_INF) { e_ = 1.0; while (phi(e_) >= 0.0 && guard++ < 4000) e_ *= 2.0; }
+        int steps = 0;
+        while (e_ - s > a.sec_tol && steps++ < 100000) {
+            const double mid = (s + e_) / 2.0;
+            const double p = phi(mid);
+            if (p > 0.0) s = mid;
+            else if (p < 0.0) e_ = mid;
+            else { s = e_ = mid; break; }
+        }
+        (void)phi((s + e_) / 2.0);
+    }
+#pragma unroll
+    for (int e = 0; e < RP; e++) {
+        if (a.project_only) { zq[e * 16] = X[e]; continue; }
+        uh[e * 16] = V[e] - X[e];
+        zq[e * 16] = 2.0 * X[e] - V[e] - Zq[e];
+    }
 }
 
-// dst = alpha * src (element-wise); used for S = m x0 (xs = x0, us = 0)
+// ---- per-tile kernels on the tile-major n x R arrays: 256 threads = 16 restarts x 16 row lanes ----------------------
+
+// dst = alpha * src (whole padded array)
 __global__ void admm_scale_kernel(double *dst, const double *src, int64_t count, double alpha) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < count) dst[idx] = alpha * src[idx];
@@ -178,54 +259,121 @@ __global__ void admm_scale_kernel(double *dst, const double *src, int64_t count,
 
 // dst[:, r] = pick[r] ? a[:, r] : b[:, r]
 __global__ void admm_select_cols_kernel(double *dst, const double *a, const double *b, const uint8_t *pick,
-                                        int64_t n, int64_t R) {
+                                        int64_t n16, int64_t R, int64_t count) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * R) return;
-    dst[idx] = pick[idx / n] ? a[idx] : b[idx];
+    if (idx >= count) return;
+    const int64_t r = (idx / (n16 * 16)) * 16 + (idx & 15);
+    dst[idx] = (r < R && pick[r]) ? a[idx] : b[idx];
 }
 
-// rhs = 2 rho S - q0 (qcqp.py:231)
-__global__ void admm_rhs_kernel(double *RHS, const double *S, const double *q0, int64_t n, int64_t R, double rho) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * R) return;
-    RHS[idx] = 2.0 * rho * S[idx] - q0[idx % n];
-}
+struct AdmmZArgs {
+    int64_t n, n16, R;
+    int phase;            // 1: z = S / m ; 2: rhs = 2 rho S - q0, then z = dinv * rhs (diagonal) or rhs -> Y (dense solve follows)
+    int zs;               // partial planes of S = W D to be summed (fixed order)
+    int64_t plane;        // doubles per plane
+    int add_mz;           // reduced basis: S = m z + W D
+    double m, rho;
+    const double *Sp;     // [zs][tile][n16][16]
+    double *S;            // summed S (kept: phase switches reuse it)
+    double *Z;            // current z (updated in place for active restarts when the solve is diagonal / phase 1)
+    double *Y;            // phase 2, dense solve: rhs
+    const double *q0;     // [n16]
+    const double *dinv;   // [n16] 1 / (2 (P0_ii + rho m)) for a diagonal P0, or nullptr
+    const double *Zlast;  // phase 2
+    double *dist2;        // [R] ||Zlast - Znew||^2 (phase 2, diagonal solve)
+    const uint8_t *act;
+};
 
-// Znew -> Z for active restarts, and ||Zlast - Znew||^2 per restart (one block per restart)
-__global__ __launch_bounds__(256) void admm_take_z_kernel(double *Z, const double *Znew, const double *Zlast,
-                                                           const uint8_t *act, double *dist2, int64_t n) {
+// one workgroup per tile: sums the planes of the consensus product and performs the z-update that needs no solve
+__global__ __launch_bounds__(256) void admm_zupdate_kernel(AdmmZArgs a) {
     __shared__ double red[256];
-    const int64_t r = blockIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
+    const int64_t r = tile * 16 + rr;
+    const bool on = r < a.R && a.act[r];
     double acc = 0.0;
-    if (act[r]) {
-        for (int64_t j = threadIdx.x; j < n; j += 256) {
-            const double zn = Znew[r * n + j];
-            const double d = Zlast[r * n + j] - zn;
-            acc += d * d;
-            Z[r * n + j] = zn;
+    for (int64_t j = jl; j < a.n16; j += 16) {
+        const int64_t idx = (tile * a.n16 + j) * 16 + rr;
+        double s = a.Sp[idx];
+        for (int z = 1; z < a.zs; z++) s += a.Sp[(int64_t)z * a.plane + idx];
+        if (a.add_mz) s += a.m * a.Z[idx];
+        a.S[idx] = s;
+        if (!on || j >= a.n) continue;
+        if (a.phase == 1) {
+            a.Z[idx] = s / a.m;                              // qcqp.py:205
+        } else {
+            const double rhs = 2.0 * a.rho * s - a.q0[j];    // qcqp.py:231
+            if (a.dinv) {
+                const double zn = a.dinv[j] * rhs;
+                const double d = a.Zlast[idx] - zn;
+                acc += d * d;
+                a.Z[idx] = zn;
+            } else {
+                a.Y[idx] = rhs;
+            }
         }
+    }
+    if (a.phase == 2 && a.dinv) {
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            double s = 0.0;
+            for (int g = 0; g < 16; g++) s += red[g * 16 + threadIdx.x];
+            if (tile * 16 + threadIdx.x < a.R) a.dist2[tile * 16 + threadIdx.x] = s;
+        }
+    }
+}
+
+// dense solve: Znew = Minv rhs came out of the GEMM; Z <- Znew for active restarts, ||Zlast - Znew||^2 per restart
+__global__ __launch_bounds__(256) void admm_take_z_kernel(double *Z, const double *Znew, const double *Zlast,
+                                                           const uint8_t *act, double *dist2, int64_t n, int64_t n16, int64_t R) {
+    __shared__ double red[256];
+    const int64_t tile = blockIdx.x;
+    const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
+    const int64_t r = tile * 16 + rr;
+    const bool on = r < R && act[r];
+    double acc = 0.0;
+    if (on)
+        for (int64_t j = jl; j < n; j += 16) {
+            const int64_t idx = (tile * n16 + j) * 16 + rr;
+            const double zn = Znew[idx];
+            const double d = Zlast[idx] - zn;
+            acc += d * d;
+            Z[idx] = zn;
+        }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double s = 0.0;
+        for (int g = 0; g < 16; g++) s += red[g * 16 + threadIdx.x];
+        if (tile * 16 + threadIdx.x < R) dist2[tile * 16 + threadIdx.x] = s;
+    }
+}
+
+// f0(z) = z.(Y + q0) + r0 with Y = P0 z from the GEMM, or Y_j = d_j z_j for a diagonal P0 (pdiag != nullptr)
+__global__ __launch_bounds__(256) void admm_f0_kernel(const double *Z, const double *Y, const double *pdiag, const double *q0,
+                                                       double r0, double *f0, int64_t n, int64_t n16, int64_t R) {
+    __shared__ double red[256];
+    const int64_t tile = blockIdx.x;
+    const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
+    double acc = 0.0;
+    for (int64_t j = jl; j < n; j += 16) {
+        const int64_t idx = (tile * n16 + j) * 16 + rr;
+        const double z = Z[idx];
+        const double y = pdiag ? pdiag[j] * z : Y[idx];
+        acc += (y + q0[j]) * z;
     }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) dist2[r] = red[0];
-}
-
-// f0(z) = z.(Y + q0) + r0 with Y = P0 z (one block per restart)
-__global__ __launch_bounds__(256) void admm_f0_kernel(const double *Z, const double *Y, const double *q0, double r0,
-                                                       double *f0, int64_t n) {
-    __shared__ double red[256];
-    const int64_t r = blockIdx.x;
-    double acc = 0.0;
-    for (int64_t j = threadIdx.x; j < n; j += 256) acc += (Y[r * n + j] + q0[j]) * Z[r * n + j];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) f0[r] = red[0] + r0;
+    if (threadIdx.x < 16) {
+        double s = 0.0;
+        for (int g = 0; g < 16; g++) s += red[g * 16 + threadIdx.x];
+        if (tile * 16 + threadIdx.x < R) f0[tile * 16 + threadIdx.x] = s + r0;
+    }
 }
 
 struct AdmmBook {
-    int64_t n, R;
+    int64_t n, n16, R;
     int phase;                 // 1 or 2
     double tol, viol_lim;
     int have_last;             // phase 2: a previous z exists
@@ -239,48 +387,85 @@ struct AdmmBook {
     int *nactive;
 };
 
-// per-restart control flow of admm_phase1 (qcqp.py:202-204) / admm_phase2 (qcqp.py:240-249);
-// one block per restart
+// per-restart control flow of admm_phase1 (qcqp.py:202-204) / admm_phase2 (qcqp.py:240-249); one workgroup per tile
 __global__ __launch_bounds__(256) void admm_book_kernel(AdmmBook b) {
-    const int64_t r = blockIdx.x;
-    if (!b.act[r]) return;
-    __shared__ int take;
-    const double mv = __longlong_as_double((long long)b.mvbits[r]);
-    if (threadIdx.x == 0) {
-        take = 0;
-        bool stop = false;
-        if (b.phase == 1) {
-            if (mv < b.tol) stop = true;                       // qcqp.py:203
-        } else {
-            if (b.have_last && sqrt(b.dist2[r]) < b.tol) stop = true;       // qcqp.py:241-242 (before bestx)
-            else if (mv > b.viol_lim) stop = true;                          // qcqp.py:248
-            else {
-                // bestx = better(z, bestx) (utilities.py:135-146): first argument wins only if strictly better
-                const long long v1 = (long long)(mv / 1e-4), v2 = (long long)(b.best_mv[r] / 1e-4);
-                const double f1 = b.f0z[r], f2 = b.best_f0[r];
-                if (v1 < v2 || (v1 == v2 && f1 < f2)) { take = 1; b.best_f0[r] = f1; b.best_mv[r] = mv; }
+    __shared__ int take[16], live[16];
+    const int64_t tile = blockIdx.x;
+    const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
+    if (threadIdx.x < 16) {
+        const int64_t r = tile * 16 + threadIdx.x;
+        int tk = 0, lv = 0;
+        if (r < b.R && b.act[r]) {
+            const double mv = __longlong_as_double((long long)b.mvbits[r]);
+            bool stop = false;
+            if (b.phase == 1) {
+                if (mv < b.tol) stop = true;                       // qcqp.py:203
+            } else {
+                if (b.have_last && sqrt(b.dist2[r]) < b.tol) stop = true;       // qcqp.py:241-242 (before bestx)
+                else if (mv > b.viol_lim) stop = true;                          // qcqp.py:248
+                else {
+                    // bestx = better(z, bestx) (utilities.py:135-146): first argument wins only if strictly better
+                    const long long v1 = (long long)(mv / 1e-4), v2 = (long long)(b.best_mv[r] / 1e-4);
+                    const double f1 = b.f0z[r], f2 = b.best_f0[r];
+                    if (v1 < v2 || (v1 == v2 && f1 < f2)) { tk = 1; b.best_f0[r] = f1; b.best_mv[r] = mv; }
+                }
             }
+            if (stop) b.act[r] = 0;
+            else { b.iters[r]++; atomicAdd(b.nactive, 1); }
+            lv = 1;
         }
-        if (stop) b.act[r] = 0;
-        else { b.iters[r]++; atomicAdd(b.nactive, 1); }
+        take[threadIdx.x] = tk; live[threadIdx.x] = lv;
     }
     __syncthreads();
-    if (b.phase == 2) {
-        for (int64_t j = threadIdx.x; j < b.n; j += 256) {
-            const double z = b.Z[r * b.n + j];
-            b.Zlast[r * b.n + j] = z;
-            if (take) b.BEST[r * b.n + j] = z;
+    if (b.phase == 2 && live[rr]) {
+        const bool tk = take[rr] != 0;
+        for (int64_t j = jl; j < b.n; j += 16) {
+            const int64_t idx = (tile * b.n16 + j) * 16 + rr;
+            const double z = b.Z[idx];
+            b.Zlast[idx] = z;
+            if (tk) b.BEST[idx] = z;
         }
     }
 }
 
-// S = sum_k C_k over the m batched products, fixed order
-__global__ void admm_sum_k_kernel(const double *__restrict__ Cb, double *__restrict__ S, int m, int64_t tot) {
+// onecons unit operator: keep the hat rows of constraint k only.  Full basis: zero the others (x = Q_k xhat).  Reduced
+// basis: rows of k become xhat - B_k^T z, the others zero (x = z + B_k (xhat - B_k^T z)).
+__global__ void admm_onecons_mask_kernel(double *ZQ, const double *ZB, int64_t Mh16, int64_t rows, int64_t k, int64_t count, int lowrank) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= tot) return;
-    double s = Cb[idx];
-    for (int k = 1; k < m; k++) s += Cb[(int64_t)k * tot + idx];
-    S[idx] = s;
+    if (idx >= count) return;
+    const int64_t h = (idx / 16) % Mh16;
+    const bool mine = h >= k * rows && h < (k + 1) * rows;
+    ZQ[idx] = mine ? (lowrank ? ZQ[idx] - ZB[idx] : ZQ[idx]) : 0.0;
+}
+
+// y += x
+__global__ void admm_axpy_kernel(double *y, const double *x, int64_t count) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) y[idx] += x[idx];
+}
+
+// out[k][i][c] = sum_j P_k[i][j] Vin[(shared ? 0 : k)][j][c]   (p columns, row-major n x p blocks): the two passes over the
+// constraint matrices of the rank-revealing setup (range probe Y = P Omega, then Z = P Q).  One workgroup per
+// (constraint, 16 rows): thread (row, column).
+__global__ __launch_bounds__(256) void admm_apply_constraints_kernel(const double *__restrict__ gP, const double *__restrict__ Vin,
+                                                                      double *__restrict__ out, int64_t n, int p, int shared) {
+    const int64_t k = blockIdx.y, i0 = (int64_t)blockIdx.x * 16;
+    const int c = threadIdx.x & 15, il = threadIdx.x >> 4;
+    const int64_t i = i0 + il;
+    if (i >= n) return;
+    const double *Pr = gP + (k * n + i) * n;
+    const double *V = Vin + (shared ? 0 : k * n * p);
+    for (int c0 = 0; c0 < p; c0 += 16) {
+        if (c0 + c >= p) continue;
+        double s0 = 0.0, s1 = 0.0;
+        int64_t j = 0;
+        for (; j + 1 < n; j += 2) {
+            s0 = __builtin_fma(Pr[j], V[j * p + c0 + c], s0);
+            s1 = __builtin_fma(Pr[j + 1], V[(j + 1) * p + c0 + c], s1);
+        }
+        if (j < n) s0 = __builtin_fma(Pr[j], V[j * p + c0 + c], s0);
+        out[(k * n + i) * p + c0 + c] = s0 + s1;
+    }
 }
 
 }  // namespace qcqpmi

@@ -15,6 +15,7 @@
 #include "../../include/qcqp_mi.h"
 #include "kernels.hip"
 #include "admm.h"
+#include "gemm_pk.h"
 #include "cd_general.h"
 #include "cd_dense.h"
 #include "sdr_solve.h"
@@ -109,10 +110,15 @@ struct qcqpmi_ctx {
     // SDR factor
     double *d_Fpack = nullptr, *d_Frow = nullptr, *d_mu = nullptr;
     Timer timers[5];
-    // ADMM: stacked eigenvectors W = [Q_1 ... Q_m] (n x mn col-major), eigenvalues, Q^T q, brackets
-    double *ad_W = nullptr, *ad_lam = nullptr, *ad_qhat = nullptr, *ad_rk = nullptr, *ad_slo = nullptr, *ad_ehi = nullptr, *ad_Minv = nullptr;
+    // ADMM: the stacked bases B = [B_1 ... B_m] packed for the two products (gemm_pk.h), eigenvalues, B^T q, brackets
+    double *ad_WTpk = nullptr, *ad_Wpk = nullptr, *ad_lam = nullptr, *ad_qhat = nullptr, *ad_rk = nullptr, *ad_slo = nullptr, *ad_ehi = nullptr;
+    double *ad_Minvpk = nullptr;
     int *ad_relop = nullptr;
-    void *rb_handle = nullptr;
+    int64_t ad_rows = 0, ad_Mh16 = 0;   // hat rows per constraint (n, or rp of a reduced basis); m * rows padded to 16
+    int ad_lowrank = 0;
+    void *rb_handle = nullptr;          // rocBLAS handle: only the rocSOLVER setup path needs one
+    bool p0_diag = false;               // P0 has no off-diagonal entries (z-update and f0 need no product then)
+    std::vector<double> p0_diag_host;
     // outputs of a run packed into one device buffer, copied with ONE transfer into pinned host memory
     char *d_out = nullptr, *h_out = nullptr;
     int64_t out_cap = 0;
@@ -371,6 +377,30 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
         return 0;
     }
     const DevProblem &dp = c->dp;
+    // second-generation role-split kernel (cd_phase2_q.h): one mirrored equality class, positive diagonal, n a
+    // multiple of 16, the tile resident in LDS -- the Boolean least squares family of the headline benchmark
+    if (MAXC == 1 && c->K == 1 && c->objclass == 1 && c->symcls && c->n % 16 == 0 && !c->force_generic && !(c->dbg & 64)) {
+        const size_t q_lds = ((size_t)RQ_LDS_COMMON + (size_t)c->n16 * 16) * sizeof(double);
+        const int NBq = (int)(c->n16 / 16);
+        int cs = (c->dbg & 128) ? ((c->dbg >> 8) & 7) : 4;     // debug knob: blocks of the contraction the chain wave multiplies
+        cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
+        if (cs >= NBq) cs = 0;
+        cs &= ~1;
+        if (q_lds <= 160 * 1024 && NBq - cs <= RQ_NMW * RQ_PFU) {
+            used_lds = true;
+            const bool prof_ = a1.prof != nullptr;
+            auto k = cd_phase2_q_kernel<4, false>;
+            if (prof_) k = cs == 0 ? cd_phase2_q_kernel<0, true> : cs == 2 ? cd_phase2_q_kernel<2, true> : cs == 4 ? cd_phase2_q_kernel<4, true> : cd_phase2_q_kernel<6, true>;
+            else k = cs == 0 ? cd_phase2_q_kernel<0, false> : cs == 2 ? cd_phase2_q_kernel<2, false> : cs == 4 ? cd_phase2_q_kernel<4, false> : cd_phase2_q_kernel<6, false>;
+            HIPCHK(c, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds));
+            tic(c, 2);
+            hipLaunchKernelGGL(k, grid, dim3(512), q_lds, c->stream, a1, dp.Apack, dp.Apack2, dp.P0, dp.q0, dp.rcp2d);
+            toc(c, 2);
+            HIPCHK(c, hipGetLastError());
+            if (used_rs) *used_rs = true;
+            return 0;
+        }
+    }
     // role-split pipelined kernel for the single-class Boolean / box families
     if (MAXC == 1 && c->K == 1 && (c->objclass == 1 || c->objclass == 2) && !c->force_generic) {
         const size_t rs_common = (size_t)(2 * 6 * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8) * sizeof(double);
@@ -673,6 +703,13 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             (void)hipFree(tmp);
             if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "finalize: generated objective: %s", hipGetErrorString(e));
+        }
+        {
+            bool dg = true;
+            for (size_t e = 0; e < h.cv.size() && dg; e++) dg = h.ci[e] == h.cj[e];
+            c->p0_diag = dg && !h.gen;
+            c->p0_diag_host.assign((size_t)n, 0.0);
+            for (int64_t i = 0; i < n; i++) c->p0_diag_host[(size_t)i] = P[(size_t)i * n16 + i];
         }
         if ((rc = prob_upload(c, &dp.P0, P))) return rc;
         if ((rc = prob_upload(c, &dp.q0, q))) return rc;

@@ -1,0 +1,582 @@
+// Coordinate descent phase 2 (qcqp.py:152-178): role-split pipelined kernel, second generation, for the
+// family the headline benchmark runs -- every coordinate carries the one constraint  p x_i^2 + r == 0
+// (single class, feasible sets mirrored about 0), every P0[i,i] > 0, n a multiple of 16 and the tile of
+// 16 restarts resident in LDS (n <= 1024).  Everything else stays on cd_phase2_rs.h / cd_phase2.h.
+//
+// Same blocked Gauss-Seidel and the same decisions as cd_phase2_rs.h (vertex of the scalar objective, clamp
+// onto the mirrored band, |move| > tol, near-tie detection with replay in the reference's arithmetic); what
+// changed is how the work is laid out:
+//
+//   chain wave (wave 0, alone on its SIMD)
+//     * QUAD layout: lane 4 r + g carries restart r and OWNS the columns c = 4 v + g (v = 0..3) of the
+//       block: at step c the owner quad-lane decides, the move travels to the other three lanes of the
+//       quad with two v_mov_b32 quad_perm DPPs, and every lane folds it into the <= 4 columns it owns
+//       (the first generation carried each restart 4x redundantly: 120 fmas and ~75 LDS broadcast reads
+//       per block and lane; here 40 fmas and 24 reads).  The matrix-core accumulator layout
+//       (row = (l >> 4) + 4 v) is the same column assignment, so the partial tiles are stored [v][4 r + g]
+//       and every lane sums exactly the 4 entries it needs: no G tile round trip through LDS.
+//     * bookkeeping that does not feed the next step -- objective tracking, near-tie test, move mask --
+//       is computed once per block from the values the lane still holds (G of a finished column is never
+//       updated again: the masked diagonal block has zeros there).
+//     * the 4 k-steps of the block just rewritten (the "fix-up") run BEFORE the barrier, straight after the
+//       commit of the block, together with the chain wave's own share of the next product (RQ_CS blocks
+//       of the contraction): the chain is short enough now that its SIMD has matrix time to spare.
+//   mfma waves (1, 2, 3, 5, 6, 7; two per SIMD)
+//     * STATIC ownership of the contraction: wave mw owns a fixed range of blocks of 16 coordinates, its
+//       B operands (the X rows of those blocks) stay in registers for the whole kernel; after a barrier
+//       only the wave that owns the block the chain has just rewritten re-reads 4 values from LDS
+//       (first generation: 44 LDS reads per wave and block before the first MFMA could issue).
+//     * A fragments as before: register resident, refilled in place one block ahead with unconditional
+//       16-byte loads from the pair-packed copy of P0; the block the chain is rewriting is skipped.
+//
+//     * CYCLIC ownership instead of contiguous ranges, see below.
+//   synchronisation
+//     * NO s_barrier inside the block loop.  Producer / consumer counters in LDS (RQ_PARTS, RQ_CONS, RQ_COMMIT,
+//       RQ_STOP): the chain waits for the six partial tiles of its block, an mfma wave waits for the chain's commit
+//       only when it owns the block the chain has just rewritten, and for the release of the slots it is about to
+//       overwrite.  With a barrier both waves of a SIMD did their store / wait / stage phases at the same time and
+//       the matrix pipe idled ~1.4 k of every 7.5 k cycles; free-running waves drift apart and cover each other.
+//       Partial tiles and staged operands are double-buffered by block parity.
+#pragma once
+#include <stdint.h>
+#include "cd_phase2_rs.h"
+
+namespace qcqpmi {
+
+constexpr int RQ_NMW = 6;     // mfma waves
+constexpr int RQ_PFU = 11;    // blocks an mfma wave can own (A and B operands in registers)
+constexpr int RQ_CSMAX = 6;   // blocks the chain wave can own
+
+// LDS doubles besides the X tile
+constexpr int RQ_LDS_COMMON = 2 * RQ_NMW * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8;
+
+template <int CTRL>
+__device__ __attribute__((always_inline)) inline double rq_quad_bcast(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __attribute__((always_inline)) inline double rq_quad_sum(double v) {
+    const double a = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xf, 0xf, true),
+                                      __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    const double s = v + a;
+    const double b = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(s), 0x4E, 0xf, 0xf, true),
+                                      __builtin_amdgcn_mov_dpp(__double2loint(s), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    return s + b;
+}
+
+__device__ __attribute__((always_inline)) inline unsigned rq_quad_or(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+    v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
+    return v;
+}
+
+// Ownership of the contraction: the chain wave multiplies the last CS blocks of 16 coordinates itself, the others are
+// dealt cyclically to the six mfma waves: block j < NB - CS belongs to wave j % 6, register slot j / 6.  (Cyclic: the
+// wave that owns the block the chain has just rewritten must wait for the commit; dealing the blocks round robin makes
+// that a different wave every block and keeps the two waves of a SIMD out of phase.)
+struct RqOwn {
+    int first;    // first owned block
+    int stride;   // distance between owned blocks
+    int nu;       // number of owned blocks
+    int NB;
+};
+
+__device__ __attribute__((always_inline)) inline RqOwn rq_own(int NB, int CS, int mw) {
+    RqOwn o;
+    const int cs = CS < NB ? CS : 0;
+    const int rest = NB - cs;
+    o.NB = NB;
+    if (mw >= RQ_NMW) { o.first = rest; o.stride = 1; o.nu = cs; }
+    else { o.first = mw; o.stride = RQ_NMW; o.nu = mw < rest ? (rest - mw + RQ_NMW - 1) / RQ_NMW : 0; }
+    return o;
+}
+
+// block held by register slot U (clamped to a valid block: slots past the owned ones are loaded, never multiplied)
+__device__ __attribute__((always_inline)) inline int rq_block(const RqOwn &o, int U) {
+    const int bb = o.first + U * o.stride;
+    return bb < o.NB ? bb : o.NB - 1;
+}
+
+// slot of block j, or -1 if the wave does not own it
+__device__ __attribute__((always_inline)) inline int rq_slot(const RqOwn &o, int j) {
+    const int d = j - o.first;
+    if (d < 0 || d % o.stride != 0) return -1;
+    const int U = d / o.stride;
+    return U < o.nu ? U : -1;
+}
+
+// A fragments (pair-packed copy: k-steps 2 kk2, 2 kk2 + 1 of block row bn at ((bn KS/2 + kk2) 64 + lane) 2) of the
+// owned blocks for the product of block row bn -> registers
+template <int NU>
+__device__ __attribute__((always_inline)) inline void rq_load_A(v2d_ (&ar)[2 * NU], const double *__restrict__ Apack2, int KS, const RqOwn &o, int lane, int bn) {
+#pragma unroll
+    for (int U = 0; U < NU; U++) {
+        const v2d_ *ap = reinterpret_cast<const v2d_ *>(Apack2) + ((int64_t)bn * (KS / 2) + 2 * rq_block(o, U)) * 64;
+        ar[2 * U] = ap[(unsigned)lane];
+        ar[2 * U + 1] = ap[64u + (unsigned)lane];
+    }
+}
+
+// product of block row bn over the owned blocks except slot `hs` (the block the chain is rewriting, or -1); every
+// fragment register is refilled right after the MFMAs that consumed it with the fragment of block row bn2
+template <int NU>
+__device__ __attribute__((always_inline)) inline v4d_ rq_product(v2d_ (&ar)[2 * NU], const double (&bq)[4 * NU], const double *__restrict__ Apack2, int KS,
+                                  const RqOwn &o, int lane, int hs, int bn2, v4d_ acc0) {
+    v4d_ acc = acc0, acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = acc1, acc3 = acc1;
+#pragma unroll
+    for (int U = 0; U < NU; U++) {
+        if (U < o.nu && U != hs) {   // wave-uniform
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U][0], bq[4 * U], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U][1], bq[4 * U + 1], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U + 1][0], bq[4 * U + 2], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U + 1][1], bq[4 * U + 3], acc3, 0, 0, 0);
+        }
+        {   // unconditional refill: s_waitcnt can count the loads
+            const v2d_ *ap = reinterpret_cast<const v2d_ *>(Apack2) + ((int64_t)bn2 * (KS / 2) + 2 * rq_block(o, U)) * 64;
+            ar[2 * U] = ap[(unsigned)lane];
+            ar[2 * U + 1] = ap[64u + (unsigned)lane];
+        }
+    }
+    return (acc + acc1) + (acc2 + acc3);
+}
+
+// B operands of the owned blocks from the X tile in LDS (MFMA B layout: lane l <- X[4 kk + (l >> 4)][l & 15])
+template <int NU>
+__device__ __attribute__((always_inline)) inline void rq_load_B(double (&bq)[4 * NU], const double *Xs, const RqOwn &o, int lane) {
+    const int xoff = (lane >> 4) * 16 + (lane & 15);
+#pragma unroll
+    for (int U = 0; U < NU; U++) {
+        const int bb = rq_block(o, U);
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[4 * U + q] = Xs[(4 * bb + q) * 64 + xoff];
+    }
+}
+
+// the block in slot `us` has been rewritten by the chain: refresh those 4 operands
+template <int NU>
+__device__ __attribute__((always_inline)) inline void rq_refresh_B(double (&bq)[4 * NU], const double *Xs, const RqOwn &o, int lane, int us) {
+    const int xoff = (lane >> 4) * 16 + (lane & 15);
+    const int bb = rq_block(o, us < 0 ? 0 : us);
+    const double n0 = Xs[(4 * bb + 0) * 64 + xoff], n1 = Xs[(4 * bb + 1) * 64 + xoff];
+    const double n2 = Xs[(4 * bb + 2) * 64 + xoff], n3 = Xs[(4 * bb + 3) * 64 + xoff];
+#pragma unroll
+    for (int U = 0; U < NU; U++) {
+        const bool hit = (U == us);      // wave-uniform
+        bq[4 * U + 0] = hit ? n0 : bq[4 * U + 0];
+        bq[4 * U + 1] = hit ? n1 : bq[4 * U + 1];
+        bq[4 * U + 2] = hit ? n2 : bq[4 * U + 2];
+        bq[4 * U + 3] = hit ? n3 : bq[4 * U + 3];
+    }
+}
+
+// ---- synchronisation words in LDS (no s_barrier inside the block loop: waves only wait for what they consume)
+//   [0] cons    = g + 1 once the chain has read the partial tiles of interval g
+//   [1] commit  = g + 1 once the chain has committed the block of interval g to the X tile (and is done with its staged operands)
+//   [2] stop    != 0: leave the loop
+//   [4 + w]     iterations published by mfma wave w (its partial tile and its share of the staged operands are stored);
+//               one word PER WAVE: a shared counter would let a wave that runs ahead stand in for one that lags
+// LDS operations of one wave complete in program order, so "data, then flag" needs no wait on the producer side and
+// "flag, then data" none on the consumer side.
+enum { RQ_CONS = 0, RQ_COMMIT = 1, RQ_STOP = 2, RQ_PARTS = 4 };
+
+typedef int rq_i4 __attribute__((ext_vector_type(4)));
+// explicit LDS address space: a volatile access through a generic pointer becomes a FLAT instruction (vmcnt + lgkmcnt,
+// not ordered with the wave's DS queue) -- the protocol needs plain ds_read / ds_write
+typedef __attribute__((address_space(3))) int rq_lds_int;
+typedef __attribute__((address_space(3))) rq_i4 rq_lds_i4;
+
+__device__ __attribute__((always_inline)) inline rq_i4 rq_sync_read(rq_lds_int *sy) {
+    rq_i4 v = *(volatile rq_lds_i4 *)sy;                     // one ds_read_b128
+    asm volatile("" ::: "memory");                           // nothing that follows may be read before the flags
+    v[0] = __builtin_amdgcn_readfirstlane(v[0]); v[1] = __builtin_amdgcn_readfirstlane(v[1]);
+    v[2] = __builtin_amdgcn_readfirstlane(v[2]); v[3] = __builtin_amdgcn_readfirstlane(v[3]);
+    return v;
+}
+
+__device__ __attribute__((always_inline)) inline void rq_sync_write(rq_lds_int *sy, int which, int value, int lane) {
+    asm volatile("" ::: "memory");                           // data first, then the flag (DS queue is in order per wave)
+    if (lane == 0) *(volatile rq_lds_int *)(sy + which) = value;
+    asm volatile("" ::: "memory");
+}
+
+// CS: blocks of the contraction the chain wave multiplies itself (0..RQ_CSMAX)
+template <int CS, bool PROF>
+__global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double *__restrict__ Apack,
+                                                          const double *__restrict__ Apack2,
+                                                          const double *__restrict__ P0,
+                                                          const double *__restrict__ q0,
+                                                          const double *__restrict__ rcp2d) {
+    constexpr int MAXC = 1;
+    constexpr int CSU = CS > 0 ? CS : 1;
+    extern __shared__ double smem[];
+    const DevProblem &P = a.P;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tile = blockIdx.x;
+    const int64_t n16 = P.n16;
+    const int NB = (int)P.NB, KS = (int)P.KS;
+    double *Xg = a.X + tile * n16 * 16;
+    // ---- dynamic LDS carve-up
+    double *sp = smem;
+    double *Xs = sp; sp += n16 * 16;
+    double *part2 = sp; sp += 2 * RQ_NMW * 256;   // partial G tiles of the mfma waves, [v][4 r + g], double-buffered
+    double *fixp = sp; sp += 256;                  // the chain wave's own plane (fix-up + its share); the generic path's G tile
+    double *DU2 = sp; sp += 2 * 256;               // strictly upper triangle of the diagonal block (zeros elsewhere), by parity
+    double *dg2 = sp; sp += 2 * 16;                // P0[i,i]
+    double *hqb2 = sp; sp += 2 * 16;               // q0 / 2
+    double *rtb2 = sp; sp += 2 * 16;               // 1 / P0[i,i]
+    double *slk = sp; sp += 16;
+    SetTable<MAXC> TC;
+    TC.slots = 16;
+    TC.lo = sp; sp += 2 * 16;
+    TC.hi = sp; sp += 2 * 16;
+    TC.n = (int *)sp; sp += 8;
+    TC.slow = (int *)sp; sp += 8;
+    rq_lds_int *sy = (rq_lds_int *)(int *)sp;      // synchronisation words (16-byte aligned: sp advances in doubles from a 16-byte base)
+
+    for (int64_t idx = tid; idx < n16 * 16; idx += 512) Xs[idx] = Xg[idx];
+    if (tid < 16) {
+        const int64_t g = tile * 16 + tid;
+        slk[tid] = (g < a.R) ? a.slack[g] : 0.0;
+    }
+    if (tid < 16) *(volatile rq_lds_int *)(sy + tid) = 0;
+    __syncthreads();
+    if (tid < 16) {
+        FeasSet<MAXC> C;
+        compute_set<MAXC>(P, P.krep[0], slk[tid], C);
+        store_set<MAXC>(TC, tid, C);
+    }
+    __syncthreads();
+
+    const int64_t gmax = a.num_iters * (int64_t)NB;
+
+    const bool lockstep = (a.dbg & 1) != 0;        // debug: one s_barrier per block on top of the flags
+    if (wave == 4) {
+        // idle: wave 4 lands on the chain wave's SIMD and stays out of its way (it only joins the final barrier)
+        if (lockstep)
+            for (;;) { __syncthreads(); if (rq_sync_read(sy)[RQ_STOP]) break; }
+    } else if (wave != 0) {
+        // =========================================================================== mfma role
+        const int mw = wave < 4 ? wave - 1 : wave - 2;
+        const int st = wave < 4 ? tid - 64 : tid - 128;   // 0..383: staging slot of this thread
+        const RqOwn own = rq_own(NB, CS, mw);
+        v2d_ arP[2 * RQ_PFU];
+        double bq[4 * RQ_PFU];
+        long long qc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
+#define QTICK(slot) if (PROF && a.prof && wave == 2) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); qc[slot] += now_ - tq; tq = now_; }
+        // staging of the small operands of a block: strictly upper triangle of the diagonal block (256 entries over
+        // the first 256 staging threads), diagonal, q/2 and 1/P_ii of its 16 coordinates (threads 0..15); wave mw == 0
+        // also adds q/2 to its tile so that the summed tile is G + q/2 without a separate pass.
+        double st_d0 = 0.0, st_q = 0.0, st_r = 0.0, st_dg = 0.0;
+        double hqv[4] = {0.0, 0.0, 0.0, 0.0};
+        auto stage_load = [&](int bn) {
+            if (st < 256) st_d0 = P0[(16 * (int64_t)bn + (st >> 4)) * n16 + 16 * bn + (st & 15)];
+            if (st < 16) { st_q = q0[16 * (int64_t)bn + st]; st_r = rcp2d[16 * (int64_t)bn + st];
+                           st_dg = P0[(16 * (int64_t)bn + st) * n16 + 16 * bn + st]; }
+            if (mw == 0) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) hqv[v] = q0[16 * (int64_t)bn + (lane >> 4) + 4 * v];
+            }
+        };
+        auto stage_store = [&](int buf) {
+            if (st < 256) DU2[buf * 256 + st] = ((st & 15) > (st >> 4)) ? st_d0 : 0.0;
+            if (st < 16) { hqb2[buf * 16 + st] = 0.5 * st_q; rtb2[buf * 16 + st] = st_r + st_r; dg2[buf * 16 + st] = st_dg; }
+        };
+        auto store_part = [&](v4d_ acc, int buf) {
+            double *part = part2 + buf * RQ_NMW * 256 + mw * 256;
+#pragma unroll
+            for (int v = 0; v < 4; v++) part[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v] + 0.5 * hqv[v];   // hqv == 0 unless mw == 0
+        };
+        int published = 0;
+        auto publish = [&]() { rq_sync_write(sy, RQ_PARTS + mw, ++published, lane); };
+        // prologue: full product of block row 0 (no hole); the fragments of iteration 0's product (row 1 % NB) follow
+        rq_load_A<RQ_PFU>(arP, Apack2, KS, own, lane, 0);
+        rq_load_B<RQ_PFU>(bq, Xs, own, lane);
+        stage_load(0);
+        {
+            v4d_ acc = rq_product<RQ_PFU>(arP, bq, Apack2, KS, own, lane, -1, 1 % NB, v4d_{0.0, 0.0, 0.0, 0.0});
+            store_part(acc, 0);
+            stage_store(0);
+            publish();
+        }
+        if (PROF && a.prof) tq = (long long)__builtin_amdgcn_s_memtime();
+        // iteration g: product of block row b(g+1) with hole b(g); prefetch of the fragments of row b(g+2)
+        int b = 0;
+        for (int64_t g = 0; g < gmax + (lockstep ? 1 : 0); g++) {
+            const int bn = (b + 1 == NB) ? 0 : b + 1, bn2 = (bn + 1 == NB) ? 0 : bn + 1;
+            const int bprev = (b == 0) ? NB - 1 : b - 1;
+            QTICK(0)
+            bool stop = false;
+            if (lockstep) { __syncthreads(); if (rq_sync_read(sy)[RQ_STOP]) break; }
+            if (g > 0) {
+                const int us = rq_slot(own, bprev);
+                if (us >= 0) {
+                    // the chain rewrote one of this wave's blocks during interval g - 1: wait for its commit
+                    for (;;) {
+                        const rq_i4 s4 = rq_sync_read(sy);
+                        if (s4[RQ_STOP]) { stop = true; break; }
+                        if (s4[RQ_COMMIT] >= (int)g) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (stop) break;
+                    rq_refresh_B<RQ_PFU>(bq, Xs, own, lane, us);
+                }
+            }
+            QTICK(1)
+            stage_load(bn);
+            v4d_ acc = rq_product<RQ_PFU>(arP, bq, Apack2, KS, own, lane, rq_slot(own, b), bn2, v4d_{0.0, 0.0, 0.0, 0.0});
+            QTICK(2)
+            // the slots written now were last read by the chain during interval g - 1: partial tiles at its start
+            // (cons >= g), staged operands until its commit (commit >= g)
+            for (;;) {
+                const rq_i4 s4 = rq_sync_read(sy);
+                if (s4[RQ_STOP]) { stop = true; break; }
+                if (s4[RQ_CONS] >= (int)g && s4[RQ_COMMIT] >= (int)g) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (stop) break;
+            QTICK(3)
+            store_part(acc, (int)((g + 1) & 1));
+            stage_store((int)((g + 1) & 1));
+            publish();
+            b = bn;
+        }
+        if (PROF && a.prof && tid == 128)
+            for (int k = 0; k < 8; k++) a.prof[tile * 16 + 8 + k] = qc[k];
+#undef QTICK
+    } else {
+        // ========================================================================== chain role
+        __builtin_amdgcn_s_setprio(3);
+        const int r = lane >> 2, gq = lane & 3;
+        const int64_t gr = tile * 16 + r;
+        const bool live_r = gr < a.R;
+        // feasible set of this lane's restart (registers for the whole kernel): [-symb, -syma] u [syma, symb]
+        const int Un = TC.n[r], Uslow = TC.slow[r];
+        const double Ul0 = TC.lo[r], Uh0 = TC.hi[r], Ul1 = TC.lo[16 + r], Uh1 = TC.hi[16 + r];
+        const bool two = Un >= 2;
+        const double thr = two ? 1e-7 * (Ul1 - Uh0) : 0.0;
+        const double syma = two ? Ul1 : 0.0, symb = two ? Uh1 : Uh0;
+        ChainState S;
+        S.fcur = 0.0; S.upd_counter = 0; S.visits = 0; S.accepted = 0; S.sweeps = 0;
+        S.conv = true; S.status = 0;
+        if (live_r) S.conv = a.flag[gr] ? false : true;
+        // tracked objective: the four lanes of a quad hold partial sums; lane g == 0 starts from the evaluated value
+        double fpart = (live_r && gq == 0) ? a.f0cur[gr] : 0.0;
+        const RqOwn cown = rq_own(NB, CS, RQ_NMW);
+        v2d_ arC[2 * CSU];
+        double bqC[4 * CSU];
+        double afix[4] = {0.0, 0.0, 0.0, 0.0};
+        if (CS > 0) {
+            rq_load_A<CSU>(arC, Apack2, KS, cown, lane, 0);
+            rq_load_B<CSU>(bqC, Xs, cown, lane);
+            // prologue share: product of block row 0 over the chain's blocks (no hole), into the chain's plane
+            v4d_ acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, -1, 1 % NB, v4d_{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+            for (int v = 0; v < 4; v++) fixp[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; v++) fixp[v * 64 + lane] = 0.0;
+        }
+        long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;
+#define PROF_TICK(slot) if (PROF && a.prof) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); pc[slot] += now_ - tp; tp = now_; }
+        if (PROF && a.prof) tp = (long long)__builtin_amdgcn_s_memtime();
+        const double tolv = a.tol;
+        int b = 0;
+        int64_t t = 0;
+        for (int64_t g = 0; g < gmax; g++) {
+            const int bn = (b + 1 == NB) ? 0 : b + 1, bn2 = (bn + 1 == NB) ? 0 : bn + 1;
+            const int cur = (int)(g & 1);
+            const double *DU = DU2 + cur * 256, *rtb = rtb2 + cur * 16, *dgb = dg2 + cur * 16;
+            const double *part = part2 + cur * RQ_NMW * 256;
+            PROF_TICK(0)
+            if (lockstep) __syncthreads();
+            // partial tiles / staged operands of block b: all six mfma waves have published iteration g - 1
+            for (;;) {
+                const rq_i4 p4 = rq_sync_read(sy + RQ_PARTS), p2 = rq_sync_read(sy + RQ_PARTS + 4);
+                int lo4 = p4[0] < p4[1] ? p4[0] : p4[1];
+                const int lo2 = p4[2] < p4[3] ? p4[2] : p4[3], lo1 = p2[0] < p2[1] ? p2[0] : p2[1];
+                lo4 = lo4 < lo2 ? lo4 : lo2;
+                lo4 = lo4 < lo1 ? lo4 : lo1;
+                if (lo4 >= (int)g + 1) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            PROF_TICK(1)
+            // ---- G + q/2 of the lane's own columns: its own plane, then the six partial tiles, in a fixed order
+            double gb[4], g0[4], xo[4], xn[4], rto[4], t2o[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                double s = fixp[v * 64 + lane];
+#pragma unroll
+                for (int w = 0; w < RQ_NMW; w++) s += part[w * 256 + v * 64 + lane];
+                gb[v] = s;
+                g0[v] = s;
+            }
+            rq_sync_write(sy, RQ_CONS, (int)g + 1, lane);     // the partial tiles have been read (LDS is in order per wave)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                xo[v] = Xs[(16 * b + 4 * v + gq) * 16 + r];
+                rto[v] = rtb[4 * v + gq];
+                t2o[v] = dgb[4 * v + gq];
+            }
+            {   // A fragments for the fix-up of the NEXT block row: k-steps of this block
+                const double *ap = Apack + ((int64_t)bn * KS + 4 * b) * 64 + lane;
+#pragma unroll
+                for (int u = 0; u < 4; u++) afix[u] = ap[u * 64];
+            }
+            if (b == 0 && !S.conv) S.sweeps++;
+            PROF_TICK(2)
+            const bool act = !S.conv;
+            const bool actn = act && Un > 0;
+            const double tole = actn ? tolv : QM_INF;     // a restart that is not sweeping never moves
+            // ---- the 16 steps: only what the next step waits for
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int v = c >> 2, go = c & 3;
+                // every lane works on its own column 4 v + gq; only the owner quad-lane (gq == go) is at step c
+                const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);              // vertex of the scalar objective
+                const double pick = __builtin_copysign(fmin(fmax(fabs(xv), syma), symb), xv);
+                const double dlt = pick - xo[v];
+                const double dl = (fabs(dlt) > tole) ? dlt : 0.0;
+                double delta;
+                if (go == 0) delta = rq_quad_bcast<0x00>(dl);
+                else if (go == 1) delta = rq_quad_bcast<0x55>(dl);
+                else if (go == 2) delta = rq_quad_bcast<0xAA>(dl);
+                else delta = rq_quad_bcast<0xFF>(dl);
+                // fold the move into the columns the lane owns that are still ahead (the masked block has zeros elsewhere,
+                // in particular at the lane's own finished columns: their G stays what the decision saw)
+#pragma unroll
+                for (int v2 = v; v2 < 4; v2++) gb[v2] = __builtin_fma(DU[c * 16 + 4 * v2 + gq], delta, gb[v2]);
+            }
+            PROF_TICK(3)
+            // ---- once per block, per own column: the decision again from the frozen G (bit-identical to what the step
+            // computed when the lane was the owner), new x, near-tie test, move mask, objective tracking
+            bool allfar = true;
+            unsigned mv = 0;
+            double fadd = 0.0;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);
+                const double pick = __builtin_copysign(fmin(fmax(fabs(xv), syma), symb), xv);
+                const double dlt = pick - xo[v];
+                const bool mvd = fabs(dlt) > tole;
+                const double d = mvd ? dlt : 0.0;
+                xn[v] = mvd ? pick : xo[v];
+                allfar = allfar && (fabs(xv) > thr);                                   // false for NaN as well
+                mv |= mvd ? (1u << (4 * v + gq)) : 0u;
+                // f(x + d e_i) - f(x) = d (2 (P x)_i + q_i + P_ii d) = d (t2 d + 2 g):  g = G_i + q_i / 2 contains P_ii x_i
+                fadd = __builtin_fma(d, __builtin_fma(t2o[v], d, gb[v] + gb[v]), fadd);
+            }
+            mv = rq_quad_or(mv);                                                       // bit c = coordinate c moved
+            bool redo = act && Un > 0 && (!allfar || Uslow != 0);
+            if (__builtin_amdgcn_ballot_w64(redo) == 0ull) {
+                if (act) {
+                    fpart += fadd;
+                    const int accn = __builtin_popcount(mv);
+                    const int upd = mv ? (__builtin_clz(mv) - 16) : (int)S.upd_counter + 16;
+                    S.accepted += accn;
+                    const int over = upd - (int)P.n;
+                    S.visits += 16 - (over > 0 ? over : 0);
+                    S.upd_counter = upd;
+                    if (over >= 0) S.conv = true;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; v++) Xs[(16 * b + 4 * v + gq) * 16 + r] = xn[v];
+            } else {
+                // ---- generic loop (rare): the reference's arithmetic; G tile (kept from the block's start: the partial
+                // tiles may already be overwritten) rebuilt in the chain's plane, all four lanes of a quad walk their
+                // restart redundantly (same values, benign identical LDS writes)
+                if (PROF) pc[6]++;
+                const double *hqb = hqb2 + cur * 16;
+                S.fcur = rq_quad_sum(fpart);
+                double *Gsc = fixp;
+#pragma unroll
+                for (int v = 0; v < 4; v++) Gsc[(4 * v + gq) * 16 + r] = g0[v];
+                for (int c = 0; c < 16; c++) {
+                    const int64_t i = 16 * (int64_t)b + c;
+                    FeasSet<MAXC> C;
+                    C.n = Un; C.lo[0] = Ul0; C.hi[0] = Uh0; C.lo[1] = Ul1; C.hi[1] = Uh1;
+                    const double t2g = dgb[c];
+                    const double xi = Xs[i * 16 + r];
+                    const double hq = hqb[c];
+                    const double t1 = 2.0 * ((Gsc[c * 16 + r] - hq) - t2g * xi) + (hq + hq);
+                    const double t0 = S.fcur - xi * (t2g * xi + t1);
+                    DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t | 0x80000000u, 0u};
+                    double xnew = xi;
+                    int got = S.conv ? 0 : onevar_minimise<MAXC>(t2g, t1, t0, C, dk, &xnew);
+                    bool moved;
+                    double delta;
+                    chain_commit<MAXC>(S, got, xnew, xi, t2g, t1, t0, a.tol, P.n, moved, delta);
+                    if (moved) {
+                        Xs[i * 16 + r] = xnew;
+                        for (int c2 = c + 1; c2 < 16; c2++) Gsc[c2 * 16 + r] += DU[c * 16 + c2] * delta;
+                    }
+                }
+                fpart = (gq == 0) ? S.fcur : 0.0;
+            }
+            rq_sync_write(sy, RQ_COMMIT, (int)g + 1, lane);   // block b is in the X tile; its staged operands are free
+            PROF_TICK(4)
+            const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv);
+            if (PROF) pc[5]++;
+            if (livem == 0ull || g + 1 >= gmax) break;
+            // ---- fix-up (the 4 k-steps of the block just committed) + the chain's own share of the next product
+            {
+                v4d_ acc = {0.0, 0.0, 0.0, 0.0};
+                const int xoff = (4 * b) * 64 + (lane >> 4) * 16 + (lane & 15);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afix[u], Xs[xoff + u * 64], acc, 0, 0, 0);
+                if (CS > 0) {
+                    const int us = rq_slot(cown, b);
+                    if (us >= 0) rq_refresh_B<CSU>(bqC, Xs, cown, lane, us);
+                    acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, us, bn2, acc);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; v++) fixp[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
+            }
+            PROF_TICK(7)
+            b = bn;
+            if (b == 0) t++;
+        }
+        rq_sync_write(sy, RQ_STOP, 1, lane);
+        if (lockstep) __syncthreads();
+        const double ftot = rq_quad_sum(fpart);
+        if (gq == 0 && live_r) {
+            a.visits[gr] = S.visits; a.accepted[gr] = S.accepted; a.sweeps[gr] = S.sweeps;
+            a.status[gr] = S.status;
+            if (a.f0out && a.flag[gr]) a.f0out[gr] = ftot;   // tracked exactly through every accepted move
+        }
+        if (PROF && a.prof && tid == 0)
+            for (int k = 0; k < 8; k++) a.prof[tile * 16 + k] = pc[k];
+#undef PROF_TICK
+    }
+    __syncthreads();
+    if (a.mvout) {
+        // max violation of the final points, same expression as eval_kernel: (p x + q) x + r of the one
+        // constraint every coordinate carries (single class, one constraint per coordinate)
+        const int e0 = P.cptr[P.krep[0]];
+        const double cp = P.cp[e0], cq = P.cq[e0], cr = P.cr[e0];
+        const int rel = P.crel[e0];
+        const int r = tid & 15, slot = tid >> 4;
+        double v = -QM_INF;
+        for (int64_t i = slot; i < P.n; i += 32) {
+            const double x = Xs[i * 16 + r];
+            const double f = (cp * x + cq) * x + cr;
+            const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+            v = w > v ? w : v;
+        }
+        double *red = part2;                 // 512 doubles of the partial-tile area, free by now
+        red[tid] = v;
+        __syncthreads();
+        if (tid < 16) {
+            const int64_t g = tile * 16 + tid;
+            double m = -QM_INF;
+            for (int s2 = 0; s2 < 32; s2++) { const double w = red[s2 * 16 + tid]; m = w > m ? w : m; }
+            if (g < a.R && a.flag[g]) a.mvout[g] = m;
+        }
+    }
+    for (int64_t idx = tid; idx < n16 * 16; idx += 512) Xg[idx] = Xs[idx];
+}
+
+}  // namespace qcqpmi

@@ -388,11 +388,12 @@ __global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
     if (slot == 0 && live) a.sweeps[gr] = sweeps_done;
 }
 
-// coordinate descent phase 2: cd_phase2.h (general kernel), cd_phase2_rs.h (role-split pipelined kernel)
+// coordinate descent phase 2: cd_phase2.h (general kernel), cd_phase2_rs.h / cd_phase2_q.h (role-split pipelined kernels)
 
 }  // namespace qcqpmi
 #include "cd_phase2.h"
 #include "cd_phase2_rs.h"
+#include "cd_phase2_q.h"
 namespace qcqpmi {
 
 // gate of improve_coord_descent (qcqp.py:189): phase 2 runs only for restarts whose max violation

@@ -87,10 +87,15 @@ def solve_sdr(engine, form, max_sweeps=5000, tol=1e-11, seed=0):
     V, hist, sweeps = engine.sdr_solve_unitdiag(C, max_sweeps=max_sweeps, tol=tol, seed=seed)
     Y = V.dot(V.T)
     X = Y * np.outer(sc, sc)
-    # rotate so that the homogenising coordinate is +1 exactly (X_nn = 1 already; sign of the last column
-    # is fixed by the optimisation itself)
-    bound = float(hist[-1])
-    return X, bound, dict(V=V, C=C, hist=hist, sweeps=sweeps, scale=sc)
+    # The mixing iterate's <C, V V'> is an UPPER estimate of the SDP value (exact only at convergence); what is
+    # published as sdr_bound is the rigorous dual bound  -sum(y) + N min(0, lambda_min(C + diag(y)))  of the
+    # stationarity multipliers (valid for any V), and the solve is checked like a solver status.
+    primal = float(hist[-1])
+    y, lmin, lower = dual_certificate(C, V)
+    info = dict(V=V, C=C, hist=hist, sweeps=sweeps, scale=sc, y=y, primal=primal, dual_bound=lower, infeas=0.0,
+                sweep_limit_hit=bool(sweeps >= max_sweeps))
+    certify(info, lmin, 1.0 + float(np.max(np.abs(C))), 'solve_sdr (mixing method)')
+    return X, lower, info
 
 
 # ------------------------------------------------------------------------- general QCQPs
@@ -105,24 +110,11 @@ def _functions(form, engine=None):
     return Q, r, eq
 
 
-def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400, feas_tol=1e-6, seed=0, verbose=False):
-    """SDP relaxation of ANY QCQP the dense path holds (constraints that couple coordinates), in the
-    Burer-Monteiro form X = V V' (V: (n+1) x r, r(r+1)/2 > m+1) with an augmented Lagrangian on the
-    constraints  <M_k, X> (<=, ==) 0,  X_nn = 1   (solve_sdr, qcqp.py:72-97).  The heavy linear algebra runs
-    on the device through the engine: the constraint values are quadratic forms of the r columns of V
-    (one batched evaluation with the quadratic and the linear parts of the homogeneous forms kept apart) and the gradient is 2 S V with S = sum_k w_k M_k (qcqpmi_pop_weighted_product: one pass over all
-    matrices + one GEMM).  The host runs L-BFGS on the (n+1) r entries of V and the multiplier updates.
-    Returns (X, bound, info); info['y'] are the multipliers (info['dual_value'] = -y_N is a lower bound of the
-    SDP value whenever C + sum y_k M_k + y_N E_NN is PSD -- dual_certificate_general checks that on the host)."""
+def _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inner, feas_tol, seed, verbose):
+    """Augmented-Lagrangian loop on the Burer-Monteiro factor V ((n+1) x rank) of the lifted matrix, shared by the
+    dense and the separable operator sets.  values(V) -> h (m+1,): <M_k, V V'> for the objective (k = 0) and every
+    constraint; gradient(V, ws, wN) -> d/dV of sum_k ws_k <M_k, V V'> + wN |t|^2 (V is the matrix `values` saw last)."""
     from scipy.optimize import minimize
-    n, m = form.n, form.m
-    Q, rr, eq = _functions(form, engine)
-    if rank is None:
-        rank = int(np.ceil(np.sqrt(2.0 * (m + 2)))) + 1
-    rank = int(min(max(rank, 2), 64))
-    # row scaling of the constraints (the multipliers are un-scaled at the end)
-    sc = np.ones(m + 1)
-    sc[1:] = 1.0 / (1.0 + np.abs(rr[1:]) + np.linalg.norm(Q[1:], axis=1) / np.sqrt(n))
     ineq = ~eq
     ineq[0] = False
     eqc = eq.copy()
@@ -134,19 +126,10 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
     y = np.zeros(m + 1)      # y[0] unused
     yN = 0.0
     sigma = float(sigma0)
-    evals = [0]
-
-    def values(Vm):
-        Vx, t = Vm[:n, :], Vm[n, :]
-        engine.upload(Vx)
-        quad, lin = engine.eval_parts()          # x'P_k x + r_k and q_k'x per column, one pass on the device
-        evals[0] += 1
-        h = (quad - rr[:, None]).sum(axis=1) + lin.dot(t) + rr * t.dot(t)
-        return h
 
     def fun_grad(v):
         Vm = v.reshape(n + 1, rank)
-        Vx, t = Vm[:n, :], Vm[n, :]
+        t = Vm[n, :]
         h = values(Vm) * sc
         tt = t.dot(t) - 1.0
         w = np.zeros(m + 1)
@@ -156,16 +139,12 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
         wN = yN + sigma * tt
         L = h[0] + np.sum(y[eqc] * h[eqc] + 0.5 * sigma * h[eqc] ** 2) \
             + np.sum((w[ineq] ** 2 - y[ineq] ** 2) / (2.0 * sigma)) + yN * tt + 0.5 * sigma * tt * tt
-        ws = w * sc
-        SVx = engine.weighted_product(ws)                       # population = Vx (uploaded by values())                       # (sum_k ws_k P_k) Vx
-        qh = 0.5 * ws.dot(Q)                                    # sum_k ws_k q_k / 2
-        G = np.empty_like(Vm)
-        G[:n, :] = 2.0 * (SVx + np.outer(qh, t))
-        G[n, :] = 2.0 * (qh.dot(Vx) + (ws.dot(rr) + wN) * t)
+        G = gradient(Vm, w * sc, wN)
         return L, G.ravel()
 
     hist = []
     prev_infeas = None
+    infeas = np.inf
     for it in range(outer):
         # inexact inner solves: no point in polishing the Lagrangian far below the current infeasibility
         rough = prev_infeas is not None and prev_infeas > 1e-4
@@ -190,7 +169,167 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
     X = V.dot(V.T)
     X = X / X[n, n]
     bound = float(values(V)[0] / V[n, :].dot(V[n, :]))
-    return X, bound, dict(V=V, y=y * sc, yN=yN, hist=hist, evals=evals[0], rank=rank, dual_value=-yN)
+    return X, bound, dict(V=V, y=y * sc, yN=yN, hist=hist, rank=rank, dual_value=-yN, primal=bound,
+                          infeas=float(infeas), outer_limit_hit=(len(hist) >= outer and not infeas < feas_tol))
+
+
+def _default_rank(m, rank):
+    if rank is None:
+        rank = int(np.ceil(np.sqrt(2.0 * (m + 2)))) + 1
+    return int(min(max(rank, 2), 64))
+
+
+def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400, feas_tol=1e-6, seed=0, verbose=False):
+    """SDP relaxation of ANY QCQP the dense path holds (constraints that couple coordinates), in the
+    Burer-Monteiro form X = V V' (V: (n+1) x r, r(r+1)/2 > m+1) with an augmented Lagrangian on the
+    constraints  <M_k, X> (<=, ==) 0,  X_nn = 1   (solve_sdr, qcqp.py:72-97).  The heavy linear algebra runs
+    on the device through the engine: the constraint values are quadratic forms of the r columns of V
+    (one batched evaluation with the quadratic and the linear parts of the homogeneous forms kept apart) and the
+    gradient is 2 S V with S = sum_k w_k M_k (qcqpmi_pop_weighted_product: one pass over all matrices + one GEMM).
+    The host runs L-BFGS on the (n+1) r entries of V and the multiplier updates.
+    Returns (X, bound, info); info['y'] are the multipliers (info['dual_value'] = -y_N is a lower bound of the
+    SDP value whenever C + sum y_k M_k + y_N E_NN is PSD -- certify_general checks that)."""
+    n, m = form.n, form.m
+    Q, rr, eq = _functions(form, engine)
+    rank = _default_rank(m, rank)
+    # row scaling of the constraints (the multipliers are un-scaled at the end)
+    sc = np.ones(m + 1)
+    sc[1:] = 1.0 / (1.0 + np.abs(rr[1:]) + np.linalg.norm(Q[1:], axis=1) / np.sqrt(n))
+    evals = [0]
+
+    def values(Vm):
+        Vx, t = Vm[:n, :], Vm[n, :]
+        engine.upload(Vx)
+        quad, lin = engine.eval_parts()          # x'P_k x + r_k and q_k'x per column, one pass on the device
+        evals[0] += 1
+        return (quad - rr[:, None]).sum(axis=1) + lin.dot(t) + rr * t.dot(t)
+
+    def gradient(Vm, ws, wN):
+        Vx, t = Vm[:n, :], Vm[n, :]
+        SVx = engine.weighted_product(ws)                       # population = Vx (uploaded by values()): (sum_k ws_k P_k) Vx
+        qh = 0.5 * ws.dot(Q)                                    # sum_k ws_k q_k / 2
+        G = np.empty_like(Vm)
+        G[:n, :] = 2.0 * (SVx + np.outer(qh, t))
+        G[n, :] = 2.0 * (qh.dot(Vx) + (ws.dot(rr) + wN) * t)
+        return G
+
+    X, bound, info = _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inner, feas_tol, seed, verbose)
+    info['evals'] = evals[0]
+    return X, bound, info
+
+
+def separable_family(form):
+    """(coord, p, q, r) arrays (one entry per constraint) if every constraint of the form touches exactly one
+    coordinate -- boxes, discs / annuli in one variable, one-sided bounds, x_i^2 = d_i -- else None."""
+    if not hasattr(form, 'fs'):
+        return None
+    m = form.m
+    coord = np.zeros(m, dtype=np.int64); p = np.zeros(m); q = np.zeros(m); r = np.zeros(m)
+    for k, f in enumerate(form.fs):
+        qa = np.asarray(f.qarray, dtype=np.float64).ravel()
+        if hasattr(f.P, 'tocoo'):
+            Pc = f.P.tocoo()
+            keep = Pc.data != 0.0
+            rows, cols, vals = Pc.row[keep], Pc.col[keep], Pc.data[keep]
+        else:
+            P = np.asarray(f.P)
+            rows, cols = np.nonzero(P)
+            vals = P[rows, cols]
+        qi = np.nonzero(qa)[0]
+        idx = set(int(a) for a in rows) | set(int(a) for a in cols) | set(int(a) for a in qi)
+        if len(idx) != 1:
+            return None
+        i = idx.pop()
+        coord[k] = i
+        p[k] = float(vals.sum()) if len(vals) else 0.0
+        q[k] = qa[i]
+        r[k] = f.r
+    return coord, p, q, r
+
+
+def solve_sdr_separable(engine, form, rank=None, sigma0=10.0, outer=40, inner=400, feas_tol=1e-6, seed=0, verbose=False):
+    """The same relaxation for problems whose constraints each touch ONE coordinate (any mix of boxes, discs,
+    annuli, bounds, x_i^2 = d_i): <M_k, X> = p_k X_ii + q_k X_in + r_k X_nn is elementwise on the factor, only the
+    objective's P0 V is a matrix product -- on the device (the engine's packed P0: qcqpmi_pop_eval for the quadratic
+    form of every column, qcqpmi_pop_weighted_product for P0 V)."""
+    fam = separable_family(form)
+    if fam is None:
+        return None
+    coord, p, q, r = fam
+    n, m = form.n, form.m
+    q0 = np.asarray(form.f0.qarray, dtype=np.float64).ravel()
+    r0 = float(form.f0.r)
+    eq = np.array([False] + [f.relop == '==' for f in form.fs])
+    rank = _default_rank(m, rank)
+    sc = np.ones(m + 1)
+    sc[1:] = 1.0 / (1.0 + np.abs(r) + np.abs(q) + np.abs(p))
+    w0 = np.zeros(m + 1)
+    w0[0] = 1.0
+
+    def values(Vm):
+        Vx, t = Vm[:n, :], Vm[n, :]
+        engine.upload(Vx)
+        f0, _ = engine.eval()                                    # x'P0x + q0'x + r0 per column
+        tt = t.dot(t)
+        h = np.empty(m + 1)
+        h[0] = (f0 - Vx.T.dot(q0) - r0).sum() + q0.dot(Vx.dot(t)) + r0 * tt
+        Xii = np.einsum('ik,ik->i', Vx, Vx)
+        Xin = Vx.dot(t)
+        h[1:] = p * Xii[coord] + q * Xin[coord] + r * tt
+        return h
+
+    def gradient(Vm, ws, wN):
+        Vx, t = Vm[:n, :], Vm[n, :]
+        P0V = engine.weighted_product(w0)                        # P0 Vx on the device (population = Vx)
+        pw = np.bincount(coord, weights=ws[1:] * p, minlength=n)     # sum of w_k p_k on each coordinate
+        qw = np.bincount(coord, weights=ws[1:] * q, minlength=n)
+        qh = 0.5 * (ws[0] * q0 + qw)
+        G = np.empty_like(Vm)
+        G[:n, :] = 2.0 * (ws[0] * P0V + pw[:, None] * Vx + np.outer(qh, t))
+        G[n, :] = 2.0 * (qh.dot(Vx) + (ws[0] * r0 + ws[1:].dot(r) + wN) * t)
+        return G
+
+    X, bound, info = _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inner, feas_tol, seed, verbose)
+    info['family'] = 'separable'
+    return X, bound, info
+
+
+def certify(info, lmin, scale, what):
+    """Turn the raw outcome of a relaxation solve into what may be published as a BOUND (the reference only accepts
+    solver status OPTIMAL / OPTIMAL_INACCURATE, qcqp.py:94-95).  info['converged'] is True when the iterate is feasible
+    to tolerance, the iteration limit was not the reason to stop and the dual slack matrix is PSD to rounding
+    (lambda_min >= -1e-6 scale).  Raises when the solve is clearly not a solution of the relaxation."""
+    import logging
+    log = logging.getLogger('qcqp_amd')
+    ok_psd = lmin >= -1e-6 * scale
+    ok_feas = info.get('infeas', 0.0) <= 1e-5
+    limit = bool(info.get('outer_limit_hit', False)) or bool(info.get('sweep_limit_hit', False))
+    info['lambda_min'] = float(lmin)
+    info['converged'] = bool(ok_psd and ok_feas and not limit)
+    if not info['converged']:
+        msg = ('%s: relaxation not solved to optimality (lambda_min of the dual slack %.3e, infeasibility %.2e, iteration '
+               'limit hit: %s)' % (what, lmin, info.get('infeas', 0.0), limit))
+        if lmin < -1e-2 * scale or info.get('infeas', 0.0) > 1e-2:
+            raise Exception("Relaxation problem status: " + msg)
+        log.warning(msg + '; the published bound is the rigorous / dual value where one exists')
+    return info
+
+
+def dual_slack_separable(form, fam, y, yN):
+    """S = M0 + sum_k y_k M_k + y_N E_NN for separable constraints (host, O(n^2)): the constraints only touch the
+    diagonal and the last row / column of the lifted matrix."""
+    coord, p, q, r = fam
+    n = form.n
+    P0 = _dense(form.f0.P)
+    S = np.zeros((n + 1, n + 1))
+    S[:n, :n] = 0.5 * (P0 + P0.T)
+    yk = y[1:]
+    S[np.arange(n), np.arange(n)] += np.bincount(coord, weights=yk * p, minlength=n)
+    qh = 0.5 * (np.asarray(form.f0.qarray, dtype=np.float64).ravel() + np.bincount(coord, weights=yk * q, minlength=n))
+    S[:n, n] = qh
+    S[n, :n] = qh
+    S[n, n] = form.f0.r + yk.dot(r) + yN
+    return float(np.linalg.eigvalsh(S)[0]), S
 
 
 def dual_certificate_device(engine, y, yN):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     L = _ffi.lib()
-    assert L.qcqpmi_abi_version() == 1
+    assert L.qcqpmi_abi_version() == 2
     assert L.qcqpmi_device_count() >= 0
 
 
@@ -268,3 +268,82 @@ def test_sdr_dual_certificate_on_a_known_solution():
     V2 = np.zeros((N, 64)); V2[np.arange(N), np.arange(N)] = 1.0   # X = I: feasible, not optimal
     y2, lmin2, lower2 = sdr.dual_certificate(C, V2)
     assert lmin2 < -1.0 and lower2 <= -N * N + 1e-9
+
+
+# ------------------------------------------------------------------ cvxpy front end (duck-typed: cvxpy is not installed)
+def test_cvxpy_adapter_extracts_the_reference_form():
+    """get_qcqp_form's job (utilities.py:318-347) through qcqp_amd.cvxpy_adapter on a duck-typed cvxpy >= 1 problem:
+    Boolean least squares as the README writes it (sum_squares(A x - b), square(x) == 1) plus a dense quadratic
+    inequality and a >= constraint; one function per scalar constraint entry, symmetric P, maximise negated,
+    non-quadratic expressions refused with the reference's messages, variable values restored."""
+    from qcqp_amd.cvxpy_adapter import problem_from_cvxpy
+
+    class Var(object):
+        def __init__(self, shape):
+            self.shape, self.value, self.id = shape, None, 7
+
+    class Expr(object):
+        def __init__(self, fn, shape, quad=True):
+            self.fn, self.shape, self.quad = fn, shape, quad
+        value = property(lambda self: self.fn())
+
+        def is_quadratic(self):
+            return self.quad
+
+    class Objective(object):
+        def __init__(self, name, e):
+            self.NAME, self.args = name, [e]
+
+    class Equality(object):
+        def __init__(self, e):
+            self.expr = e
+
+    class Inequality(object):
+        def __init__(self, e):
+            self.expr = e
+
+    class NonNeg(object):
+        def __init__(self, e):
+            self.args = [e]
+
+    class Prob(object):
+        def __init__(self, o, cs, vs):
+            self.objective, self.constraints, self._vs = o, cs, vs
+
+        def variables(self):
+            return self._vs
+
+    rs = np.random.RandomState(0)
+    n = 6
+    A, b = rs.randn(9, n), rs.randn(9)
+    G = rs.randn(n, n)
+    g = rs.randn(n)
+    x = Var((n,))
+    x.value = np.arange(n, dtype=float)
+    obj = Expr(lambda: np.sum((A.dot(x.value) - b) ** 2), ())
+    cons = [Equality(Expr(lambda: x.value ** 2 - 1.0, (n,))),
+            Inequality(Expr(lambda: x.value.dot(G).dot(x.value) + g.dot(x.value) - 3.0, ())),
+            NonNeg(Expr(lambda: x.value[:2] + 2.0, (2,)))]
+    p = problem_from_cvxpy(Prob(Objective('minimize', obj), cons, [x]))
+    f = p.qcqp_form
+    assert (f.n, f.m) == (n, n + 1 + 2) and p.objective.NAME == 'minimize'
+    assert np.allclose(f.f0.P, A.T.dot(A)) and np.allclose(f.f0.qarray, -2 * A.T.dot(b)) and np.isclose(f.f0.r, b.dot(b))
+    for i in range(n):
+        E = np.zeros((n, n)); E[i, i] = 1.0
+        assert np.allclose(np.asarray(f.fs[i].P), E) and f.fs[i].r == -1.0 and f.fs[i].relop == '=='
+    assert np.allclose(f.fs[n].P, (G + G.T) / 2) and np.allclose(f.fs[n].qarray, g) and f.fs[n].relop == '<='
+    # x_0 + 2 >= 0  ->  -x_0 - 2 <= 0
+    assert f.fs[n + 1].relop == '<=' and f.fs[n + 1].qarray[0] == -1.0 and f.fs[n + 1].r == -2.0
+    assert np.array_equal(x.value, np.arange(n, dtype=float))          # caller's values restored
+    # maximise: negated like utilities.py:335-336
+    pm = problem_from_cvxpy(Prob(Objective('maximize', obj), cons[:1], [x]))
+    assert pm.objective.NAME == 'maximize' and np.allclose(pm.qcqp_form.f0.P, -A.T.dot(A))
+    # variables adapter: (rows, cols) size, column-major values
+    v = pm.variables()[0]
+    assert v.size == (n, 1)
+    v.value = np.ones((n, 1))
+    assert x.value.shape == (n,) and np.all(x.value == 1.0)
+    with pytest.raises(Exception, match='Objective is not quadratic'):
+        problem_from_cvxpy(Prob(Objective('minimize', Expr(lambda: 0.0, (), quad=False)), [], [x]))
+    with pytest.raises(Exception, match='Not all constraints are quadratic'):
+        problem_from_cvxpy(Prob(Objective('minimize', obj), [Equality(Expr(lambda: x.value, (n,), quad=False))], [x]))

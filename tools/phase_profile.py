@@ -36,6 +36,18 @@ print('sweeps/restart', out['visits2'].mean() / n, 'max', out['visits2'].max() /
 blocks = s[5] / tiles
 print('blocks per tile', blocks, '= sweeps', blocks / (n / 16))
 print('generic-path blocks', s[6], 'of', s[5])
+quad = (not generic) and n % 16 == 0 and n <= 1024 and not ((mode >> 4) & 64)
+if quad:
+    print('kernel variant: cd_phase2_q_kernel (quad chain)')
+    for k, nm in enumerate(['chain: loop top', 'chain: wait for partial tiles', 'chain: sum partials + loads', 'chain: 16 steps',
+                            'chain: block end + commit', '-', '-', 'chain: fix-up + own share']):
+        if nm != '-':
+            print('%-34s %10.0f cycles/block' % (nm, s[k] / max(s[5], 1)))
+    print('%-34s %10.0f' % ('generic-path blocks', s[6]))
+    for k, nm in enumerate(['mfma wave 2: store + publish', 'mfma wave 2: commit wait + refresh', 'mfma wave 2: stage loads + product',
+                            'mfma wave 2: slot-release wait']):
+        print('%-34s %10.0f cycles/block' % (nm, s[8 + k] / max(s[5], 1)))
+    sys.exit(0)
 names = (['mfma', 'stage', 'barrier1', 'sequential', 'barrier2'] if generic
          else ['chain', 'barrier wait', 'fix-up + preload', '-'])
 for k in range(len(names)):
