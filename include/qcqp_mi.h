@@ -171,7 +171,8 @@ int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, 
 /* Y = (sum_k w_k P_k) X for the resident population (w: m+1 weights, objective first; Y: R x n like
  * qcqpmi_pop_download).  Building block of the general SDP-relaxation solver (qcqp_amd/sdr.py: the gradient of
  * the Burer-Monteiro augmented Lagrangian is 2 S V with S = C + sum_k y_k M_k); one streaming pass over all
- * matrices + one GEMM.  Needs the packed dense matrices (problems whose constraints couple coordinates). */
+ * matrices + one GEMM.  For problems whose constraints are separable only the objective has a matrix: Y = w_0 P0 X
+ * (the constraints are elementwise operators the caller applies itself). */
 int qcqpmi_pop_weighted_product(qcqpmi_ctx *ctx, const double *w, double *Y);
 /* S = sum_k w_k P_k itself (n x n row-major on the host): the dual matrix of the SDP certificate when the matrices
  * only exist on the device.  qcqpmi_get_linear returns q_k, r_k, relop of function k as the context holds them

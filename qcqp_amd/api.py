@@ -266,8 +266,16 @@ class QCQP(object):
             raise Exception("improve(IPOPT) delegates to an external solver and is out of scope of the HIP engine.")
 
     def _improve_admm(self, *args, **kwargs):
-        """improve_admm (qcqp.py:254-285): kwargs, rho check / auto-rho and the LAPACK work stay on
-        the host exactly like in the reference; the iterations run on the GPU."""
+        """improve_admm (qcqp.py:254-285): same kwargs, rho check / auto-rho; the iterations run on the GPU.
+        Setup (what the reference gets from LAPACK / SuperLU):
+          * constraint eigenpairs (utilities.py:160-162).  Default for constraints that couple coordinates: a
+            rank-revealing range finder whose passes over the matrices run on the device (qcqp_amd.lowrank) -- if every
+            constraint has rank <= 8 the iteration runs in the reduced bases (csrc/admm.h).  Otherwise, or with
+            lowrank=False: full eigendecompositions, NumPy on the host like the reference (device_eigh=True:
+            rocSOLVER's batched dsyevd on the device).
+          * the z-update solve (qcqp.py:224-227): for a diagonal P0 the inverse is formed on the device; otherwise
+            (2 (P0 + rho m I))^-1 is computed on the host like the reference's factorisation and applied by the engine's
+            GEMM."""
         form = self.qcqp_form
         num_iters = kwargs.get('num_iters', 1000)
         viol_lim = kwargs.get('viol_lim', 1e4)
@@ -275,8 +283,8 @@ class QCQP(object):
         rho = kwargs.get('rho', None)
         phase1 = kwargs.get('phase1', True)
         P0 = np.asarray(form.f0.P.todense()) if hasattr(form.f0.P, 'todense') else np.asarray(form.f0.P)
-        lmb0 = np.linalg.eigh(P0)[0]
-        lmb_min = np.min(lmb0)
+        p0_diag = not np.any(P0 - np.diag(np.diag(P0)))
+        lmb_min = float(np.min(np.diag(P0))) if p0_diag else float(np.min(np.linalg.eigh(P0)[0]))   # qcqp.py:262, 272
         if rho is not None:
             if lmb_min + form.m * rho < 0:
                 raise Exception("rho parameter is too small, need at least %.3f." % rho)
@@ -286,28 +294,43 @@ class QCQP(object):
             else:
                 rho = 1. / form.m
             rho *= 50.
-        if not getattr(self, '_eig_uploaded', False) and kwargs.get('device_eigh', False):
-            # opt-in: f.eigh for every constraint on the device (rocSOLVER batched dsyevd); needs the dense
-            # constraint matrices resident (coupled constraints).  The first use in a process loads the
-            # 0.9 GB librocsolver.so.
-            self.engine.admm_setup()
-            self._eig_uploaded = True
         if not getattr(self, '_eig_uploaded', False):
-            lm = np.zeros((form.m, form.n))
-            Q = np.zeros((form.m, form.n, form.n))
-            for k, f in enumerate(form.fs):
-                if f.eigh is None:   # cached like utilities.py:160-162
-                    Pk = np.asarray(f.P.todense()) if hasattr(f.P, 'todense') else np.asarray(f.P)
-                    f.eigh = np.linalg.eigh((Pk + Pk.T) / 2.)
-                lm[k], Q[k] = f.eigh
-            self.engine.admm_set_eig(lm, Q)
+            mode = None
+            if kwargs.get('device_eigh', False):
+                # f.eigh for every constraint on the device (rocSOLVER batched dsyevd); needs the dense constraint
+                # matrices resident.  The first use in a process loads the 0.9 GB librocsolver.so.
+                self.engine.admm_setup()
+                mode = 'rocsolver'
+            elif kwargs.get('lowrank', True) and not self.engine.separable and form.n >= 64:
+                from . import lowrank as _lr
+                red = _lr.reduced_bases(self.engine, form, seed=0)
+                if red is not None:
+                    lam, Bv, qhat, info = red
+                    self.engine.admm_set_basis(lam, Bv, qhat)
+                    mode = 'reduced basis (rank <= %d, rp = %d)' % (int(info['rank'].max()), info['rp'])
+            if mode is None:
+                lm = np.zeros((form.m, form.n))
+                Q = np.zeros((form.m, form.n, form.n))
+                for k, f in enumerate(form.fs):
+                    if f.eigh is None:   # cached like utilities.py:160-162
+                        Pk = np.asarray(f.P.todense()) if hasattr(f.P, 'todense') else np.asarray(f.P)
+                        f.eigh = np.linalg.eigh((Pk + Pk.T) / 2.)
+                    lm[k], Q[k] = f.eigh
+                self.engine.admm_set_eig(lm, Q)
+                mode = 'full eigenbasis (host eigh)'
             self._eig_uploaded = True
-        if form.rho != rho or form.z_solver is None:
-            form.rho = rho
-            form.z_solver = np.linalg.inv(2. * (P0 + rho * form.m * np.eye(form.n)))   # qcqp.py:224-227
-        out = self.engine.admm_run(rho, form.z_solver, phase1=phase1, num_iters=num_iters, tol=tol,
+            self._admm_mode = mode
+            log.info('admm setup: %s', mode)
+        if p0_diag:
+            Minv = None
+        else:
+            if form.rho != rho or form.z_solver is None:
+                form.rho = rho
+                form.z_solver = np.linalg.inv(2. * (P0 + rho * form.m * np.eye(form.n)))   # qcqp.py:224-227
+            Minv = form.z_solver
+        out = self.engine.admm_run(rho, Minv, phase1=phase1, num_iters=num_iters, tol=tol,
                                    viol_lim=viol_lim)
-        self.last_stats = dict(out, method=s.ADMM, num_restarts=len(out['f0']), rho=rho)
+        self.last_stats = dict(out, method=s.ADMM, num_restarts=len(out['f0']), rho=rho, setup=getattr(self, '_admm_mode', None))
         log.info('admm: %d restarts, rho %.4g, phase-1 iterations %.1f (max %d), phase-2 iterations %.1f (max %d)',
                  len(out['f0']), rho, out['iters1'].mean(), int(out['iters1'].max()), out['iters2'].mean(),
                  int(out['iters2'].max()))

@@ -94,7 +94,7 @@ template <int EPL>
 __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (widx >= a.m * a.R) return;
+    if (widx >= a.m * ((a.R + 15) / 16) * 16) return;
     // consecutive waves: the 16 restarts of a tile for one constraint (they share every cache line they touch)
     const int64_t tile = widx / (16 * a.m), rem = widx % (16 * a.m);
     const int64_t k = rem / 16, r = tile * 16 + (rem % 16);

@@ -1031,9 +1031,13 @@ int qcqpmi_pop_weighted_product(qcqpmi_ctx *c, const double *w, double *Y) {
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!w || !Y) return fail(c, QCQPMI_EINVAL, "pop_weighted_product: w / Y missing");
-    if (!c->dn_Gpack) return fail(c, QCQPMI_EUNSUPPORTED, "pop_weighted_product needs the packed dense matrices (constraints that couple coordinates)");
     HIPCHK(c, hipSetDevice(c->device));
-    const DenseProblem D = dense_problem(c);
+    DenseProblem D = dense_problem(c);
+    if (!c->dn_Gpack) {
+        // separable constraints: only the objective has a matrix (the packed P0 of the separable path: the same fragment
+        // layout with one function); the weights of the constraints are the caller's business (elementwise operators)
+        D.Gpack = c->dp.Apack; D.m1 = 1; D.m1p = 64; D.q = nullptr; D.qT = nullptr; D.r = nullptr; D.relop = nullptr;
+    }
     const int64_t n16 = c->n16, ntiles = c->Rpad / 16;
     if (!c->d_wS) {
         if ((rc = dev_alloc(c, &c->d_ww, (size_t)D.m1, false))) return rc;

@@ -167,10 +167,36 @@ class Engine(object):
         assert method == 'rocsolver'
         self._chk(self.L.qcqpmi_admm_setup(self.h))
 
+    def admm_set_basis(self, lam, Bv, qhat):
+        """Reduced bases of low-rank constraints: lam (m, rp), Bv (m, rp, n) orthonormal rows (zero padded), qhat (m, rp)."""
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        Bv = np.ascontiguousarray(Bv, dtype=np.float64)
+        qhat = np.ascontiguousarray(qhat, dtype=np.float64)
+        rp = lam.shape[1]
+        assert lam.shape == (self.m, rp) and Bv.shape == (self.m, rp, self.n) and qhat.shape == (self.m, rp)
+        self._chk(self.L.qcqpmi_admm_set_basis(self.h, rp, _dp(lam), _dp(Bv), _dp(qhat)))
+
+    def admm_apply_constraints(self, V, shared=True):
+        """out[k] = P_k V_k (n x p blocks) on the device; V: (n, p) shared by all constraints or (m, n, p)."""
+        V = np.ascontiguousarray(V, dtype=np.float64)
+        p = V.shape[-1]
+        assert V.shape == ((self.n, p) if shared else (self.m, self.n, p))
+        out = np.empty((self.m, self.n, p))
+        self._chk(self.L.qcqpmi_admm_apply_constraints(self.h, p, _dp(V), 1 if shared else 0, _dp(out)))
+        return out
+
+    def admm_onecons(self, k):
+        """onecons_qcqp(z, f_k) (utilities.py:149-196) for every resident point (k = 1..m); returns (n, R)."""
+        out = np.empty((self.pop_size, self.n))
+        self._chk(self.L.qcqpmi_admm_onecons(self.h, int(k), _dp(out)))
+        return np.ascontiguousarray(out.T)
+
     def admm_run(self, rho, Minv, phase1=True, num_iters=1000, tol=1e-2, viol_lim=1e4):
+        """Minv = (2 (P0 + rho m I))^-1 (n, n), or None when P0 is diagonal (formed on the device)."""
         R = self.pop_size
-        Minv = np.ascontiguousarray(Minv, dtype=np.float64)
-        assert Minv.shape == (self.n, self.n)
+        if Minv is not None:
+            Minv = np.ascontiguousarray(Minv, dtype=np.float64)
+            assert Minv.shape == (self.n, self.n)
         out = dict(iters1=np.zeros(R, dtype=np.int64), iters2=np.zeros(R, dtype=np.int64),
                    f0=np.empty(R), maxviol=np.empty(R))
         self._chk(self.L.qcqpmi_admm_run(self.h, int(bool(phase1)), int(num_iters), float(tol),

@@ -90,18 +90,44 @@ def test_errors_mirror_reference():
     assert 'Unknown improve method(s)' in str(ei.value.args[0])
     q.suggest(SDR)              # Boolean family: the engine's own SDP solver applies
     assert q.sdr_sol is not None and q.sdr_bound is not None
-    # a separable family outside x_i^2 == d_i (box constraints): X must come from the caller
-    n2 = 5
-    funcs2 = [(np.eye(n2), np.ones(n2), 0.0, None)]
-    for i in range(n2):
-        P = np.zeros((n2, n2)); P[i, i] = 1.0
-        funcs2.append((P, np.zeros(n2), -2.0, '<='))
-    with pytest.raises(Exception) as ei:
-        handler(funcs2).suggest(SDR)
-    assert 'suggest(SDR, X=...)' in str(ei.value)
     with pytest.raises(Exception) as ei:
         q.improve('dccp')
     assert 'DCCP package is not installed.' in str(ei.value)
+
+
+def test_suggest_sdr_separable_families():
+    """solve_sdr (qcqp.py:72-97) for separable constraints other than x_i^2 = d_i: boxes / discs on single
+    coordinates go through the Burer-Monteiro solver with elementwise constraint operators (P0 V on the device).
+    Convex case with a known answer: min sum x_i^2 + x_i  s.t. x_i^2 <= 2  ->  x = -1/2, value -n/4, relaxation
+    tight; mixed case: an indefinite objective with boxes and an annulus, bound certified (dual slack PSD) and below
+    every feasible point that local search finds."""
+    from qcqp_amd import SDR, COORD_DESCENT
+    n = 12
+    funcs = [(np.eye(n), np.ones(n), 0.0, None)]
+    for i in range(n):
+        P = np.zeros((n, n)); P[i, i] = 1.0
+        funcs.append((P, np.zeros(n), -2.0, '<='))
+    q = handler(funcs)
+    np.random.seed(0)
+    f, v = q.suggest(SDR)
+    assert q.sdr_info['converged'] and q.sdr_info.get('family') == 'separable'
+    assert abs(q.sdr_bound - (-0.25 * n)) < 1e-5
+    assert np.max(np.abs(q.mu - (-0.5))) < 1e-4
+    # indefinite objective, boxes -1 <= x_i <= 2 written as (x - 1/2)^2 <= 9/4, one annulus 1 <= x_0^2 <= 4
+    rs = np.random.RandomState(3)
+    G = rs.randn(n, n); G = (G + G.T) / 2
+    funcs = [(G, rs.randn(n), 0.0, None)]
+    for i in range(n):
+        P = np.zeros((n, n)); P[i, i] = 1.0
+        qq = np.zeros(n); qq[i] = -1.0
+        funcs.append((P, qq, -2.0, '<='))          # x^2 - x - 2 <= 0  <=>  -1 <= x <= 2
+    P = np.zeros((n, n)); P[0, 0] = -1.0
+    funcs.append((P, np.zeros(n), 1.0, '<='))      # 1 - x_0^2 <= 0
+    q = handler(funcs)
+    f, v = q.suggest(SDR, num_samples=64, seed=1)
+    assert q.sdr_info['lambda_min'] > -1e-5 * (1 + abs(q.sdr_bound))
+    f2, v2 = q.improve(COORD_DESCENT, seed=2)
+    assert v2 < 1e-2 and q.sdr_bound <= f2 + 1e-6 * (1 + abs(f2))
 
 
 def test_improve_method_list_with_admm_matches_reference():
