@@ -386,7 +386,7 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
         cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
         if (cs >= NBq) cs = 0;
         cs &= ~1;
-        if (q_lds <= 160 * 1024 && NBq - cs <= RQ_NMW * RQ_PFU) {
+        if (q_lds <= 160 * 1024 && NBq - cs <= RQ_NMW * RQ_PFU && NBq >= 3) {
             used_lds = true;
             const bool prof_ = a1.prof != nullptr;
             auto k = cd_phase2_q_kernel<4, false>;

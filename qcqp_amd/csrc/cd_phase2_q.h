@@ -22,21 +22,24 @@
 //       commit of the block, together with the chain wave's own share of the next product (RQ_CS blocks
 //       of the contraction): the chain is short enough now that its SIMD has matrix time to spare.
 //   mfma waves (1, 2, 3, 5, 6, 7; two per SIMD)
-//     * STATIC ownership of the contraction: wave mw owns a fixed range of blocks of 16 coordinates, its
-//       B operands (the X rows of those blocks) stay in registers for the whole kernel; after a barrier
-//       only the wave that owns the block the chain has just rewritten re-reads 4 values from LDS
-//       (first generation: 44 LDS reads per wave and block before the first MFMA could issue).
-//     * A fragments as before: register resident, refilled in place one block ahead with unconditional
-//       16-byte loads from the pair-packed copy of P0; the block the chain is rewriting is skipped.
-//
-//     * CYCLIC ownership instead of contiguous ranges, see below.
+//     * STATIC, CYCLIC ownership of the contraction: block j of 16 coordinates belongs to wave j % 6 (the chain keeps
+//       the last CS blocks for itself), its B operands (those X rows) stay in registers for the whole kernel;
+//       generation 1 re-read 44 LDS operands per wave and block before the first MFMA could issue.
+//     * A fragments as before: register resident, refilled in place one block ahead with unconditional 16-byte loads
+//       from the pair-packed copy of P0.
+//     * TWO holes: the product for block row b+1 leaves out block b (being rewritten) AND block b-1 (rewritten just
+//       before); the chain supplies both -- after committing block b it multiplies it with the fragments of rows b+1 and
+//       b+2 (8 MFMAs) and carries the second tile in registers for one block.  No mfma wave ever needs a block within
+//       one interval of its commit: the owner refreshes its 4 operands a whole block later and never waits.
+//   staging wave (wave 4, on the chain's SIMD): fetches the small operands of the next block (masked diagonal block,
+//     diagonal, q/2, 1/P_ii) one block ahead.
 //   synchronisation
-//     * NO s_barrier inside the block loop.  Producer / consumer counters in LDS (RQ_PARTS, RQ_CONS, RQ_COMMIT,
-//       RQ_STOP): the chain waits for the six partial tiles of its block, an mfma wave waits for the chain's commit
-//       only when it owns the block the chain has just rewritten, and for the release of the slots it is about to
-//       overwrite.  With a barrier both waves of a SIMD did their store / wait / stage phases at the same time and
-//       the matrix pipe idled ~1.4 k of every 7.5 k cycles; free-running waves drift apart and cover each other.
-//       Partial tiles and staged operands are double-buffered by block parity.
+//     * NO s_barrier inside the block loop.  Producer / consumer words in LDS (RQ_CONS, RQ_COMMIT, RQ_STOP, one
+//       progress word per producer): the chain waits for the six partial tiles and the staged operands of its block, a
+//       producer for the release of the slot it is about to overwrite.  With a barrier both waves of a SIMD did their
+//       store / wait phases at the same time and the matrix pipe idled ~1.4 k of every 7.5 k cycles; free-running
+//       waves, started half a product apart, cover each other.  Partial tiles and staged operands are double-buffered
+//       by block parity.
 #pragma once
 #include <stdint.h>
 #include "cd_phase2_rs.h"
@@ -119,15 +122,16 @@ __device__ __attribute__((always_inline)) inline void rq_load_A(v2d_ (&ar)[2 * N
     }
 }
 
-// product of block row bn over the owned blocks except slot `hs` (the block the chain is rewriting, or -1); every
+// product of block row bn over the owned blocks except slots `hs`, `hs2` (the block the chain is rewriting and the one it
+// rewrote just before: the chain supplies both itself; -1 = none); every
 // fragment register is refilled right after the MFMAs that consumed it with the fragment of block row bn2
 template <int NU>
 __device__ __attribute__((always_inline)) inline v4d_ rq_product(v2d_ (&ar)[2 * NU], const double (&bq)[4 * NU], const double *__restrict__ Apack2, int KS,
-                                  const RqOwn &o, int lane, int hs, int bn2, v4d_ acc0) {
+                                  const RqOwn &o, int lane, int hs, int hs2, int bn2, v4d_ acc0) {
     v4d_ acc = acc0, acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = acc1, acc3 = acc1;
 #pragma unroll
     for (int U = 0; U < NU; U++) {
-        if (U < o.nu && U != hs) {   // wave-uniform
+        if (U < o.nu && U != hs && U != hs2) {   // wave-uniform
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U][0], bq[4 * U], acc, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U][1], bq[4 * U + 1], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U + 1][0], bq[4 * U + 2], acc2, 0, 0, 0);
@@ -175,8 +179,9 @@ __device__ __attribute__((always_inline)) inline void rq_refresh_B(double (&bq)[
 //   [0] cons    = g + 1 once the chain has read the partial tiles of interval g
 //   [1] commit  = g + 1 once the chain has committed the block of interval g to the X tile (and is done with its staged operands)
 //   [2] stop    != 0: leave the loop
-//   [4 + w]     iterations published by mfma wave w (its partial tile and its share of the staged operands are stored);
-//               one word PER WAVE: a shared counter would let a wave that runs ahead stand in for one that lags
+//   [4 + w]     iterations published by producer w: the six mfma waves (partial tiles), w = 6: the staging wave (small
+//               operands of the block); one word PER WAVE: a shared counter would let a wave that runs ahead stand in for
+//               one that lags
 // LDS operations of one wave complete in program order, so "data, then flag" needs no wait on the producer side and
 // "flag, then data" none on the consumer side.
 enum { RQ_CONS = 0, RQ_COMMIT = 1, RQ_STOP = 2, RQ_PARTS = 4 };
@@ -252,72 +257,93 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
 
     const int64_t gmax = a.num_iters * (int64_t)NB;
 
-    const bool lockstep = (a.dbg & 1) != 0;        // debug: one s_barrier per block on top of the flags
     if (wave == 4) {
-        // idle: wave 4 lands on the chain wave's SIMD and stays out of its way (it only joins the final barrier)
-        if (lockstep)
-            for (;;) { __syncthreads(); if (rq_sync_read(sy)[RQ_STOP]) break; }
+        // ========================================================================= staging role
+        // wave 4 shares the chain wave's SIMD (no matrix work there while the chain runs); it fetches the small operands
+        // of the next block -- strictly upper triangle of the 16 x 16 diagonal block of P0 (zeros elsewhere), diagonal,
+        // q/2, 1/P_ii -- one block ahead and drops them into the slot the chain has just released.
+        double d4[4], sq = 0.0, sr = 0.0, sd = 0.0;
+        auto stage_load = [&](int bn) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int st = lane + 64 * e;
+                d4[e] = P0[(16 * (int64_t)bn + (st >> 4)) * n16 + 16 * bn + (st & 15)];
+            }
+            if (lane < 16) { sq = q0[16 * (int64_t)bn + lane]; sr = rcp2d[16 * (int64_t)bn + lane];
+                             sd = P0[(16 * (int64_t)bn + lane) * n16 + 16 * bn + lane]; }
+        };
+        auto stage_store = [&](int buf) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int st = lane + 64 * e;
+                DU2[buf * 256 + st] = ((st & 15) > (st >> 4)) ? d4[e] : 0.0;
+            }
+            if (lane < 16) { hqb2[buf * 16 + lane] = 0.5 * sq; rtb2[buf * 16 + lane] = sr + sr; dg2[buf * 16 + lane] = sd; }
+        };
+        int published = 0;
+        stage_load(0);
+        stage_store(0);
+        rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
+        int b = 0;
+        for (int64_t g = 0; g < gmax; g++) {
+            const int bn = (b + 1 == NB) ? 0 : b + 1;
+            stage_load(bn);
+            bool stop = false;
+            for (;;) {     // slot (g + 1) & 1 was in use during interval g - 1
+                const rq_i4 s4 = rq_sync_read(sy);
+                if (s4[RQ_STOP]) { stop = true; break; }
+                if (s4[RQ_COMMIT] >= (int)g) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (stop) break;
+            stage_store((int)((g + 1) & 1));
+            rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
+            b = bn;
+        }
     } else if (wave != 0) {
         // =========================================================================== mfma role
         const int mw = wave < 4 ? wave - 1 : wave - 2;
-        const int st = wave < 4 ? tid - 64 : tid - 128;   // 0..383: staging slot of this thread
         const RqOwn own = rq_own(NB, CS, mw);
         v2d_ arP[2 * RQ_PFU];
         double bq[4 * RQ_PFU];
         long long qc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
 #define QTICK(slot) if (PROF && a.prof && wave == 2) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); qc[slot] += now_ - tq; tq = now_; }
-        // staging of the small operands of a block: strictly upper triangle of the diagonal block (256 entries over
-        // the first 256 staging threads), diagonal, q/2 and 1/P_ii of its 16 coordinates (threads 0..15); wave mw == 0
-        // also adds q/2 to its tile so that the summed tile is G + q/2 without a separate pass.
-        double st_d0 = 0.0, st_q = 0.0, st_r = 0.0, st_dg = 0.0;
-        double hqv[4] = {0.0, 0.0, 0.0, 0.0};
-        auto stage_load = [&](int bn) {
-            if (st < 256) st_d0 = P0[(16 * (int64_t)bn + (st >> 4)) * n16 + 16 * bn + (st & 15)];
-            if (st < 16) { st_q = q0[16 * (int64_t)bn + st]; st_r = rcp2d[16 * (int64_t)bn + st];
-                           st_dg = P0[(16 * (int64_t)bn + st) * n16 + 16 * bn + st]; }
-            if (mw == 0) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) hqv[v] = q0[16 * (int64_t)bn + (lane >> 4) + 4 * v];
-            }
-        };
-        auto stage_store = [&](int buf) {
-            if (st < 256) DU2[buf * 256 + st] = ((st & 15) > (st >> 4)) ? st_d0 : 0.0;
-            if (st < 16) { hqb2[buf * 16 + st] = 0.5 * st_q; rtb2[buf * 16 + st] = st_r + st_r; dg2[buf * 16 + st] = st_dg; }
-        };
         auto store_part = [&](v4d_ acc, int buf) {
             double *part = part2 + buf * RQ_NMW * 256 + mw * 256;
 #pragma unroll
-            for (int v = 0; v < 4; v++) part[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v] + 0.5 * hqv[v];   // hqv == 0 unless mw == 0
+            for (int v = 0; v < 4; v++) part[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
         };
         int published = 0;
         auto publish = [&]() { rq_sync_write(sy, RQ_PARTS + mw, ++published, lane); };
-        // prologue: full product of block row 0 (no hole); the fragments of iteration 0's product (row 1 % NB) follow
+        // prologue: full product of block row 0 (no hole); the fragments of iteration 0's product (row 1) follow
         rq_load_A<RQ_PFU>(arP, Apack2, KS, own, lane, 0);
         rq_load_B<RQ_PFU>(bq, Xs, own, lane);
-        stage_load(0);
         {
-            v4d_ acc = rq_product<RQ_PFU>(arP, bq, Apack2, KS, own, lane, -1, 1 % NB, v4d_{0.0, 0.0, 0.0, 0.0});
+            v4d_ acc = rq_product<RQ_PFU>(arP, bq, Apack2, KS, own, lane, -1, -1, 1, v4d_{0.0, 0.0, 0.0, 0.0});
             store_part(acc, 0);
-            stage_store(0);
             publish();
         }
+        // the two waves of a SIMD start half a product apart: while one is between products (store, flags, refresh) the
+        // other keeps the matrix pipe busy; nothing synchronises them afterwards, so the offset persists
+        if (wave > 4) __builtin_amdgcn_s_sleep(20);
         if (PROF && a.prof) tq = (long long)__builtin_amdgcn_s_memtime();
-        // iteration g: product of block row b(g+1) with hole b(g); prefetch of the fragments of row b(g+2)
+        // iteration g: product of block row b(g+1) without the blocks b(g) (being rewritten) and b(g-1) (rewritten last):
+        // the chain adds both; prefetch of the fragments of row b(g+2)
         int b = 0;
-        for (int64_t g = 0; g < gmax + (lockstep ? 1 : 0); g++) {
+        for (int64_t g = 0; g < gmax; g++) {
             const int bn = (b + 1 == NB) ? 0 : b + 1, bn2 = (bn + 1 == NB) ? 0 : bn + 1;
-            const int bprev = (b == 0) ? NB - 1 : b - 1;
+            const int bprev = (b == 0) ? NB - 1 : b - 1, bpp = (bprev == 0) ? NB - 1 : bprev - 1;
             QTICK(0)
             bool stop = false;
-            if (lockstep) { __syncthreads(); if (rq_sync_read(sy)[RQ_STOP]) break; }
-            if (g > 0) {
-                const int us = rq_slot(own, bprev);
+            if (g > 1) {
+                const int us = rq_slot(own, bpp);
                 if (us >= 0) {
-                    // the chain rewrote one of this wave's blocks during interval g - 1: wait for its commit
+                    // the chain rewrote one of this wave's blocks during interval g - 2: a whole interval ago, the wait is
+                    // a formality unless the wave runs far ahead
                     for (;;) {
                         const rq_i4 s4 = rq_sync_read(sy);
                         if (s4[RQ_STOP]) { stop = true; break; }
-                        if (s4[RQ_COMMIT] >= (int)g) break;
+                        if (s4[RQ_COMMIT] >= (int)g - 1) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
                     if (stop) break;
@@ -325,21 +351,19 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                 }
             }
             QTICK(1)
-            stage_load(bn);
-            v4d_ acc = rq_product<RQ_PFU>(arP, bq, Apack2, KS, own, lane, rq_slot(own, b), bn2, v4d_{0.0, 0.0, 0.0, 0.0});
+            v4d_ acc = rq_product<RQ_PFU>(arP, bq, Apack2, KS, own, lane, rq_slot(own, b), g > 0 ? rq_slot(own, bprev) : -1, bn2,
+                                          v4d_{0.0, 0.0, 0.0, 0.0});
             QTICK(2)
-            // the slots written now were last read by the chain during interval g - 1: partial tiles at its start
-            // (cons >= g), staged operands until its commit (commit >= g)
+            // the slot written now was read by the chain at the start of interval g - 1
             for (;;) {
                 const rq_i4 s4 = rq_sync_read(sy);
                 if (s4[RQ_STOP]) { stop = true; break; }
-                if (s4[RQ_CONS] >= (int)g && s4[RQ_COMMIT] >= (int)g) break;
+                if (s4[RQ_CONS] >= (int)g) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             if (stop) break;
             QTICK(3)
             store_part(acc, (int)((g + 1) & 1));
-            stage_store((int)((g + 1) & 1));
             publish();
             b = bn;
         }
@@ -367,12 +391,13 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
         const RqOwn cown = rq_own(NB, CS, RQ_NMW);
         v2d_ arC[2 * CSU];
         double bqC[4 * CSU];
-        double afix[4] = {0.0, 0.0, 0.0, 0.0};
+        double afix[4] = {0.0, 0.0, 0.0, 0.0}, afix2[4] = {0.0, 0.0, 0.0, 0.0};
+        v4d_ carry = {0.0, 0.0, 0.0, 0.0};      // the block rewritten last times the fragments of the row after next
         if (CS > 0) {
             rq_load_A<CSU>(arC, Apack2, KS, cown, lane, 0);
             rq_load_B<CSU>(bqC, Xs, cown, lane);
             // prologue share: product of block row 0 over the chain's blocks (no hole), into the chain's plane
-            v4d_ acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, -1, 1 % NB, v4d_{0.0, 0.0, 0.0, 0.0});
+            v4d_ acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, -1, -1, 1, v4d_{0.0, 0.0, 0.0, 0.0});
 #pragma unroll
             for (int v = 0; v < 4; v++) fixp[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
         } else {
@@ -387,29 +412,31 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
         int64_t t = 0;
         for (int64_t g = 0; g < gmax; g++) {
             const int bn = (b + 1 == NB) ? 0 : b + 1, bn2 = (bn + 1 == NB) ? 0 : bn + 1;
+            const int bprev = (b == 0) ? NB - 1 : b - 1;
             const int cur = (int)(g & 1);
-            const double *DU = DU2 + cur * 256, *rtb = rtb2 + cur * 16, *dgb = dg2 + cur * 16;
+            const double *DU = DU2 + cur * 256, *rtb = rtb2 + cur * 16, *dgb = dg2 + cur * 16, *hqb = hqb2 + cur * 16;
             const double *part = part2 + cur * RQ_NMW * 256;
             PROF_TICK(0)
-            if (lockstep) __syncthreads();
-            // partial tiles / staged operands of block b: all six mfma waves have published iteration g - 1
+            // partial tiles and staged operands of block b: every producer has published iteration g - 1
             for (;;) {
                 const rq_i4 p4 = rq_sync_read(sy + RQ_PARTS), p2 = rq_sync_read(sy + RQ_PARTS + 4);
                 int lo4 = p4[0] < p4[1] ? p4[0] : p4[1];
                 const int lo2 = p4[2] < p4[3] ? p4[2] : p4[3], lo1 = p2[0] < p2[1] ? p2[0] : p2[1];
                 lo4 = lo4 < lo2 ? lo4 : lo2;
                 lo4 = lo4 < lo1 ? lo4 : lo1;
+                lo4 = lo4 < p2[2] ? lo4 : p2[2];
                 if (lo4 >= (int)g + 1) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             PROF_TICK(1)
-            // ---- G + q/2 of the lane's own columns: its own plane, then the six partial tiles, in a fixed order
+            // ---- G + q/2 of the lane's own columns: its own plane, then the six partial tiles, in a fixed order, then q/2
             double gb[4], g0[4], xo[4], xn[4], rto[4], t2o[4];
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 double s = fixp[v * 64 + lane];
 #pragma unroll
                 for (int w = 0; w < RQ_NMW; w++) s += part[w * 256 + v * 64 + lane];
+                s += hqb[4 * v + gq];
                 gb[v] = s;
                 g0[v] = s;
             }
@@ -420,10 +447,11 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                 rto[v] = rtb[4 * v + gq];
                 t2o[v] = dgb[4 * v + gq];
             }
-            {   // A fragments for the fix-up of the NEXT block row: k-steps of this block
+            {   // A fragments of this block's k-steps in the next two block rows (the chain's contribution to both)
                 const double *ap = Apack + ((int64_t)bn * KS + 4 * b) * 64 + lane;
+                const double *ap2 = Apack + ((int64_t)bn2 * KS + 4 * b) * 64 + lane;
 #pragma unroll
-                for (int u = 0; u < 4; u++) afix[u] = ap[u * 64];
+                for (int u = 0; u < 4; u++) { afix[u] = ap[u * 64]; afix2[u] = ap2[u * 64]; }
             }
             if (b == 0 && !S.conv) S.sweeps++;
             PROF_TICK(2)
@@ -488,7 +516,6 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                 // tiles may already be overwritten) rebuilt in the chain's plane, all four lanes of a quad walk their
                 // restart redundantly (same values, benign identical LDS writes)
                 if (PROF) pc[6]++;
-                const double *hqb = hqb2 + cur * 16;
                 S.fcur = rq_quad_sum(fpart);
                 double *Gsc = fixp;
 #pragma unroll
@@ -520,17 +547,25 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv);
             if (PROF) pc[5]++;
             if (livem == 0ull || g + 1 >= gmax) break;
-            // ---- fix-up (the 4 k-steps of the block just committed) + the chain's own share of the next product
+            // ---- the chain's part of the next products: the block just committed times the fragments of the next TWO block
+            // rows (the mfma waves leave out the last two blocks rewritten: none of them ever waits for a fresh commit), and
+            // its own share of the next row
             {
-                v4d_ acc = {0.0, 0.0, 0.0, 0.0};
+                v4d_ acc = carry, acc2 = {0.0, 0.0, 0.0, 0.0};
                 const int xoff = (4 * b) * 64 + (lane >> 4) * 16 + (lane & 15);
+                double xb4[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afix[u], Xs[xoff + u * 64], acc, 0, 0, 0);
+                for (int u = 0; u < 4; u++) xb4[u] = Xs[xoff + u * 64];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afix[u], xb4[u], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(afix2[u], xb4[u], acc2, 0, 0, 0);
+                }
+                carry = acc2;
                 if (CS > 0) {
                     const int us = rq_slot(cown, b);
                     if (us >= 0) rq_refresh_B<CSU>(bqC, Xs, cown, lane, us);
-                    acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, us, bn2, acc);
+                    acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, us, (g > 0 ? rq_slot(cown, bprev) : -1), bn2, acc);
                 }
 #pragma unroll
                 for (int v = 0; v < 4; v++) fixp[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
@@ -540,7 +575,6 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             if (b == 0) t++;
         }
         rq_sync_write(sy, RQ_STOP, 1, lane);
-        if (lockstep) __syncthreads();
         const double ftot = rq_quad_sum(fpart);
         if (gq == 0 && live_r) {
             a.visits[gr] = S.visits; a.accepted[gr] = S.accepted; a.sweeps[gr] = S.sweeps;

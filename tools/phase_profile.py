@@ -44,7 +44,7 @@ if quad:
         if nm != '-':
             print('%-34s %10.0f cycles/block' % (nm, s[k] / max(s[5], 1)))
     print('%-34s %10.0f' % ('generic-path blocks', s[6]))
-    for k, nm in enumerate(['mfma wave 2: store + publish', 'mfma wave 2: commit wait + refresh', 'mfma wave 2: stage loads + product',
+    for k, nm in enumerate(['mfma wave 2: store + publish', 'mfma wave 2: refresh (+ wait)', 'mfma wave 2: product',
                             'mfma wave 2: slot-release wait']):
         print('%-34s %10.0f cycles/block' % (nm, s[8 + k] / max(s[5], 1)))
     sys.exit(0)
