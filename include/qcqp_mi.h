@@ -209,6 +209,8 @@ int qcqpmi_sync(qcqpmi_ctx *ctx);
 /* debug: enable in-kernel cycle counters of the phase-2 kernel / read their sums over tiles
  * (slots: 0 mfma, 1 feasible sets, 2 barrier, 3 sequential part, 4 barrier, 5 #blocks) */
 int qcqpmi_debug_profile(qcqpmi_ctx *ctx, int enable, int64_t *sums8);
+/* debug: per-wave event trace (cycle stamps) of tile 0 of the last profiled phase-2 run; count <= 2048 words */
+int qcqpmi_debug_trace(qcqpmi_ctx *ctx, int64_t *out, int count);
 
 /* ---- multi-GPU: one process per GPU, restarts sharded by global index, ONE collective at the
  * end to pick the global best (RCCL over xGMI; librccl is loaded lazily). --------------- */

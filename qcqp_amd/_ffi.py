@@ -55,6 +55,7 @@ PROTOTYPES = [
     ('qcqpmi_last_kernel_ms', C.c_int, [C.c_void_p, C.c_int, c_dp]),
     ('qcqpmi_sync', C.c_int, [C.c_void_p]),
     ('qcqpmi_debug_profile', C.c_int, [C.c_void_p, C.c_int, c_ip]),
+    ('qcqpmi_debug_trace', C.c_int, [C.c_void_p, c_ip, C.c_int]),
     ('qcqpmi_comm_unique_id', C.c_int, [c_bp]),
     ('qcqpmi_comm_init', C.c_int, [C.c_void_p, C.c_int, C.c_int, c_bp]),
     ('qcqpmi_comm_select_best', C.c_int, [C.c_void_p, C.c_double, C.c_int64, c_ip, c_dp, c_dp, c_dp]),

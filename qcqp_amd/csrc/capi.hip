@@ -380,13 +380,15 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
     // second-generation role-split kernel (cd_phase2_q.h): one mirrored equality class, positive diagonal, n a
     // multiple of 16, the tile resident in LDS -- the Boolean least squares family of the headline benchmark
     if (MAXC == 1 && c->K == 1 && c->objclass == 1 && c->symcls && c->n % 16 == 0 && !c->force_generic && !(c->dbg & 64)) {
-        const size_t q_lds = ((size_t)RQ_LDS_COMMON + (size_t)c->n16 * 16) * sizeof(double);
+        // (at least RQ_LDS_MIN: the product loop's look-ahead loads address a full-size tile)
+        size_t q_lds = ((size_t)RQ_LDS_COMMON + (size_t)c->n16 * 16) * sizeof(double);
+        if (q_lds < RQ_LDS_MIN) q_lds = RQ_LDS_MIN;
         const int NBq = (int)(c->n16 / 16);
         int cs = (c->dbg & 128) ? ((c->dbg >> 8) & 7) : 4;     // debug knob: blocks of the contraction the chain wave multiplies
         cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
         if (cs >= NBq) cs = 0;
         cs &= ~1;
-        if (q_lds <= 160 * 1024 && NBq - cs <= RQ_NMW * RQ_PFU && NBq >= 3) {
+        if (q_lds <= 160 * 1024 && NBq - cs <= RQ_NSIMD * RQ_MAXU && NBq >= 3) {
             used_lds = true;
             const bool prof_ = a1.prof != nullptr;
             auto k = cd_phase2_q_kernel<4, false>;
@@ -1169,7 +1171,8 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
     a.dbg = c->dbg;
     if (c->profile) {
         if (c->d_prof) { (void)hipFree(c->d_prof); c->d_prof = nullptr; }
-        if ((rc = dev_alloc(c, &c->d_prof, (size_t)(c->Rpad / 16) * 16))) return rc;
+        if ((rc = dev_alloc(c, &c->d_prof, (size_t)(c->Rpad / 16) * 16 + QCQPMI_TRACE_WORDS))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->d_prof + (size_t)(c->Rpad / 16) * 16, 0, QCQPMI_TRACE_WORDS * sizeof(long long), c->stream));
         a.prof = c->d_prof;
     }
     bool used_lds = false;
@@ -1262,6 +1265,15 @@ int qcqpmi_debug_profile(qcqpmi_ctx *c, int enable, int64_t *sums8) {
         for (int k = 0; k < 16; k++) sums8[k] = 0;
         for (size_t t = 0; t < h.size(); t++) sums8[t & 15] += h[t];
     }
+    return 0;
+}
+
+// debug: event trace of tile 0 written by the profiled phase-2 kernel (8 slices of 256 words, one per wave: entries of
+// 4 timestamps per block / product; see cd_phase2_q.h)
+int qcqpmi_debug_trace(qcqpmi_ctx *c, int64_t *out, int count) {
+    if (!c || !out || count < 0 || count > QCQPMI_TRACE_WORDS) return QCQPMI_EINVAL;
+    if (!c->d_prof || c->Rpad <= 0) return fail(c, QCQPMI_EINVAL, "no profiled run to trace");
+    HIPCHK(c, hipMemcpy(out, c->d_prof + (size_t)(c->Rpad / 16) * 16, (size_t)count * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

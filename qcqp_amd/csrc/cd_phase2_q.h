@@ -46,12 +46,23 @@
 
 namespace qcqpmi {
 
-constexpr int RQ_NMW = 6;     // mfma waves
-constexpr int RQ_PFU = 11;    // blocks an mfma wave can own (A and B operands in registers)
+constexpr int RQ_NMW = 6;     // mfma waves: two per SIMD on three SIMDs, taking turns
+constexpr int RQ_NSIMD = 3;   // SIMDs that multiply (the fourth runs the chain)
+constexpr int RQ_PFU = 5;     // A-fragment ring of an mfma wave: units (blocks of 16 coordinates) resident at a time
+constexpr int RQ_RND = 4;     // passes over the ring per product
+constexpr int RQ_PERS = 20;   // units whose B operands stay in registers; any others are re-read for every product
+constexpr int RQ_MAXU = 20;   // blocks one SIMD can own (<= RQ_RND * RQ_PFU): n = 1024 needs the chain to take >= 4 blocks.
+                              // (22 units = 5 passes + 2 re-read units measured 2.5 % slower at the same split, and smaller
+                              //  chain shares do not pay: the mfma waves become the bottleneck)
+constexpr int RQ_YIELD = 0;         // s_sleep argument (64 cycles each) of the yield between passes
+constexpr int RQ_PRIO_POLICY = 0;   // experiment: priorities inside the mfma role
 constexpr int RQ_CSMAX = 6;   // blocks the chain wave can own
 
 // LDS doubles besides the X tile
-constexpr int RQ_LDS_COMMON = 2 * RQ_NMW * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8;
+constexpr int RQ_LDS_COMMON = 2 * RQ_NSIMD * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8;
+
+// the product loop's look-ahead loads reach unit RQ_MAXU - 1 of the X tile (at the start of the allocation) whatever n is
+constexpr size_t RQ_LDS_MIN = (size_t)((RQ_NSIMD - 1) * 256 + (12 * (RQ_MAXU - 1) + 3) * 64 + 64) * 8;
 
 template <int CTRL>
 __device__ __attribute__((always_inline)) inline double rq_quad_bcast(double v) {
@@ -76,9 +87,7 @@ __device__ __attribute__((always_inline)) inline unsigned rq_quad_or(unsigned v)
 }
 
 // Ownership of the contraction: the chain wave multiplies the last CS blocks of 16 coordinates itself, the others are
-// dealt cyclically to the six mfma waves: block j < NB - CS belongs to wave j % 6, register slot j / 6.  (Cyclic: the
-// wave that owns the block the chain has just rewritten must wait for the commit; dealing the blocks round robin makes
-// that a different wave every block and keeps the two waves of a SIMD out of phase.)
+// dealt cyclically to the three multiplying SIMDs: block j < NB - CS belongs to SIMD j % 3, unit j / 3.
 struct RqOwn {
     int first;    // first owned block
     int stride;   // distance between owned blocks
@@ -91,8 +100,8 @@ __device__ __attribute__((always_inline)) inline RqOwn rq_own(int NB, int CS, in
     const int cs = CS < NB ? CS : 0;
     const int rest = NB - cs;
     o.NB = NB;
-    if (mw >= RQ_NMW) { o.first = rest; o.stride = 1; o.nu = cs; }
-    else { o.first = mw; o.stride = RQ_NMW; o.nu = mw < rest ? (rest - mw + RQ_NMW - 1) / RQ_NMW : 0; }
+    if (mw >= RQ_NSIMD) { o.first = rest; o.stride = 1; o.nu = cs; }
+    else { o.first = mw; o.stride = RQ_NSIMD; o.nu = mw < rest ? (rest - mw + RQ_NSIMD - 1) / RQ_NSIMD : 0; }
     return o;
 }
 
@@ -216,6 +225,8 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
     constexpr int MAXC = 1;
     constexpr int CSU = CS > 0 ? CS : 1;
     extern __shared__ double smem[];
+#define RQ_TRACE(idx, e) if (PROF && a.prof && blockIdx.x == 0 && (idx) < 32 && (threadIdx.x & 63) == 0)                       \
+        a.prof[(int64_t)gridDim.x * 16 + (threadIdx.x >> 6) * 256 + 8 * (idx) + (e)] = (long long)__builtin_amdgcn_s_memtime();
     const DevProblem &P = a.P;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
     // ---- dynamic LDS carve-up
     double *sp = smem;
     double *Xs = sp; sp += n16 * 16;
-    double *part2 = sp; sp += 2 * RQ_NMW * 256;   // partial G tiles of the mfma waves, [v][4 r + g], double-buffered
+    double *part2 = sp; sp += 2 * RQ_NSIMD * 256; // partial G tiles (one per multiplying SIMD and product), [v][4 r + g], by product parity
     double *fixp = sp; sp += 256;                  // the chain wave's own plane (fix-up + its share); the generic path's G tile
     double *DU2 = sp; sp += 2 * 256;               // strictly upper triangle of the diagonal block (zeros elsewhere), by parity
     double *dg2 = sp; sp += 2 * 16;                // P0[i,i]
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
         const int64_t g = tile * 16 + tid;
         slk[tid] = (g < a.R) ? a.slack[g] : 0.0;
     }
-    if (tid < 16) *(volatile rq_lds_int *)(sy + tid) = 0;
+    if (tid < 16) *(volatile rq_lds_int *)(sy + tid) = (tid >= RQ_PARTS && tid < RQ_PARTS + 3) ? -1 : 0;   // words of the even-product waves start odd
     __syncthreads();
     if (tid < 16) {
         FeasSet<MAXC> C;
@@ -298,78 +309,151 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             if (stop) break;
             stage_store((int)((g + 1) & 1));
             rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
+            RQ_TRACE(g, 0)
             b = bn;
         }
     } else if (wave != 0) {
         // =========================================================================== mfma role
-        const int mw = wave < 4 ? wave - 1 : wave - 2;
-        const RqOwn own = rq_own(NB, CS, mw);
+        // The two waves of a SIMD TAKE TURNS: wave parity pw computes the products i = pw, pw + 2, ... (product i = block
+        // row b(i), consumed by the chain in interval i) over ALL blocks of its SIMD, alone on the matrix pipe; while it
+        // stores, waits and loads, its partner multiplies.  B operands come straight from the X tile one unit ahead of the
+        // MFMAs that use them (the partner hides the start-up); A fragments live in a ring of RQ_PFU units, refilled in
+        // place: first with the second half of the same block row, then with the first half of the row of product i + 2.
+        const int sm = wave < 4 ? wave - 1 : wave - 5;     // SIMD of the pair (waves w and w + 4 share one)
+        const int pw = wave < 4 ? 0 : 1;
+        const int mw = wave < 4 ? wave - 1 : wave - 2;     // progress word
+        const RqOwn own = rq_own(NB, CS, sm);
         v2d_ arP[2 * RQ_PFU];
-        double bq[4 * RQ_PFU];
         long long qc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
-#define QTICK(slot) if (PROF && a.prof && wave == 2) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); qc[slot] += now_ - tq; tq = now_; }
-        auto store_part = [&](v4d_ acc, int buf) {
-            double *part = part2 + buf * RQ_NMW * 256 + mw * 256;
+#define QTICK(slot) if (PROF && a.prof && (wave == 2 || wave == 6)) { long long now_ = (long long)__builtin_amdgcn_s_memtime(); qc[slot] += now_ - tq; tq = now_; }
+        // No address arithmetic and no LDS traffic in the product loop.  Unit u of this SIMD is block sm + 3 u:
+        //   B operands: PERSISTENT in registers (4 per unit); a product only re-reads the (at most two) blocks committed
+        //   since this wave's previous product;
+        //   A fragments of block row `row`: buffer loads, descriptor = Apack2, scalar offset = row * KS * 512 + block * 2048
+        //   (one s_add per unit), vector offset = lane * 16, through a ring of RQ_PFU units.  Units past the owned ones
+        //   read the next block row, or zeros past the end of the buffer: loaded, never used.
+        const unsigned vlane = (unsigned)lane * 16u;
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Apack2), 0, NB * KS * 512, 0x00020000);
+        // (three opaque LDS bases 8 units apart keep every operand read within the 16-bit immediate of ds_read: no
+        //  per-unit address registers)
+        typedef __attribute__((address_space(3))) const double rq_lds_cd;
+        rq_lds_cd *xbase = (rq_lds_cd *)(Xs + (lane >> 4) * 16 + (lane & 15) + sm * 256);
+        rq_lds_cd *xb3[3] = {xbase, xbase + 8 * 12 * 64, xbase + 16 * 12 * 64};
+        asm volatile("" : "+v"(xb3[0]), "+v"(xb3[1]), "+v"(xb3[2]));
+        const int rowstride = KS * 512;
+        typedef unsigned rq_u4 __attribute__((ext_vector_type(4)));
+#define RQ_LDA(dst, soff, vo) { const rq_u4 t0_ = __builtin_amdgcn_raw_buffer_load_b128(arsrc, (vo), (soff), 0);           \
+                                const rq_u4 t1_ = __builtin_amdgcn_raw_buffer_load_b128(arsrc, (vo) + 1024u, (soff), 0);   \
+                                (dst)[0] = __builtin_bit_cast(v2d_, t0_); (dst)[1] = __builtin_bit_cast(v2d_, t1_); }
+        double bq[4 * RQ_PERS], bx[RQ_MAXU > RQ_PERS ? 4 * (RQ_MAXU - RQ_PERS) : 4];
 #pragma unroll
-            for (int v = 0; v < 4; v++) part[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
-        };
-        int published = 0;
-        auto publish = [&]() { rq_sync_write(sy, RQ_PARTS + mw, ++published, lane); };
-        // prologue: full product of block row 0 (no hole); the fragments of iteration 0's product (row 1) follow
-        rq_load_A<RQ_PFU>(arP, Apack2, KS, own, lane, 0);
-        rq_load_B<RQ_PFU>(bq, Xs, own, lane);
-        {
-            v4d_ acc = rq_product<RQ_PFU>(arP, bq, Apack2, KS, own, lane, -1, -1, 1, v4d_{0.0, 0.0, 0.0, 0.0});
-            store_part(acc, 0);
-            publish();
-        }
-        // the two waves of a SIMD start half a product apart: while one is between products (store, flags, refresh) the
-        // other keeps the matrix pipe busy; nothing synchronises them afterwards, so the offset persists
-        if (wave > 4) __builtin_amdgcn_s_sleep(20);
+        for (int u = 0; u < RQ_PERS; u++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq[4 * u + q] = xb3[u >> 3][(12 * (u & 7) + q) * 64];
+        int row = pw % NB;
+#pragma unroll
+        for (int U = 0; U < RQ_PFU; U++) RQ_LDA(arP + 2 * U, row * rowstride + (sm + RQ_NSIMD * U) * 2048, vlane)
         if (PROF && a.prof) tq = (long long)__builtin_amdgcn_s_memtime();
-        // iteration g: product of block row b(g+1) without the blocks b(g) (being rewritten) and b(g-1) (rewritten last):
-        // the chain adds both; prefetch of the fragments of row b(g+2)
-        int b = 0;
-        for (int64_t g = 0; g < gmax; g++) {
-            const int bn = (b + 1 == NB) ? 0 : b + 1, bn2 = (bn + 1 == NB) ? 0 : bn + 1;
-            const int bprev = (b == 0) ? NB - 1 : b - 1, bpp = (bprev == 0) ? NB - 1 : bprev - 1;
+        for (int64_t i = pw; i < gmax; i += 2) {
+            // block row of product i + 2 and the two blocks the chain supplies itself (being rewritten / rewritten last)
+            int row2 = row + 2; row2 = row2 >= NB ? row2 - NB : row2;
+            const int h1 = (i >= 1) ? (row == 0 ? NB - 1 : row - 1) : -1;
+            const int h2 = (i >= 2) ? (h1 == 0 ? NB - 1 : h1 - 1) : -1;
+            // ... and the two committed since this wave's previous product (its holes then): their operands are stale
+            const int r1 = (i >= 3) ? (h2 == 0 ? NB - 1 : h2 - 1) : -1;
+            const int r2 = (i >= 4) ? (r1 == 0 ? NB - 1 : r1 - 1) : -1;
+            // units this product leaves out: the two holes (when this SIMD owns them) and everything past the owned units
+            unsigned skip = ~0u << own.nu, fresh = 0u;
+            if (h1 >= 0 && h1 % RQ_NSIMD == sm && h1 >= own.first) skip |= 1u << ((h1 - own.first) / RQ_NSIMD);
+            if (h2 >= 0 && h2 % RQ_NSIMD == sm && h2 >= own.first) skip |= 1u << ((h2 - own.first) / RQ_NSIMD);
+            if (r1 >= 0 && r1 % RQ_NSIMD == sm && r1 >= own.first) fresh |= 1u << ((r1 - own.first) / RQ_NSIMD);
+            if (r2 >= 0 && r2 % RQ_NSIMD == sm && r2 >= own.first) fresh |= 1u << ((r2 - own.first) / RQ_NSIMD);
+            fresh &= ~(~0u << own.nu);
+            const int so1 = row * rowstride + sm * 2048, so2 = row2 * rowstride + sm * 2048;
             QTICK(0)
+            RQ_TRACE(i, 0)
             bool stop = false;
-            if (g > 1) {
-                const int us = rq_slot(own, bpp);
-                if (us >= 0) {
-                    // the chain rewrote one of this wave's blocks during interval g - 2: a whole interval ago, the wait is
-                    // a formality unless the wave runs far ahead
-                    for (;;) {
-                        const rq_i4 s4 = rq_sync_read(sy);
-                        if (s4[RQ_STOP]) { stop = true; break; }
-                        if (s4[RQ_COMMIT] >= (int)g - 1) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (stop) break;
-                    rq_refresh_B<RQ_PFU>(bq, Xs, own, lane, us);
+            if (i >= 3) {
+                // every block except the two holes must be final: the latest one was committed in interval i - 3
+                for (;;) {
+                    const rq_i4 s4 = rq_sync_read(sy);
+                    if (s4[RQ_STOP]) { stop = true; break; }
+                    if (s4[RQ_COMMIT] >= (int)i - 2) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (stop) break;
+                RQ_TRACE(i, 1)
+                if (fresh) {
+#pragma unroll
+                    for (int u = 0; u < RQ_PERS; u++)
+                        if ((fresh >> u) & 1u) {   // wave-uniform
+#pragma unroll
+                            for (int q = 0; q < 4; q++) bq[4 * u + q] = xb3[u >> 3][(12 * (u & 7) + q) * 64];
+                        }
                 }
             }
+#pragma unroll
+            for (int u = RQ_PERS; u < RQ_MAXU; u++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) bx[4 * (u - RQ_PERS) + q] = xb3[u >> 3][(12 * (u & 7) + q) * 64];
             QTICK(1)
-            v4d_ acc = rq_product<RQ_PFU>(arP, bq, Apack2, KS, own, lane, rq_slot(own, b), g > 0 ? rq_slot(own, bprev) : -1, bn2,
-                                          v4d_{0.0, 0.0, 0.0, 0.0});
-            QTICK(2)
-            // the slot written now was read by the chain at the start of interval g - 1
-            for (;;) {
-                const rq_i4 s4 = rq_sync_read(sy);
-                if (s4[RQ_STOP]) { stop = true; break; }
-                if (s4[RQ_CONS] >= (int)g) break;
-                __builtin_amdgcn_s_sleep(1);
+            RQ_TRACE(i, 2)
+            v4d_ acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc;    // two chains: a wave issues an MFMA every >= 64 cycles anyway
+#pragma unroll
+            for (int third = 0; third < RQ_RND; third++) {
+                // Two experiments kept behind constants, both without effect on MI355X ("matrix pipe arbitration"):
+                // a yield (s_sleep) between passes and s_setprio by deadline.  A wave's MFMAs run ahead of the pipe in a deep
+                // queue, and the later VALU work of a wave that has MFMAs queued (adds, store, flag) is served only when the
+                // partner's queued stream has drained: occasionally a finished product is published ~5 k cycles late.
+                if (RQ_YIELD && third > 0) __builtin_amdgcn_s_sleep(RQ_YIELD);
+                if (RQ_PRIO_POLICY && third == 0) __builtin_amdgcn_s_setprio(0);
+                if (RQ_PRIO_POLICY && third == 1) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                for (int U = 0; U < RQ_PFU; U++) {
+                    const int u = RQ_PFU * third + U;
+                    if (u < RQ_MAXU && !((skip >> u) & 1u)) {   // wave-uniform
+                        const double *bu = u < RQ_PERS ? bq + 4 * u : bx + 4 * (u < RQ_MAXU ? u - RQ_PERS : 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arP[2 * U][0], bu[0], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(arP[2 * U][1], bu[1], acc1, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arP[2 * U + 1][0], bu[2], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(arP[2 * U + 1][1], bu[3], acc1, 0, 0, 0);
+                    }
+                    // unconditional refill of the ring slot: the unit RQ_PFU further on, then the first units of row2
+                    if (third < RQ_RND - 1) { if (u + RQ_PFU < RQ_MAXU) RQ_LDA(arP + 2 * U, so1 + RQ_NSIMD * 2048 * (u + RQ_PFU), vlane) }
+                    else RQ_LDA(arP + 2 * U, so2 + RQ_NSIMD * 2048 * U, vlane)
+                }
             }
-            if (stop) break;
+            if (RQ_PRIO_POLICY) __builtin_amdgcn_s_setprio(3);
+            acc = acc + acc1;
+            QTICK(2)
+            RQ_TRACE(i, 3)
+            if (i >= 2) {
+                // the slot of this wave (parity) held product i - 2: read by the chain at the start of interval i - 2
+                for (;;) {
+                    const rq_i4 s4 = rq_sync_read(sy);
+                    if (s4[RQ_STOP]) { stop = true; break; }
+                    if (s4[RQ_CONS] >= (int)i - 1) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (stop) break;
+            }
             QTICK(3)
-            store_part(acc, (int)((g + 1) & 1));
-            publish();
-            b = bn;
+            RQ_TRACE(i, 4)
+            {
+                double *part = part2 + (int)(i & 1) * RQ_NSIMD * 256 + sm * 256;
+#pragma unroll
+                for (int v = 0; v < 4; v++) part[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
+            }
+            RQ_TRACE(i, 5)
+            rq_sync_write(sy, RQ_PARTS + mw, (int)i + 1, lane);
+            RQ_TRACE(i, 6)
+            if (RQ_PRIO_POLICY) __builtin_amdgcn_s_setprio(0);
+            row = row2;
         }
-        if (PROF && a.prof && tid == 128)
-            for (int k = 0; k < 8; k++) a.prof[tile * 16 + 8 + k] = qc[k];
+        if (PROF && a.prof && (tid == 128 || tid == 384))   // the elder and the younger wave of one pair
+            for (int k = 0; k < 4; k++) a.prof[tile * 16 + (tid == 128 ? 8 : 12) + k] = qc[k];
 #undef QTICK
+#undef RQ_LDA
     } else {
         // ========================================================================== chain role
         __builtin_amdgcn_s_setprio(3);
@@ -388,7 +472,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
         if (live_r) S.conv = a.flag[gr] ? false : true;
         // tracked objective: the four lanes of a quad hold partial sums; lane g == 0 starts from the evaluated value
         double fpart = (live_r && gq == 0) ? a.f0cur[gr] : 0.0;
-        const RqOwn cown = rq_own(NB, CS, RQ_NMW);
+        const RqOwn cown = rq_own(NB, CS, RQ_NSIMD);
         v2d_ arC[2 * CSU];
         double bqC[4 * CSU];
         double afix[4] = {0.0, 0.0, 0.0, 0.0}, afix2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -415,27 +499,30 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             const int bprev = (b == 0) ? NB - 1 : b - 1;
             const int cur = (int)(g & 1);
             const double *DU = DU2 + cur * 256, *rtb = rtb2 + cur * 16, *dgb = dg2 + cur * 16, *hqb = hqb2 + cur * 16;
-            const double *part = part2 + cur * RQ_NMW * 256;
+            const double *part = part2 + cur * RQ_NSIMD * 256;
             PROF_TICK(0)
-            // partial tiles and staged operands of block b: every producer has published iteration g - 1
+            RQ_TRACE(g, 0)
+            // partial tiles (product g: the three waves whose turn it was) and staged operands of block b
             for (;;) {
                 const rq_i4 p4 = rq_sync_read(sy + RQ_PARTS), p2 = rq_sync_read(sy + RQ_PARTS + 4);
                 int lo4 = p4[0] < p4[1] ? p4[0] : p4[1];
                 const int lo2 = p4[2] < p4[3] ? p4[2] : p4[3], lo1 = p2[0] < p2[1] ? p2[0] : p2[1];
                 lo4 = lo4 < lo2 ? lo4 : lo2;
                 lo4 = lo4 < lo1 ? lo4 : lo1;
-                lo4 = lo4 < p2[2] ? lo4 : p2[2];
-                if (lo4 >= (int)g + 1) break;
+                // an mfma wave publishes i + 1 after product i and only computes every other product: "all six >= g" says the
+                // three waves of parity g have delivered product g (their values jump by 2)
+                if (lo4 >= (int)g && p2[2] >= (int)g + 1) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             PROF_TICK(1)
-            // ---- G + q/2 of the lane's own columns: its own plane, then the six partial tiles, in a fixed order, then q/2
+            RQ_TRACE(g, 1)
+            // ---- G + q/2 of the lane's own columns: its own plane, then the three partial tiles, in a fixed order, then q/2
             double gb[4], g0[4], xo[4], xn[4], rto[4], t2o[4];
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 double s = fixp[v * 64 + lane];
 #pragma unroll
-                for (int w = 0; w < RQ_NMW; w++) s += part[w * 256 + v * 64 + lane];
+                for (int w = 0; w < RQ_NSIMD; w++) s += part[w * 256 + v * 64 + lane];
                 s += hqb[4 * v + gq];
                 gb[v] = s;
                 g0[v] = s;
@@ -544,6 +631,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             }
             rq_sync_write(sy, RQ_COMMIT, (int)g + 1, lane);   // block b is in the X tile; its staged operands are free
             PROF_TICK(4)
+            RQ_TRACE(g, 2)
             const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv);
             if (PROF) pc[5]++;
             if (livem == 0ull || g + 1 >= gmax) break;
@@ -571,6 +659,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                 for (int v = 0; v < 4; v++) fixp[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
             }
             PROF_TICK(7)
+            RQ_TRACE(g, 3)
             b = bn;
             if (b == 0) t++;
         }

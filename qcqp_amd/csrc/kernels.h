@@ -55,6 +55,9 @@ struct EvalArgs {
     int nplanes;            // (dense_products_kernel<2>); the kernel then only adds q0'x + r0 and the constraints
 };
 
+// debug trace of the profiled phase-2 kernel: words appended to the prof buffer (8 waves x 64 entries x 4 stamps)
+#define QCQPMI_TRACE_WORDS 2048
+
 struct CdArgs {
     DevProblem P;
     double *X;

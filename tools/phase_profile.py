@@ -44,9 +44,9 @@ if quad:
         if nm != '-':
             print('%-34s %10.0f cycles/block' % (nm, s[k] / max(s[5], 1)))
     print('%-34s %10.0f' % ('generic-path blocks', s[6]))
-    for k, nm in enumerate(['mfma wave 2: store + publish', 'mfma wave 2: refresh (+ wait)', 'mfma wave 2: product',
-                            'mfma wave 2: slot-release wait']):
-        print('%-34s %10.0f cycles/block' % (nm, s[8 + k] / max(s[5], 1)))
+    for w, base in (('2 (elder)', 8), ('6 (younger)', 12)):
+        for k, nm in enumerate(['store + publish', 'commit wait + refresh', 'product', 'slot-release wait']):
+            print('%-34s %10.0f cycles/block' % ('mfma wave %s: %s' % (w, nm), s[base + k] / max(s[5], 1)))
     sys.exit(0)
 names = (['mfma', 'stage', 'barrier1', 'sequential', 'barrier2'] if generic
          else ['chain', 'barrier wait', 'fix-up + preload', '-'])
