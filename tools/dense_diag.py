@@ -1,5 +1,5 @@
 """Diagnostic: dense path vs oracle, one phase-1 sweep, first coordinate where a restart leaves the oracle's trajectory.
-usage: python tools/dense_diag.py [n] [m] [R]"""
+usage: python tools/dense_diag.py [n] [m] [R] [family: dense | beam]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +12,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 130
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 seed, first = 13, 5
-funcs, _, _ = problems.dense_indefinite(n, m, seed=11)
+fam = sys.argv[4] if len(sys.argv) > 4 else 'dense'
+if fam == 'beam':
+    funcs, _, _ = problems.beamforming(n // 2, m, max(m // 3, 1), seed=3)
+else:
+    funcs, _, _ = problems.dense_indefinite(n, m, seed=11)
 e = Engine(QCQPForm.from_arrays(funcs))
 prob = orc.Problem(funcs)
 X0 = 1.5 * np.random.RandomState(3).randn(n, R)
