@@ -53,6 +53,113 @@ def profiled_counters():
     return best
 
 
+# ------------------------------------------------------------------------------------- secondary records
+def secondary_records(device):
+    """Bounded measurements of the other BASELINE.json configurations on ONE GPU (not part of `value`): the share of
+    one rank, inputs resident, a few seconds in total.  Each record names its workload, kernel time and roofline."""
+    import numpy as np
+    from qcqp_amd import lowrank, problems
+    from qcqp_amd.engine import Engine
+    from qcqp_amd.form import QCQPForm
+    recs = []
+    # configs[2]: MAXCUT n = 2000, 8192 Goemans-Williamson samples: x = F xi (MFMA GEMM sampler) + batched evaluation
+    try:
+        n, S, rk = 2000, 8192, 40
+        funcs, _, _ = problems.maxcut(n, 0.5, seed=1)
+        e = Engine(QCQPForm.from_arrays(funcs), device=device)
+        rs = np.random.RandomState(5)
+        V = rs.randn(n, rk)
+        V /= np.linalg.norm(V, axis=1)[:, None]
+        F = np.zeros((n, n))
+        F[:, :rk] = V
+        mu = np.zeros(n)
+        e.sdr_sample(mu, F, S, seed=1, first_index=0)
+        e.eval()
+        e.sync()
+        reps, t_s, t_e = 3, 0.0, 0.0
+        t0 = time.perf_counter()
+        for k in range(reps):
+            e.sdr_sample(mu, F, S, seed=2 + k, first_index=0)
+            t_s += e.kernel_ms(Engine.KERNEL_SDR)
+            e.eval()
+            t_e += e.kernel_ms(Engine.KERNEL_EVAL)
+        e.sync()
+        dt = time.perf_counter() - t0
+        fl = 2.0 * n * n * S
+        recs.append({'config': 'BASELINE.json configs[2]: MAXCUT G(2000, 0.5), 8192 SDR samples drawn and evaluated on one GPU',
+                     'metric': 'samples drawn + evaluated / s', 'value': reps * S / dt, 'unit': 'samples/s',
+                     'sampler_kernel_ms': t_s / reps, 'eval_kernel_ms': t_e / reps,
+                     'roofline': {'bound': 'mfma', 'kernel': 'dense_products_kernel (sampler x = mu + F xi; evaluation X^T P X)',
+                                  'achieved': fl / 1e12 / (t_s / reps / 1e3), 'achieved_eval': fl / 1e12 / (t_e / reps / 1e3),
+                                  'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / 1e12 / (t_s / reps / 1e3) / FP64_PEAK_TFLOPS,
+                                  'algorithmic_flops_per_launch': fl}})
+        del e
+    except Exception as ex:      # a secondary record must never take the headline down
+        recs.append({'config': 'configs[2]', 'error': repr(ex)})
+    # configs[3]: secondary-user beamforming, 512 antennas (n = 1024 real), 16 + 64 constraints, improve(ADMM, rho = 1)
+    try:
+        funcs, _, _ = problems.beamforming(512, 16, 64, seed=1)
+        form = QCQPForm.from_arrays(funcs)
+        e = Engine(form, device=device)
+        t0 = time.perf_counter()
+        lam, Bv, qhat, info = lowrank.reduced_bases(e, form)
+        e.admm_set_basis(lam, Bv, qhat)
+        t_setup = time.perf_counter() - t0
+        R, iters = 1024, 40
+        e.randn(R, seed=3)
+        X0 = e.download()
+        e.admm_run(1.0, None, phase1=True, num_iters=2)
+        e.upload(X0)
+        e.sync()
+        t0 = time.perf_counter()
+        out = e.admm_run(1.0, None, phase1=True, num_iters=iters)
+        e.sync()
+        dt = time.perf_counter() - t0
+        its = float(out['iters1'].sum() + out['iters2'].sum())
+        rp = int(info['rp'])
+        bytes_it = 8.0 * (4.0 * form.n + 6.0 * form.m * rp)      # z in/out twice (two GEMM passes), reduced coordinates + duals
+        recs.append({'config': 'BASELINE.json configs[3]: beamforming 512 antennas, m = 80, improve(ADMM, rho=1), 1024 restarts on one GPU',
+                     'metric': 'restart-iterations / s', 'value': its / dt, 'unit': 'restart-iterations/s',
+                     'setup_s': t_setup, 'setup': 'reduced bases (rank <= 2) by device products + Jacobi, no eigendecomposition',
+                     'iterations_per_restart': its / R, 'feasible': int((out['maxviol'] < 1e-2).sum()),
+                     'secular_kernel_ms': e.kernel_ms(Engine.KERNEL_ADMM),
+                     'roofline': {'bound': 'hbm', 'kernel': 'gemm_pk_kernel + admm_secular_small_kernel + admm_zupdate_kernel',
+                                  'achieved': its * bytes_it / dt / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                                  'frac': its * bytes_it / dt / 1e9 / 8000.0,
+                                  'algorithmic_bytes_per_restart_iteration': bytes_it,
+                                  'note': 'launch- and tile-bound at this size (7 short launches per iteration), far below HBM'}})
+        del e
+    except Exception as ex:
+        recs.append({'config': 'configs[3]', 'error': repr(ex)})
+    # configs[4] family at 1/16 linear size: dense indefinite n = 1024, m = 256 generated on the device, CD on 512 restarts
+    try:
+        n, m, R = 1024, 256, 512
+        form = problems.dense_indefinite_generated(n, m, seed=7)
+        e = Engine(form, device=device)
+        e.randn(R, seed=5)
+        e.cd_run(phase1=True, num_iters=1, seed=5)
+        e.randn(R, seed=6)
+        e.sync()
+        t0 = time.perf_counter()
+        out = e.cd_run(phase1=True, num_iters=2, seed=6)
+        e.sync()
+        dt = time.perf_counter() - t0
+        sw = float(out['sweeps1'].sum()) + float(out['visits2'].sum()) / n
+        fl = sw * 2.0 * n * n * (m + 1)
+        recs.append({'config': 'BASELINE.json configs[4] family at n = 1024, m = 256 (full size is 137.6 GB of matrices): dense indefinite '
+                               'QCQP generated on the device, COORD_DESCENT, 512 restarts, 2 sweeps per phase',
+                     'metric': 'restarts x coord-sweeps / s (phase 1 + phase 2)', 'value': sw / dt, 'unit': 'restart-sweeps/s',
+                     'roofline': {'bound': 'mfma', 'kernel': 'dense_products_kernel (G_k = P_k X for all k) + dense chain',
+                                  'achieved': fl / 1e12 / dt, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': fl / 1e12 / dt / FP64_PEAK_TFLOPS,
+                                  'algorithmic_flops_per_restart_sweep': 2.0 * n * n * (m + 1),
+                                  'timing': 'wall clock of the whole cd_run (products, chain, host loop over sweeps)'}})
+        del e
+    except Exception as ex:
+        recs.append({'config': 'configs[4]', 'error': repr(ex)})
+    return recs
+
+
 # ------------------------------------------------------------------------------------- CPU baselines
 def effective_cores():
     """Host cores this process may actually use: the affinity mask, cut down by the container's CPU quota
@@ -147,6 +254,7 @@ def main():
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--cpu-cores', type=int, default=0, help='host cores for the CPU baselines (0 = all usable, at most 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the bounded records of the other BASELINE.json configs')
     args = ap.parse_args()
 
     from qcqp_amd import dist, problems
@@ -228,7 +336,7 @@ def main():
                                'qcqp.py:114): not counted in value'},
             'best': {'objective': best[1], 'max_violation': best[2], 'global_restart_index': best[0],
                      'step': best_step},
-            'roofline': {'bound': 'mfma', 'kernel': 'cd_phase2_rs_kernel', 'achieved': achieved,
+            'roofline': {'bound': 'mfma', 'kernel': eng.last_cd_kernel() or 'cd_general_kernel', 'achieved': achieved,
                          'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_PEAK_TFLOPS,
                          'traffic': pmc['traffic'] if pmc else None,
@@ -243,6 +351,8 @@ def main():
         if world > 1:
             res['roofline']['kernel_ms_per_launch_max_over_ranks'] = p2_ms_max / K
             res['roofline']['achieved_all_gpus'] = (flops_all / 1e12) / (p2_ms_max / 1e3) if p2_ms_max > 0 else 0.0
+        if world == 1 and not args.no_secondary:
+            res['secondary'] = secondary_records(local_rank)
         if not args.no_cpu_baseline:
             cores = args.cpu_cores or min(effective_cores(), 32)
             # the winning restart of the winning step again on the CPU: the cross-check of `best`

@@ -205,6 +205,9 @@ int qcqpmi_select_best(qcqpmi_ctx *ctx, double tol, int64_t *best_index, double 
  * which: 0 = eval, 1 = cd phase 1, 2 = cd phase 2, 3 = sdr sampling, 4 = admm secular kernel.  Returns the duration of
  * the most recent launch of that kernel in milliseconds. */
 int qcqpmi_last_kernel_ms(qcqpmi_ctx *ctx, int which, double *ms);
+/* name of the phase-2 kernel the most recent qcqpmi_cd_run dispatched to ("cd_phase2_q_kernel", "cd_phase2_rs_kernel",
+ * "" for the general / dense paths): static storage */
+const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *ctx);
 int qcqpmi_sync(qcqpmi_ctx *ctx);
 /* debug: enable in-kernel cycle counters of the phase-2 kernel / read their sums over tiles
  * (slots: 0 mfma, 1 feasible sets, 2 barrier, 3 sequential part, 4 barrier, 5 #blocks) */

@@ -142,6 +142,7 @@ struct qcqpmi_ctx {
     int rank = 0, world = 1;
     double *d_comm = nullptr;
     long long *d_prof = nullptr;
+    const char *last_cd2_kernel = "";     // name of the phase-2 kernel of the most recent cd run (bench / profiles)
     bool profile = false;
     int dbg = 0;
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
@@ -368,6 +369,7 @@ int launch_eval(qcqpmi_ctx *c, bool want_F) {
 template <int MAXC>
 int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool *used_rs = nullptr) {
     if (used_rs) *used_rs = false;
+    if (!phase1) c->last_cd2_kernel = "";
     dim3 grid((unsigned)(c->Rpad / 16)), block(256);
     if (phase1) {
         tic(c, 1);
@@ -398,6 +400,7 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
             tic(c, 2);
             hipLaunchKernelGGL(k, grid, dim3(512), q_lds, c->stream, a1, dp.Apack, dp.Apack2, dp.P0, dp.q0, dp.rcp2d);
             toc(c, 2);
+            c->last_cd2_kernel = "cd_phase2_q_kernel";
             HIPCHK(c, hipGetLastError());
             if (used_rs) *used_rs = true;
             return 0;
@@ -428,6 +431,7 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
         else if (c->objclass == 1) QM_RS(false, 1);
         else QM_RS(false, 2);
 #undef QM_RS
+        c->last_cd2_kernel = "cd_phase2_rs_kernel";
         HIPCHK(c, hipGetLastError());
         if (used_rs) *used_rs = true;
         return 0;
@@ -1243,6 +1247,8 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
     }
     return 0;
 }
+
+const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
 
 int qcqpmi_last_kernel_ms(qcqpmi_ctx *c, int which, double *ms) {
     if (!c || which < 0 || which > 4 || !ms) return QCQPMI_EINVAL;

@@ -268,6 +268,10 @@ class Engine(object):
         self._chk(self.L.qcqpmi_last_kernel_ms(self.h, int(which), _dp(ms)))
         return float(ms[0])
 
+    def last_cd_kernel(self):
+        """Name of the phase-2 kernel the most recent cd_run dispatched to ('' for the general / dense paths)."""
+        return (self.L.qcqpmi_last_cd_kernel(self.h) or b'').decode()
+
     def sync(self):
         self._chk(self.L.qcqpmi_sync(self.h))
 

@@ -23,7 +23,14 @@ def short(name):
     return name.split('(')[0].replace('void ', '').replace('qcqpmi::', '')[:60]
 
 
-out = {'tag': tag}
+import datetime
+import subprocess
+
+out = {'tag': tag, 'date': datetime.date.today().isoformat()}
+try:
+    out['git_commit'] = subprocess.check_output(['git', '-C', REPO, 'rev-parse', '--short', 'HEAD']).decode().strip()
+except Exception:
+    out['git_commit'] = None
 # ---- kernel statistics
 ks = find('stats', 'kernel_stats.csv')
 lines = []
@@ -37,6 +44,7 @@ if ks:
             float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, float(r['Percentage'])))
         if 'cd_phase2' in r['Name']:
             out['cd_phase2_avg_ms'] = float(r['AverageNs']) / 1e6
+            out['kernel'] = short(r['Name']).split('<')[0]
             out['cd_phase2_calls'] = int(r['Calls'])
     open(os.path.join(dst, tag + '_kernel_stats.csv'), 'w').write(open(ks).read())
 
@@ -91,7 +99,7 @@ bj = os.path.join(src, 'bench_under_profiler.json')
 if os.path.exists(bj) and os.path.getsize(bj):
     out['bench_under_profiler'] = json.load(open(bj))
 hdr = ['# rocprofv3 summary %s' % tag, '',
-       'Command: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline` (tools/profile_round.sh).',
+       'Command: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary` (tools/profile_round.sh).',
        'Pass 1 `--kernel-trace --stats`; passes 2-4 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc TCC_HIT_sum TCC_MISS_sum`',
        '(separate runs, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled (gfx950 reports half the bytes of',
        'wide coalesced reads); WRITE_SIZE is taken as is (uncalibrated).  Pass 5 `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`:',
