@@ -62,6 +62,32 @@ def secondary_records(device):
     from qcqp_amd.engine import Engine
     from qcqp_amd.form import QCQPForm
     recs = []
+    # the headline family with 4 tiles per CU: the hardware's workgroup queue refills a CU as soon as its tile of 16 restarts
+    # has converged, so the 1-workgroup-per-CU straggler effect of the headline (kernel time = slowest tile) is amortised
+    try:
+        n, R = 1024, 16384
+        funcs, _, _ = problems.boolean_least_squares(n, 256, seed=1)
+        e = Engine(QCQPForm.from_arrays(funcs), device=device)
+        e.randn(R, seed=90)
+        e.cd_run(phase1=True, seed=90)
+        sw = ms = 0.0
+        e.sync()
+        t0 = time.perf_counter()
+        for k in range(5):
+            e.randn(R, seed=91 + k)
+            out = e.cd_run(phase1=True, seed=91 + k)
+            sw += float(out['visits2'].sum()) / n
+            ms += e.kernel_ms(Engine.KERNEL_CD2)
+        e.sync()
+        dt = time.perf_counter() - t0
+        recs.append({'config': 'headline family (Boolean LS n=1024 m=256) with 16384 restarts on one GPU: 1024 tiles queued on 256 CUs',
+                     'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': sw / dt, 'unit': 'restart-sweeps/s',
+                     'roofline': {'bound': 'mfma', 'kernel': e.last_cd_kernel(), 'achieved': sw * 2.0 * n * n / 1e12 / (ms / 1e3),
+                                  'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': sw * 2.0 * n * n / 1e12 / (ms / 1e3) / FP64_PEAK_TFLOPS,
+                                  'kernel_ms_per_launch': ms / 5}})
+        del e
+    except Exception as ex:
+        recs.append({'config': 'headline family, 16384 restarts', 'error': repr(ex)})
     # configs[2]: MAXCUT n = 2000, 8192 Goemans-Williamson samples: x = F xi (MFMA GEMM sampler) + batched evaluation
     try:
         n, S, rk = 2000, 8192, 40
@@ -245,7 +271,7 @@ def cpu_baseline(n, m_rows, seed, winner, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--steps', type=int, default=250)      # ~1 s of timed work at N = 1
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--n', type=int, default=1024)
     ap.add_argument('--m-rows', type=int, default=256)
