@@ -164,9 +164,17 @@ int qcqpmi_admm_apply_constraints(qcqpmi_ctx *ctx, int p, const double *Vin, int
  * basis: out = R x n projections (host layout of qcqpmi_pop_download); the population is not changed.  (The reference's
  * own test examples/tests/one_constraint_qcqp.py exercises exactly this function.) */
 int qcqpmi_admm_onecons(qcqpmi_ctx *ctx, int64_t k, double *out);
+/* Device-side setup of the z-update for a non-diagonal P0: (2 (P0 + rho m I))^-1 -- the matrix the reference factorises
+ * with SuperLU (qcqp.py:224-227) -- by a Newton-Schulz iteration on the engine's own GEMM; kept packed inside the context.
+ * A following qcqpmi_admm_run with the same rho may then pass Minv = NULL.  resid_out: estimate of max |I - M X| reached;
+ * iters_out: iterations taken.  Fails (QCQPMI_EREFERENCE) if P0 + rho m I is not positive definite. */
+int qcqpmi_admm_zsolver_device(qcqpmi_ctx *ctx, double rho, int64_t max_iter, double *resid_out, int64_t *iters_out);
+/* lambda_min(P0) for the rho check / auto-rho of improve_admm (qcqp.py:262, 272: LA.eigh in the reference): Lanczos with
+ * full reorthogonalisation, the products P0 v on the device.  max_steps <= 0: up to n steps. */
+int qcqpmi_p0_lambda_min(qcqpmi_ctx *ctx, int64_t max_steps, double tol, double *lmin_out, int64_t *steps_out);
 int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, double viol_lim,
                     double rho, const double *Minv, int64_t *iters1, int64_t *iters2, double *f0,
-                    double *maxviol);
+                    double *maxviol);   /* Minv may be NULL if P0 is diagonal or after qcqpmi_admm_zsolver_device(rho) */
 
 /* Y = (sum_k w_k P_k) X for the resident population (w: m+1 weights, objective first; Y: R x n like
  * qcqpmi_pop_download).  Building block of the general SDP-relaxation solver (qcqp_amd/sdr.py: the gradient of

@@ -49,6 +49,8 @@ PROTOTYPES = [
     ('qcqpmi_admm_set_basis', C.c_int, [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp]),
     ('qcqpmi_admm_apply_constraints', C.c_int, [C.c_void_p, C.c_int, c_dp, C.c_int, c_dp]),
     ('qcqpmi_admm_onecons', C.c_int, [C.c_void_p, C.c_int64, c_dp]),
+    ('qcqpmi_admm_zsolver_device', C.c_int, [C.c_void_p, C.c_double, C.c_int64, c_dp, c_ip]),
+    ('qcqpmi_p0_lambda_min', C.c_int, [C.c_void_p, C.c_int64, C.c_double, c_dp, c_ip]),
     ('qcqpmi_admm_run', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double, c_dp,
                                   c_ip, c_ip, c_dp, c_dp]),
     ('qcqpmi_select_best', C.c_int, [C.c_void_p, C.c_double, c_ip, c_dp, c_dp, c_dp]),

@@ -273,18 +273,27 @@ class QCQP(object):
             constraint has rank <= 8 the iteration runs in the reduced bases (csrc/admm.h).  Otherwise, or with
             lowrank=False: full eigendecompositions, NumPy on the host like the reference (device_eigh=True:
             rocSOLVER's batched dsyevd on the device).
-          * the z-update solve (qcqp.py:224-227): for a diagonal P0 the inverse is formed on the device; otherwise
-            (2 (P0 + rho m I))^-1 is computed on the host like the reference's factorisation and applied by the engine's
-            GEMM."""
+          * the z-update solve (qcqp.py:224-227): (2 (P0 + rho m I))^-1 is formed on the device (element-wise for a diagonal
+            P0, otherwise a Newton-Schulz iteration on the engine's GEMM) and applied by the engine's GEMM;
+          * lambda_min(P0) for the rho check / auto-rho (qcqp.py:262, 272): Lanczos with device products.
+        host_setup=True computes both with NumPy/LAPACK where the reference does (bit-identical inputs for goldens)."""
         form = self.qcqp_form
         num_iters = kwargs.get('num_iters', 1000)
         viol_lim = kwargs.get('viol_lim', 1e4)
         tol = kwargs.get('tol', 1e-2)
         rho = kwargs.get('rho', None)
         phase1 = kwargs.get('phase1', True)
+        host_setup = kwargs.get('host_setup', False)     # True: eigh / inv through NumPy exactly where the reference calls LAPACK
         P0 = np.asarray(form.f0.P.todense()) if hasattr(form.f0.P, 'todense') else np.asarray(form.f0.P)
         p0_diag = not np.any(P0 - np.diag(np.diag(P0)))
-        lmb_min = float(np.min(np.diag(P0))) if p0_diag else float(np.min(np.linalg.eigh(P0)[0]))   # qcqp.py:262, 272
+        if p0_diag:
+            lmb_min = float(np.min(np.diag(P0)))
+        elif host_setup:
+            lmb_min = float(np.min(np.linalg.eigh(P0)[0]))   # qcqp.py:262, 272
+        else:
+            if getattr(form, '_lmb_min', None) is None:
+                form._lmb_min = self.engine.p0_lambda_min()[0]     # Lanczos, products on the device
+            lmb_min = form._lmb_min
         if rho is not None:
             if lmb_min + form.m * rho < 0:
                 raise Exception("rho parameter is too small, need at least %.3f." % rho)
@@ -323,11 +332,18 @@ class QCQP(object):
             log.info('admm setup: %s', mode)
         if p0_diag:
             Minv = None
-        else:
+        elif host_setup:
             if form.rho != rho or form.z_solver is None:
                 form.rho = rho
                 form.z_solver = np.linalg.inv(2. * (P0 + rho * form.m * np.eye(form.n)))   # qcqp.py:224-227
             Minv = form.z_solver
+            self._zsolver_rho = None      # the engine's device-side matrix is replaced by this one
+        else:
+            if getattr(self, '_zsolver_rho', None) != rho:
+                res, its = self.engine.admm_zsolver_device(rho)     # Newton-Schulz on the engine's GEMM
+                self._zsolver_rho = rho
+                log.info('admm z-solver on the device: %d iterations, residual %.2e', its, res)
+            Minv = None
         out = self.engine.admm_run(rho, Minv, phase1=phase1, num_iters=num_iters, tol=tol,
                                    viol_lim=viol_lim)
         self.last_stats = dict(out, method=s.ADMM, num_restarts=len(out['f0']), rho=rho, setup=getattr(self, '_admm_mode', None))

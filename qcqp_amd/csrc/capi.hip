@@ -142,6 +142,8 @@ struct qcqpmi_ctx {
     int rank = 0, world = 1;
     double *d_comm = nullptr;
     long long *d_prof = nullptr;
+    double ad_Minv_rho = 0.0;           // rho of the z-solver matrix formed by qcqpmi_admm_zsolver_device
+    bool ad_Minv_device = false;
     const char *last_cd2_kernel = "";     // name of the phase-2 kernel of the most recent cd run (bench / profiles)
     bool profile = false;
     int dbg = 0;
@@ -151,7 +153,7 @@ struct qcqpmi_ctx {
 
 namespace {
 
-void admm_free(qcqpmi_ctx *c);
+void admm_free(qcqpmi_ctx *c, bool keep_zsolver);
 
 int fail(qcqpmi_ctx *c, int code, const char *fmt, ...) {
     char buf[1024];
@@ -585,7 +587,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->comm);
     free_population(c);
-    admm_free(c);
+    admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
                     c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz};

@@ -191,8 +191,24 @@ class Engine(object):
         self._chk(self.L.qcqpmi_admm_onecons(self.h, int(k), _dp(out)))
         return np.ascontiguousarray(out.T)
 
+    def admm_zsolver_device(self, rho, max_iter=0):
+        """(2 (P0 + rho m I))^-1 formed on the device (Newton-Schulz on the engine's GEMM) and kept for admm_run(rho, None).
+        Returns (residual estimate, iterations)."""
+        res = np.zeros(1)
+        its = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.qcqpmi_admm_zsolver_device(self.h, float(rho), int(max_iter), _dp(res), _ip(its)))
+        return float(res[0]), int(its[0])
+
+    def p0_lambda_min(self, max_steps=0, tol=1e-12):
+        """lambda_min(P0) by Lanczos with device products (qcqp.py:262, 272).  Returns (value, steps)."""
+        v = np.zeros(1)
+        st = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.qcqpmi_p0_lambda_min(self.h, int(max_steps), float(tol), _dp(v), _ip(st)))
+        return float(v[0]), int(st[0])
+
     def admm_run(self, rho, Minv, phase1=True, num_iters=1000, tol=1e-2, viol_lim=1e4):
-        """Minv = (2 (P0 + rho m I))^-1 (n, n), or None when P0 is diagonal (formed on the device)."""
+        """Minv = (2 (P0 + rho m I))^-1 (n, n); None when P0 is diagonal (formed on the device) or after
+        admm_zsolver_device(rho)."""
         R = self.pop_size
         if Minv is not None:
             Minv = np.ascontiguousarray(Minv, dtype=np.float64)

@@ -380,3 +380,44 @@ def test_admm_reduced_basis_vs_full_eigenbasis(eng_mod, orc, nant, mh, ml, R):
             xa = prob.improve_admm(X0[:, r], num_iters=iters, rho=rho)
             assert rel(Xf[:, r], xa) < 1e-6, r
             assert rel(Xr[:, r], xa) < 1e-4, r
+
+
+@pytest.mark.parametrize('family', ['bls', 'dense', 'maxcut'])
+def test_admm_setup_on_device_vs_lapack(eng_mod, orc, family):
+    """What the reference asks LAPACK / SuperLU for in improve_admm (qcqp.py:224-227, 261-278), formed on the device:
+    lambda_min(P0) by Lanczos with device products against numpy.linalg.eigvalsh, and (2 (P0 + rho m I))^-1 by
+    Newton-Schulz on the engine's GEMM against numpy.linalg.inv THROUGH the iteration: the same ADMM run with the host
+    inverse handed in and with the device-side one must end on the same points (1e-6, the north-star tolerance)."""
+    from qcqp_amd import problems
+    if family == 'bls':
+        funcs = problems.boolean_least_squares(200, 50, seed=3)[0]       # P0 = A^T A: rank 50, lambda_min = 0
+    elif family == 'dense':
+        funcs = problems.dense_indefinite(96, 6, seed=5)[0]              # indefinite objective
+    else:
+        funcs = problems.maxcut(150, 0.5, seed=2)[0]
+    e = make(eng_mod, funcs)
+    P0 = np.asarray(funcs[0][0].todense() if hasattr(funcs[0][0], 'todense') else funcs[0][0], dtype=float)
+    P0 = (P0 + P0.T) / 2.
+    n, m = P0.shape[0], len(funcs) - 1
+    ev = np.linalg.eigvalsh(P0)
+    lmin, steps = e.p0_lambda_min()
+    assert abs(lmin - ev[0]) <= 1e-9 * max(1.0, abs(ev).max()), (lmin, ev[0], steps)
+    rho = (2. * (1. - ev[0]) / m if ev[0] < 0 else 1. / m) * 50.       # the reference's auto-rho (qcqp.py:272-278)
+    res, its = e.admm_zsolver_device(rho)
+    assert res < 1e-10, (res, its)
+    Minv = np.linalg.inv(2. * (P0 + rho * m * np.eye(n)))
+    lm, Q = orc.Problem(funcs).eig()
+    X0 = np.random.RandomState(1).randn(n, 24)
+    e.admm_set_eig(lm, Q)
+    e.upload(X0)
+    out_d = e.admm_run(rho, None, phase1=True, num_iters=25)           # device-side z-solver
+    Xd = e.download()
+    e.upload(X0)
+    out_h = e.admm_run(rho, Minv, phase1=True, num_iters=25)           # host inverse, as in round 1
+    Xh = e.download()
+    assert rel(Xd, Xh) < 1e-6, rel(Xd, Xh)
+    assert rel(out_d['f0'], out_h['f0']) < 1e-6
+    assert np.array_equal(out_d['iters2'], out_h['iters2'])
+    # the matrix is gone after a host-side call: Minv = None must be refused, not silently reuse something stale
+    with pytest.raises(Exception):
+        e.admm_run(rho, None, phase1=True, num_iters=1)
