@@ -59,7 +59,12 @@ constexpr int RQ_PRIO_POLICY = 0;   // experiment: priorities inside the mfma ro
 constexpr int RQ_CSMAX = 6;   // blocks the chain wave can own
 
 // LDS doubles besides the X tile
-constexpr int RQ_LDS_COMMON = 2 * RQ_NSIMD * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8;
+constexpr int RQ_LDS_COMMON = 2 * RQ_NSIMD * 256 + 2 * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8;
+// Experiment kept behind a constant: the chain's share of the contraction multiplied by wave 4 (same SIMD) WHILE the chain
+// walks its 16 steps.  Correct, but no gain on MI355X: fp64 VALU and fp64 MFMA share the SIMD's pipe, every MFMA of wave 4
+// holds the chain's dependent v_fma_f64 back for its 64 cycles (16 steps: 1.9 k -> 3.0 k cycles with 16 MFMAs beside them,
+// 3.5 k with 24), exactly what the chain saves by not multiplying itself: 3.81 ms against 3.82 ms.
+constexpr bool RQ_W4SHARE = false;
 
 // the product loop's look-ahead loads reach unit RQ_MAXU - 1 of the X tile (at the start of the allocation) whatever n is
 constexpr size_t RQ_LDS_MIN = (size_t)((RQ_NSIMD - 1) * 256 + (12 * (RQ_MAXU - 1) + 3) * 64 + 64) * 8;
@@ -238,7 +243,8 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
     double *sp = smem;
     double *Xs = sp; sp += n16 * 16;
     double *part2 = sp; sp += 2 * RQ_NSIMD * 256; // partial G tiles (one per multiplying SIMD and product), [v][4 r + g], by product parity
-    double *fixp = sp; sp += 256;                  // the chain wave's own plane (fix-up + its share); the generic path's G tile
+    double *ownp2 = sp; sp += 2 * 256;             // partial tile of the chain SIMD's share (wave 4), by product parity
+    double *fixp = sp; sp += 256;                  // the chain wave's own plane (fix-ups); the generic path's G tile
     double *DU2 = sp; sp += 2 * 256;               // strictly upper triangle of the diagonal block (zeros elsewhere), by parity
     double *dg2 = sp; sp += 2 * 16;                // P0[i,i]
     double *hqb2 = sp; sp += 2 * 16;               // q0 / 2
@@ -295,22 +301,75 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
         stage_load(0);
         stage_store(0);
         rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
-        int b = 0;
-        for (int64_t g = 0; g < gmax; g++) {
-            const int bn = (b + 1 == NB) ? 0 : b + 1;
-            stage_load(bn);
-            bool stop = false;
-            for (;;) {     // slot (g + 1) & 1 was in use during interval g - 1
-                const rq_i4 s4 = rq_sync_read(sy);
-                if (s4[RQ_STOP]) { stop = true; break; }
-                if (s4[RQ_COMMIT] >= (int)g) break;
-                __builtin_amdgcn_s_sleep(2);
+        if (RQ_W4SHARE && CS > 0) {
+            // ---- ... and multiplies the chain SIMD's share of every product (the last CS blocks of the contraction) WHILE the
+            // chain wave walks its 16 steps (the chain's own 8 fix-up MFMAs come after its commit, when this wave has long
+            // finished).  Product i (block row b(i), read by the chain at the start of interval i) is computed
+            // during the steps of interval i - 2: holes b(i-1), b(i-2) like the other mfma waves, operands persistent, the
+            // block committed in interval i - 3 re-read.
+            const RqOwn cown = rq_own(NB, CS, RQ_NSIMD);
+            v2d_ arC[2 * CSU];
+            double bqC[4 * CSU];
+            rq_load_A<CSU>(arC, Apack2, KS, cown, lane, 0);
+            rq_load_B<CSU>(bqC, Xs, cown, lane);
+            int row = 0;
+            for (int64_t i = 0; i < gmax; i++) {
+                const int rown = (row + 1 == NB) ? 0 : row + 1;
+                const int h1 = (i >= 1) ? (row == 0 ? NB - 1 : row - 1) : -1;
+                const int h2 = (i >= 2) ? (h1 == 0 ? NB - 1 : h1 - 1) : -1;
+                const int r1 = (i >= 3) ? (h2 == 0 ? NB - 1 : h2 - 1) : -1;
+                if (i >= 1) stage_load(row);
+                bool stop = false;
+                if (i >= 2) {
+                    for (;;) {     // interval i - 2 has read its tiles: the chain is stepping, slot i & 1 of ownp2 is free
+                        const rq_i4 s4 = rq_sync_read(sy);
+                        if (s4[RQ_STOP]) { stop = true; break; }
+                        if (s4[RQ_CONS] >= (int)i - 1) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (stop) break;
+                }
+                if (r1 >= 0) { const int us = rq_slot(cown, r1); if (us >= 0) rq_refresh_B<CSU>(bqC, Xs, cown, lane, us); }
+                const v4d_ acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, h1 >= 0 ? rq_slot(cown, h1) : -1,
+                                                 h2 >= 0 ? rq_slot(cown, h2) : -1, rown, v4d_{0.0, 0.0, 0.0, 0.0});
+                {
+                    double *op = ownp2 + (int)(i & 1) * 256;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) op[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
+                }
+                rq_sync_write(sy, RQ_PARTS + RQ_NMW + 1, (int)i + 1, lane);
+                if (i >= 1) {
+                    for (;;) {     // staging slot i & 1 was in use during interval i - 2
+                        const rq_i4 s4 = rq_sync_read(sy);
+                        if (s4[RQ_STOP]) { stop = true; break; }
+                        if (s4[RQ_COMMIT] >= (int)i - 1) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (stop) break;
+                    stage_store((int)(i & 1));
+                    rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
+                    RQ_TRACE(i - 1, 0)
+                }
+                row = rown;
             }
-            if (stop) break;
-            stage_store((int)((g + 1) & 1));
-            rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
-            RQ_TRACE(g, 0)
-            b = bn;
+        } else {
+            int b = 0;
+            for (int64_t g = 0; g < gmax; g++) {
+                const int bn = (b + 1 == NB) ? 0 : b + 1;
+                stage_load(bn);
+                bool stop = false;
+                for (;;) {     // slot (g + 1) & 1 was in use during interval g - 1
+                    const rq_i4 s4 = rq_sync_read(sy);
+                    if (s4[RQ_STOP]) { stop = true; break; }
+                    if (s4[RQ_COMMIT] >= (int)g) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (stop) break;
+                stage_store((int)((g + 1) & 1));
+                rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
+                RQ_TRACE(g, 0)
+                b = bn;
+            }
         }
     } else if (wave != 0) {
         // =========================================================================== mfma role
@@ -477,7 +536,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
         double bqC[4 * CSU];
         double afix[4] = {0.0, 0.0, 0.0, 0.0}, afix2[4] = {0.0, 0.0, 0.0, 0.0};
         v4d_ carry = {0.0, 0.0, 0.0, 0.0};      // the block rewritten last times the fragments of the row after next
-        if (CS > 0) {
+        if (CS > 0 && !RQ_W4SHARE) {
             rq_load_A<CSU>(arC, Apack2, KS, cown, lane, 0);
             rq_load_B<CSU>(bqC, Xs, cown, lane);
             // prologue share: product of block row 0 over the chain's blocks (no hole), into the chain's plane
@@ -511,7 +570,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                 lo4 = lo4 < lo1 ? lo4 : lo1;
                 // an mfma wave publishes i + 1 after product i and only computes every other product: "all six >= g" says the
                 // three waves of parity g have delivered product g (their values jump by 2)
-                if (lo4 >= (int)g && p2[2] >= (int)g + 1) break;
+                if (lo4 >= (int)g && p2[2] >= (int)g + 1 && (!(RQ_W4SHARE && CS > 0) || p2[3] >= (int)g + 1)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             PROF_TICK(1)
@@ -523,6 +582,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                 double s = fixp[v * 64 + lane];
 #pragma unroll
                 for (int w = 0; w < RQ_NSIMD; w++) s += part[w * 256 + v * 64 + lane];
+                if (RQ_W4SHARE && CS > 0) s += ownp2[cur * 256 + v * 64 + lane];
                 s += hqb[4 * v + gq];
                 gb[v] = s;
                 g0[v] = s;
@@ -650,7 +710,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(afix2[u], xb4[u], acc2, 0, 0, 0);
                 }
                 carry = acc2;
-                if (CS > 0) {
+                if (CS > 0 && !RQ_W4SHARE) {
                     const int us = rq_slot(cown, b);
                     if (us >= 0) rq_refresh_B<CSU>(bqC, Xs, cown, lane, us);
                     acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, us, (g > 0 ? rq_slot(cown, bprev) : -1), bn2, acc);
