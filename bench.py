@@ -379,7 +379,7 @@ def main():
             res['roofline']['achieved_all_gpus'] = (flops_all / 1e12) / (p2_ms_max / 1e3) if p2_ms_max > 0 else 0.0
         if world == 1 and not args.no_secondary:
             res['secondary'] = secondary_records(local_rank)
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:      # a reported baseline of rank 0 at N = 1 only
             cores = args.cpu_cores or min(effective_cores(), 32)
             # the winning restart of the winning step again on the CPU: the cross-check of `best`
             wseed = args.seed + best_step

@@ -52,6 +52,8 @@ struct AdmmArgs {
     int lowrank;          // 1: reduced basis (operand 2 xhat - vhat - zq, dual vhat - xhat)
     int project_only;     // 1: unit operator onecons_qcqp: out = xhat (no dual, no update)
     double sec_tol;       // 1e-6 (utilities.py:149)
+    int zq_planes;        // ZQ arrives as this many split-K partial planes (small kernel only; summed in a fixed order)
+    int64_t zq_plane;     // doubles between two planes
 };
 
 // wave-wide sum on DPP (row_shr prefix sums inside the rows of 16 lanes, row_bcast across them; lanes without
@@ -200,7 +202,9 @@ __global__ __launch_bounds__(256) void admm_secular_small_kernel(AdmmArgs a) {
 #pragma unroll
     for (int e = 0; e < RP; e++) {
         L[e] = lm[e]; Qh[e] = qh[e];
-        Zq[e] = zq[e * 16];
+        double zsum = zq[e * 16];
+        for (int z = 1; z < a.zq_planes; z++) zsum += zq[e * 16 + z * a.zq_plane];
+        Zq[e] = zsum;
         const double u = (!a.first_iter && !a.project_only) ? uh[e * 16] : 0.0;
         V[e] = Zq[e] + u;
         fz += L[e] * (Zq[e] * Zq[e]) + Qh[e] * Zq[e];
