@@ -181,6 +181,9 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
     TC.hi = sp; sp += 2 * 16;
     TC.n = (int *)sp; sp += 8;
     TC.slow = (int *)sp; sp += 8;
+    // "every restart of the tile has converged", double-buffered by block parity: the chain wave writes the flag of interval
+    // g + 1 at the end of interval g, the other waves read the flag of interval g right after barrier g -- a wave that is
+    // late after the barrier can no longer see the next interval's value and leave one barrier early
     int *done = (int *)sp;
 
     double *Xs = XLDS ? Xl : Xg;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
         const int64_t g = tile * 16 + tid;
         slk[tid] = (g < a.R) ? a.slack[g] : 0.0;
     }
-    if (tid == 0) *done = 0;
+    if (tid == 0) { done[0] = 0; done[1] = 0; }
     __syncthreads();
     if (tid < 16) {
         FeasSet<MAXC> C;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
         // only keeps the barrier protocol.
         for (int64_t g = 0;; g++) {
             __syncthreads();
-            if (*done || g >= gmax) break;
+            if (done[g & 1] || g >= gmax) break;
         }
     } else if (wave != 0) {
         // =========================================================================== mfma role
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
             const int b = (int)(g % NB);                                              \
             QTICK(0)                                                                  \
             __syncthreads();                                                          \
-            if (*done || g >= gmax) break;                                            \
+            if (done[g & 1] || g >= gmax) break;                                            \
             stage_load((b + 1) % NB);                                                 \
             QTICK(1)                                                                  \
             QTICK(2)                                                                  \
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
             PROF_TICK(0)
             __syncthreads();                  // (1) part/Dblk/hq/rt of block b and X rows of bprev are ready
             PROF_TICK(1)
-            if (*done || g >= gmax) break;
+            if (done[g & 1] || g >= gmax) break;
             double xb[16], gb[16];
             {
                 // ---- fix-up: the 4 k-steps of the block the chain has just updated (A fragments
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(512) void cd_phase2_rs_kernel(CdArgs a, const doubl
                 }
             }
             const unsigned long long live = __builtin_amdgcn_ballot_w64(lane < 16 && !S.conv);
-            if (lane == 0) *done = (live == 0ull) ? 1 : 0;
+            if (lane == 0) done[(g + 1) & 1] = (live == 0ull) ? 1 : 0;
             if (PROF) pc[5]++;
         }
         if (lane < 16 && gr < a.R) {
