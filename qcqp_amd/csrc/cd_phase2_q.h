@@ -54,6 +54,12 @@ constexpr int RQ_PERS = 20;   // units whose B operands stay in registers; any o
 constexpr int RQ_MAXU = 20;   // blocks one SIMD can own (<= RQ_RND * RQ_PFU): n = 1024 needs the chain to take >= 4 blocks.
                               // (22 units = 5 passes + 2 re-read units measured 2.5 % slower at the same split, and smaller
                               //  chain shares do not pay: the mfma waves become the bottleneck)
+// Experiment kept behind a constant: one product at a time on a SIMD's matrix pipe -- a wave starts its MFMA stream only
+// when its partner has issued (or, in a second variant, drained) its whole product.  The streams then run at full rate
+// (85 MFMAs in 5.6 k cycles), but the hand-over plus the tail of a product (adds, store, flag: 2-3 k cycles while the
+// partner streams) cost what the overlap loses: 4.11 ms with no chain share, 3.91 ms at CS = 4 against 3.78-3.82 ms.
+constexpr bool RQ_TOKEN = false;
+constexpr int RQ_TOK = 12;          // sync words 12..14: next product allowed to stream on SIMD 0..2
 constexpr int RQ_YIELD = 0;         // s_sleep argument (64 cycles each) of the yield between passes
 constexpr int RQ_PRIO_POLICY = 0;   // experiment: priorities inside the mfma role
 constexpr int RQ_CSMAX = 6;   // blocks the chain wave can own
@@ -455,6 +461,14 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             for (int u = RQ_PERS; u < RQ_MAXU; u++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) bx[4 * (u - RQ_PERS) + q] = xb3[u >> 3][(12 * (u & 7) + q) * 64];
+            if (RQ_TOKEN && i >= 1) {
+                for (;;) {
+                    const rq_i4 t4 = rq_sync_read(sy + RQ_TOK);
+                    if (t4[sm] >= (int)i) break;
+                    if (t4[3]) { stop = true; break; }      // word 15 mirrors RQ_STOP
+                }
+                if (stop) break;
+            }
             QTICK(1)
             RQ_TRACE(i, 2)
             v4d_ acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc;    // two chains: a wave issues an MFMA every >= 64 cycles anyway
@@ -483,6 +497,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                 }
             }
             if (RQ_PRIO_POLICY) __builtin_amdgcn_s_setprio(3);
+            if (RQ_TOKEN) rq_sync_write(sy, RQ_TOK + sm, (int)i + 1, lane);   // EARLY hand-over: every MFMA of this product is issued
             acc = acc + acc1;
             QTICK(2)
             RQ_TRACE(i, 3)
@@ -724,6 +739,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             if (b == 0) t++;
         }
         rq_sync_write(sy, RQ_STOP, 1, lane);
+        rq_sync_write(sy, 15, 1, lane);
         const double ftot = rq_quad_sum(fpart);
         if (gq == 0 && live_r) {
             a.visits[gr] = S.visits; a.accepted[gr] = S.accepted; a.sweeps[gr] = S.sweeps;
