@@ -88,7 +88,9 @@ int qcqpmi_pop_randn(qcqpmi_ctx *ctx, int64_t R, uint64_t seed, uint64_t first_i
 /* suggest(SDR) tail batched: x_s = mu + F xi_s, xi_s ~ N(0, I)  (qcqp.py:396), where
  * F (n x n row-major) is any factor with F F^T = Sigma (the host computes it once: Cholesky, or
  * the SVD factor NumPy's multivariate_normal uses).  Xi (n x S, column per sample) may be given
- * for reproducibility tests; NULL = device Philox normals keyed on (seed, first_index + s). */
+ * for reproducibility tests; NULL = device Philox normals keyed on (seed, first_index + s).
+ * mu == NULL and F == NULL: draw again from the pair of the previous call, which is still resident and packed (no
+ * upload; many batches from one relaxation).  Returns without synchronising: the samples are in stream order. */
 int qcqpmi_pop_sdr_sample(qcqpmi_ctx *ctx, const double *mu, const double *F, int64_t S,
                           uint64_t seed, uint64_t first_index, const double *Xi);
 

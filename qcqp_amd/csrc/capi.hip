@@ -142,6 +142,8 @@ struct qcqpmi_ctx {
     int rank = 0, world = 1;
     double *d_comm = nullptr;
     long long *d_prof = nullptr;
+    int64_t Xi_cap = 0;                 // doubles reserved for the standard normals of pop_sdr_sample
+    bool sdr_factor_resident = false;   // d_Fpack / d_mu hold the pair of the last pop_sdr_sample
     double ad_Minv_rho = 0.0;           // rho of the z-solver matrix formed by qcqpmi_admm_zsolver_device
     bool ad_Minv_device = false;
     const char *last_cd2_kernel = "";     // name of the phase-2 kernel of the most recent cd run (bench / profiles)
@@ -969,7 +971,10 @@ int qcqpmi_pop_sdr_sample(qcqpmi_ctx *c, const double *mu, const double *F, int6
                           uint64_t first_index, const double *Xi) {
     int rc = check_ready(c, false);
     if (rc) return rc;
-    if (!mu || !F) return fail(c, QCQPMI_EINVAL, "pop_sdr_sample: mu / F missing");
+    // mu == NULL && F == NULL: the factor and mean of the previous call are still resident (packed for the matrix cores)
+    const bool reuse = !mu && !F;
+    if (!reuse && (!mu || !F)) return fail(c, QCQPMI_EINVAL, "pop_sdr_sample: mu / F missing (both NULL = reuse the previous pair)");
+    if (reuse && !c->sdr_factor_resident) return fail(c, QCQPMI_ESTATE, "pop_sdr_sample: no resident factor to reuse");
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t n = c->n, n16 = c->n16;
     if (!c->d_Fpack) {
@@ -977,17 +982,23 @@ int qcqpmi_pop_sdr_sample(qcqpmi_ctx *c, const double *mu, const double *F, int6
         if ((rc = dev_alloc(c, &c->d_Frow, (size_t)n16 * n16))) return rc;
         if ((rc = dev_alloc(c, &c->d_mu, (size_t)n16))) return rc;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_Frow, 0, (size_t)n16 * n16 * sizeof(double), c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(c->d_Frow, (size_t)n16 * sizeof(double), F, (size_t)n * sizeof(double),
-                               (size_t)n * sizeof(double), (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_mu, mu, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    int64_t total = n16 * n16;
-    hipLaunchKernelGGL(pack_A_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
-                       c->d_Frow, c->d_Fpack, n16, c->dp.KS);
+    if (!reuse) {
+        HIPCHK(c, hipMemsetAsync(c->d_Frow, 0, (size_t)n16 * n16 * sizeof(double), c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(c->d_Frow, (size_t)n16 * sizeof(double), F, (size_t)n * sizeof(double),
+                                   (size_t)n * sizeof(double), (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_mu, mu, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        int64_t total = n16 * n16;
+        hipLaunchKernelGGL(pack_A_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_Frow, c->d_Fpack, n16, c->dp.KS);
+        c->sdr_factor_resident = true;
+    }
     if ((rc = pop_reserve(c, S))) return rc;
-    // the standard normals: caller-provided (host layout) or device Philox
-    if (c->Xi) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->Xi); c->Xi = nullptr; }
-    if ((rc = dev_alloc(c, &c->Xi, (size_t)c->Rpad * n16))) return rc;
+    // the standard normals: caller-provided (host layout) or device Philox; the buffer is kept across calls
+    if ((int64_t)c->Rpad * n16 > c->Xi_cap) {
+        if (c->Xi) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->Xi); c->Xi = nullptr; c->Xi_cap = 0; }
+        if ((rc = dev_alloc(c, &c->Xi, (size_t)c->Rpad * n16, false))) return rc;
+        c->Xi_cap = (int64_t)c->Rpad * n16;
+    }
     int64_t tot2 = c->Rpad * n16;
     if (Xi) {
         HIPCHK(c, hipMemcpyAsync(c->d_stage, Xi, (size_t)S * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1015,7 +1026,8 @@ int qcqpmi_pop_sdr_sample(qcqpmi_ctx *c, const double *mu, const double *F, int6
     }
     toc(c, 3);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // host inputs were staged by (synchronous) pageable copies: nothing of the caller's is referenced any more.  The
+    // samples are in stream order for whatever comes next (evaluation, download); no synchronisation here.
     return 0;
 }
 

@@ -112,15 +112,20 @@ class Engine(object):
         self._chk(self.L.qcqpmi_pop_randn(self.h, int(R), int(seed), int(first_index)))
 
     def sdr_sample(self, mu, F, S, seed=0, first_index=0, Xi=None):
-        mu = np.ascontiguousarray(mu, dtype=np.float64).ravel()
-        F = np.ascontiguousarray(F, dtype=np.float64)
-        assert F.shape == (self.n, self.n) and mu.size == self.n
+        """x_s = mu + F xi_s for S samples.  mu = F = None draws again from the pair of the previous call (resident)."""
+        if mu is None and F is None:
+            mu_p = F_p = None
+        else:
+            mu = np.ascontiguousarray(mu, dtype=np.float64).ravel()
+            F = np.ascontiguousarray(F, dtype=np.float64)
+            assert F.shape == (self.n, self.n) and mu.size == self.n
+            mu_p, F_p = mu, F
         Xc = None
         if Xi is not None:
             Xi = np.asarray(Xi, dtype=np.float64)
             assert Xi.shape == (self.n, S)
             Xc = np.ascontiguousarray(Xi.T)
-        self._chk(self.L.qcqpmi_pop_sdr_sample(self.h, _dp(mu), _dp(F), int(S), int(seed),
+        self._chk(self.L.qcqpmi_pop_sdr_sample(self.h, _dp(mu_p), _dp(F_p), int(S), int(seed),
                                                int(first_index), _dp(Xc)))
 
     # ---------------------------------------------------------------- evaluation
