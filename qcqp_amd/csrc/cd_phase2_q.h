@@ -18,28 +18,28 @@
 //     * bookkeeping that does not feed the next step -- objective tracking, near-tie test, move mask --
 //       is computed once per block from the values the lane still holds (G of a finished column is never
 //       updated again: the masked diagonal block has zeros there).
-//     * the 4 k-steps of the block just rewritten (the "fix-up") run BEFORE the barrier, straight after the
-//       commit of the block, together with the chain wave's own share of the next product (RQ_CS blocks
-//       of the contraction): the chain is short enough now that its SIMD has matrix time to spare.
-//   mfma waves (1, 2, 3, 5, 6, 7; two per SIMD)
-//     * STATIC, CYCLIC ownership of the contraction: block j of 16 coordinates belongs to wave j % 6 (the chain keeps
-//       the last CS blocks for itself), its B operands (those X rows) stay in registers for the whole kernel;
-//       generation 1 re-read 44 LDS operands per wave and block before the first MFMA could issue.
-//     * A fragments as before: register resident, refilled in place one block ahead with unconditional 16-byte loads
-//       from the pair-packed copy of P0.
-//     * TWO holes: the product for block row b+1 leaves out block b (being rewritten) AND block b-1 (rewritten just
-//       before); the chain supplies both -- after committing block b it multiplies it with the fragments of rows b+1 and
-//       b+2 (8 MFMAs) and carries the second tile in registers for one block.  No mfma wave ever needs a block within
-//       one interval of its commit: the owner refreshes its 4 operands a whole block later and never waits.
+//     * the 4 k-steps of the block just rewritten (the "fix-up") run straight after the commit of the block, together
+//       with the chain wave's own share of the next product (the last CS blocks of the contraction).
+//   mfma waves (1, 2, 3, 5, 6, 7; two per SIMD on SIMDs 1-3)
+//     * block j of 16 coordinates belongs to SIMD j % 3 (the chain keeps the last CS blocks); the two waves of a SIMD
+//       take ALTERNATE products (product i = block row b(i), read by the chain at the start of interval i), each over
+//       all blocks of its SIMD.  B operands (those X rows) stay in registers for the whole kernel; a product re-reads
+//       only the blocks committed since the wave's previous product.
+//     * A fragments stream from the pair-packed copy of P0 through a ring of RQ_PFU units with buffer loads (descriptor +
+//       scalar offset per unit + one lane-offset register): a unit is 4 MFMAs, 2 loads and 4 scalar instructions.
+//     * TWO holes: the product for block row b(i) leaves out the block being rewritten b(i-1) AND the one rewritten just
+//       before b(i-2); the chain supplies both -- after committing block b it multiplies it with the fragments of the next
+//       two rows (8 MFMAs) and carries the second tile in registers for one block.  A product may start as soon as
+//       interval i - 3 is committed and has almost three intervals to finish.
 //   staging wave (wave 4, on the chain's SIMD): fetches the small operands of the next block (masked diagonal block,
 //     diagonal, q/2, 1/P_ii) one block ahead.
 //   synchronisation
 //     * NO s_barrier inside the block loop.  Producer / consumer words in LDS (RQ_CONS, RQ_COMMIT, RQ_STOP, one
-//       progress word per producer): the chain waits for the six partial tiles and the staged operands of its block, a
-//       producer for the release of the slot it is about to overwrite.  With a barrier both waves of a SIMD did their
-//       store / wait phases at the same time and the matrix pipe idled ~1.4 k of every 7.5 k cycles; free-running
-//       waves, started half a product apart, cover each other.  Partial tiles and staged operands are double-buffered
-//       by block parity.
+//       progress word per producer): the chain waits for the three partial tiles of the product's parity and the staged
+//       operands of its block, a producer for the commit it depends on and for the release of the slot it is about to
+//       overwrite.  Partial tiles and staged operands are double-buffered by parity.
+//   Measurements, the variants that did not pay (three holes, rings of 7 / 11 units, priorities, a stream token, the
+//   chain's share on wave 4) and what was learnt about the matrix pipe: DESIGN.md section 4.1.
 #pragma once
 #include <stdint.h>
 #include "cd_phase2_rs.h"
@@ -54,23 +54,10 @@ constexpr int RQ_PERS = 20;   // units whose B operands stay in registers; any o
 constexpr int RQ_MAXU = 20;   // blocks one SIMD can own (<= RQ_RND * RQ_PFU): n = 1024 needs the chain to take >= 4 blocks.
                               // (22 units = 5 passes + 2 re-read units measured 2.5 % slower at the same split, and smaller
                               //  chain shares do not pay: the mfma waves become the bottleneck)
-// Experiment kept behind a constant: one product at a time on a SIMD's matrix pipe -- a wave starts its MFMA stream only
-// when its partner has issued (or, in a second variant, drained) its whole product.  The streams then run at full rate
-// (85 MFMAs in 5.6 k cycles), but the hand-over plus the tail of a product (adds, store, flag: 2-3 k cycles while the
-// partner streams) cost what the overlap loses: 4.11 ms with no chain share, 3.91 ms at CS = 4 against 3.78-3.82 ms.
-constexpr bool RQ_TOKEN = false;
-constexpr int RQ_TOK = 12;          // sync words 12..14: next product allowed to stream on SIMD 0..2
-constexpr int RQ_YIELD = 0;         // s_sleep argument (64 cycles each) of the yield between passes
-constexpr int RQ_PRIO_POLICY = 0;   // experiment: priorities inside the mfma role
 constexpr int RQ_CSMAX = 6;   // blocks the chain wave can own
 
 // LDS doubles besides the X tile
-constexpr int RQ_LDS_COMMON = 2 * RQ_NSIMD * 256 + 2 * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8;
-// Experiment kept behind a constant: the chain's share of the contraction multiplied by wave 4 (same SIMD) WHILE the chain
-// walks its 16 steps.  Correct, but no gain on MI355X: fp64 VALU and fp64 MFMA share the SIMD's pipe, every MFMA of wave 4
-// holds the chain's dependent v_fma_f64 back for its 64 cycles (16 steps: 1.9 k -> 3.0 k cycles with 16 MFMAs beside them,
-// 3.5 k with 24), exactly what the chain saves by not multiplying itself: 3.81 ms against 3.82 ms.
-constexpr bool RQ_W4SHARE = false;
+constexpr int RQ_LDS_COMMON = 2 * RQ_NSIMD * 256 + 256 + 2 * 256 + 2 * 16 + 2 * 16 + 2 * 16 + 16 + 4 * 16 + 8 + 8 + 8;
 
 // the product loop's look-ahead loads reach unit RQ_MAXU - 1 of the X tile (at the start of the allocation) whatever n is
 constexpr size_t RQ_LDS_MIN = (size_t)((RQ_NSIMD - 1) * 256 + (12 * (RQ_MAXU - 1) + 3) * 64 + 64) * 8;
@@ -249,8 +236,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
     double *sp = smem;
     double *Xs = sp; sp += n16 * 16;
     double *part2 = sp; sp += 2 * RQ_NSIMD * 256; // partial G tiles (one per multiplying SIMD and product), [v][4 r + g], by product parity
-    double *ownp2 = sp; sp += 2 * 256;             // partial tile of the chain SIMD's share (wave 4), by product parity
-    double *fixp = sp; sp += 256;                  // the chain wave's own plane (fix-ups); the generic path's G tile
+    double *fixp = sp; sp += 256;                  // the chain wave's own plane (fix-up + its share); the generic path's G tile
     double *DU2 = sp; sp += 2 * 256;               // strictly upper triangle of the diagonal block (zeros elsewhere), by parity
     double *dg2 = sp; sp += 2 * 16;                // P0[i,i]
     double *hqb2 = sp; sp += 2 * 16;               // q0 / 2
@@ -307,83 +293,28 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
         stage_load(0);
         stage_store(0);
         rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
-        if (RQ_W4SHARE && CS > 0) {
-            // ---- ... and multiplies the chain SIMD's share of every product (the last CS blocks of the contraction) WHILE the
-            // chain wave walks its 16 steps (the chain's own 8 fix-up MFMAs come after its commit, when this wave has long
-            // finished).  Product i (block row b(i), read by the chain at the start of interval i) is computed
-            // during the steps of interval i - 2: holes b(i-1), b(i-2) like the other mfma waves, operands persistent, the
-            // block committed in interval i - 3 re-read.
-            const RqOwn cown = rq_own(NB, CS, RQ_NSIMD);
-            v2d_ arC[2 * CSU];
-            double bqC[4 * CSU];
-            rq_load_A<CSU>(arC, Apack2, KS, cown, lane, 0);
-            rq_load_B<CSU>(bqC, Xs, cown, lane);
-            int row = 0;
-            for (int64_t i = 0; i < gmax; i++) {
-                const int rown = (row + 1 == NB) ? 0 : row + 1;
-                const int h1 = (i >= 1) ? (row == 0 ? NB - 1 : row - 1) : -1;
-                const int h2 = (i >= 2) ? (h1 == 0 ? NB - 1 : h1 - 1) : -1;
-                const int r1 = (i >= 3) ? (h2 == 0 ? NB - 1 : h2 - 1) : -1;
-                if (i >= 1) stage_load(row);
-                bool stop = false;
-                if (i >= 2) {
-                    for (;;) {     // interval i - 2 has read its tiles: the chain is stepping, slot i & 1 of ownp2 is free
-                        const rq_i4 s4 = rq_sync_read(sy);
-                        if (s4[RQ_STOP]) { stop = true; break; }
-                        if (s4[RQ_CONS] >= (int)i - 1) break;
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    if (stop) break;
-                }
-                if (r1 >= 0) { const int us = rq_slot(cown, r1); if (us >= 0) rq_refresh_B<CSU>(bqC, Xs, cown, lane, us); }
-                const v4d_ acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, h1 >= 0 ? rq_slot(cown, h1) : -1,
-                                                 h2 >= 0 ? rq_slot(cown, h2) : -1, rown, v4d_{0.0, 0.0, 0.0, 0.0});
-                {
-                    double *op = ownp2 + (int)(i & 1) * 256;
-#pragma unroll
-                    for (int v = 0; v < 4; v++) op[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
-                }
-                rq_sync_write(sy, RQ_PARTS + RQ_NMW + 1, (int)i + 1, lane);
-                if (i >= 1) {
-                    for (;;) {     // staging slot i & 1 was in use during interval i - 2
-                        const rq_i4 s4 = rq_sync_read(sy);
-                        if (s4[RQ_STOP]) { stop = true; break; }
-                        if (s4[RQ_COMMIT] >= (int)i - 1) break;
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    if (stop) break;
-                    stage_store((int)(i & 1));
-                    rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
-                    RQ_TRACE(i - 1, 0)
-                }
-                row = rown;
+        int b = 0;
+        for (int64_t g = 0; g < gmax; g++) {
+            const int bn = (b + 1 == NB) ? 0 : b + 1;
+            stage_load(bn);
+            bool stop = false;
+            for (;;) {     // slot (g + 1) & 1 was in use during interval g - 1
+                const rq_i4 s4 = rq_sync_read(sy);
+                if (s4[RQ_STOP]) { stop = true; break; }
+                if (s4[RQ_COMMIT] >= (int)g) break;
+                __builtin_amdgcn_s_sleep(2);
             }
-        } else {
-            int b = 0;
-            for (int64_t g = 0; g < gmax; g++) {
-                const int bn = (b + 1 == NB) ? 0 : b + 1;
-                stage_load(bn);
-                bool stop = false;
-                for (;;) {     // slot (g + 1) & 1 was in use during interval g - 1
-                    const rq_i4 s4 = rq_sync_read(sy);
-                    if (s4[RQ_STOP]) { stop = true; break; }
-                    if (s4[RQ_COMMIT] >= (int)g) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (stop) break;
-                stage_store((int)((g + 1) & 1));
-                rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
-                RQ_TRACE(g, 0)
-                b = bn;
-            }
+            if (stop) break;
+            stage_store((int)((g + 1) & 1));
+            rq_sync_write(sy, RQ_PARTS + RQ_NMW, ++published, lane);
+            RQ_TRACE(g, 0)
+            b = bn;
         }
     } else if (wave != 0) {
         // =========================================================================== mfma role
-        // The two waves of a SIMD TAKE TURNS: wave parity pw computes the products i = pw, pw + 2, ... (product i = block
-        // row b(i), consumed by the chain in interval i) over ALL blocks of its SIMD, alone on the matrix pipe; while it
-        // stores, waits and loads, its partner multiplies.  B operands come straight from the X tile one unit ahead of the
-        // MFMAs that use them (the partner hides the start-up); A fragments live in a ring of RQ_PFU units, refilled in
-        // place: first with the second half of the same block row, then with the first half of the row of product i + 2.
+        // The two waves of a SIMD take ALTERNATE products: wave parity pw computes the products i = pw, pw + 2, ... (product
+        // i = block row b(i), consumed by the chain in interval i) over ALL blocks of its SIMD; while it stores, waits and
+        // refreshes, its partner multiplies.
         const int sm = wave < 4 ? wave - 1 : wave - 5;     // SIMD of the pair (waves w and w + 4 share one)
         const int pw = wave < 4 ? 0 : 1;
         const int mw = wave < 4 ? wave - 1 : wave - 2;     // progress word
@@ -461,26 +392,11 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             for (int u = RQ_PERS; u < RQ_MAXU; u++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) bx[4 * (u - RQ_PERS) + q] = xb3[u >> 3][(12 * (u & 7) + q) * 64];
-            if (RQ_TOKEN && i >= 1) {
-                for (;;) {
-                    const rq_i4 t4 = rq_sync_read(sy + RQ_TOK);
-                    if (t4[sm] >= (int)i) break;
-                    if (t4[3]) { stop = true; break; }      // word 15 mirrors RQ_STOP
-                }
-                if (stop) break;
-            }
             QTICK(1)
             RQ_TRACE(i, 2)
             v4d_ acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc;    // two chains: a wave issues an MFMA every >= 64 cycles anyway
 #pragma unroll
             for (int third = 0; third < RQ_RND; third++) {
-                // Two experiments kept behind constants, both without effect on MI355X ("matrix pipe arbitration"):
-                // a yield (s_sleep) between passes and s_setprio by deadline.  A wave's MFMAs run ahead of the pipe in a deep
-                // queue, and the later VALU work of a wave that has MFMAs queued (adds, store, flag) is served only when the
-                // partner's queued stream has drained: occasionally a finished product is published ~5 k cycles late.
-                if (RQ_YIELD && third > 0) __builtin_amdgcn_s_sleep(RQ_YIELD);
-                if (RQ_PRIO_POLICY && third == 0) __builtin_amdgcn_s_setprio(0);
-                if (RQ_PRIO_POLICY && third == 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                 for (int U = 0; U < RQ_PFU; U++) {
                     const int u = RQ_PFU * third + U;
@@ -496,8 +412,6 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                     else RQ_LDA(arP + 2 * U, so2 + RQ_NSIMD * 2048 * U, vlane)
                 }
             }
-            if (RQ_PRIO_POLICY) __builtin_amdgcn_s_setprio(3);
-            if (RQ_TOKEN) rq_sync_write(sy, RQ_TOK + sm, (int)i + 1, lane);   // EARLY hand-over: every MFMA of this product is issued
             acc = acc + acc1;
             QTICK(2)
             RQ_TRACE(i, 3)
@@ -521,7 +435,6 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             RQ_TRACE(i, 5)
             rq_sync_write(sy, RQ_PARTS + mw, (int)i + 1, lane);
             RQ_TRACE(i, 6)
-            if (RQ_PRIO_POLICY) __builtin_amdgcn_s_setprio(0);
             row = row2;
         }
         if (PROF && a.prof && (tid == 128 || tid == 384))   // the elder and the younger wave of one pair
@@ -551,7 +464,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
         double bqC[4 * CSU];
         double afix[4] = {0.0, 0.0, 0.0, 0.0}, afix2[4] = {0.0, 0.0, 0.0, 0.0};
         v4d_ carry = {0.0, 0.0, 0.0, 0.0};      // the block rewritten last times the fragments of the row after next
-        if (CS > 0 && !RQ_W4SHARE) {
+        if (CS > 0) {
             rq_load_A<CSU>(arC, Apack2, KS, cown, lane, 0);
             rq_load_B<CSU>(bqC, Xs, cown, lane);
             // prologue share: product of block row 0 over the chain's blocks (no hole), into the chain's plane
@@ -585,7 +498,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                 lo4 = lo4 < lo1 ? lo4 : lo1;
                 // an mfma wave publishes i + 1 after product i and only computes every other product: "all six >= g" says the
                 // three waves of parity g have delivered product g (their values jump by 2)
-                if (lo4 >= (int)g && p2[2] >= (int)g + 1 && (!(RQ_W4SHARE && CS > 0) || p2[3] >= (int)g + 1)) break;
+                if (lo4 >= (int)g && p2[2] >= (int)g + 1) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             PROF_TICK(1)
@@ -597,7 +510,6 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                 double s = fixp[v * 64 + lane];
 #pragma unroll
                 for (int w = 0; w < RQ_NSIMD; w++) s += part[w * 256 + v * 64 + lane];
-                if (RQ_W4SHARE && CS > 0) s += ownp2[cur * 256 + v * 64 + lane];
                 s += hqb[4 * v + gq];
                 gb[v] = s;
                 g0[v] = s;
@@ -725,7 +637,7 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
                     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(afix2[u], xb4[u], acc2, 0, 0, 0);
                 }
                 carry = acc2;
-                if (CS > 0 && !RQ_W4SHARE) {
+                if (CS > 0) {
                     const int us = rq_slot(cown, b);
                     if (us >= 0) rq_refresh_B<CSU>(bqC, Xs, cown, lane, us);
                     acc = rq_product<CSU>(arC, bqC, Apack2, KS, cown, lane, us, (g > 0 ? rq_slot(cown, bprev) : -1), bn2, acc);
@@ -739,7 +651,6 @@ __global__ __launch_bounds__(512) void cd_phase2_q_kernel(CdArgs a, const double
             if (b == 0) t++;
         }
         rq_sync_write(sy, RQ_STOP, 1, lane);
-        rq_sync_write(sy, 15, 1, lane);
         const double ftot = rq_quad_sum(fpart);
         if (gq == 0 && live_r) {
             a.visits[gr] = S.visits; a.accepted[gr] = S.accepted; a.sweeps[gr] = S.sweeps;
