@@ -33,6 +33,10 @@
 
 namespace qcqpmi {
 
+// threads of the per-tile streaming kernels (z-update, f0, book): one workgroup per tile of 16 restarts, 64 row groups --
+// with 256 threads the 64 workgroups of 1024 restarts kept a quarter of the chip's memory pipes busy
+constexpr int ADMM_TPB = 1024;
+
 struct AdmmArgs {
     int64_t n, m, R;
     int64_t rows_k;       // hat rows per constraint (n or rp)
@@ -289,14 +293,14 @@ struct AdmmZArgs {
 };
 
 // one workgroup per tile: sums the planes of the consensus product and performs the z-update that needs no solve
-__global__ __launch_bounds__(256) void admm_zupdate_kernel(AdmmZArgs a) {
-    __shared__ double red[256];
+__global__ __launch_bounds__(ADMM_TPB) void admm_zupdate_kernel(AdmmZArgs a) {
+    __shared__ double red[ADMM_TPB];
     const int64_t tile = blockIdx.x;
     const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
     const int64_t r = tile * 16 + rr;
     const bool on = r < a.R && a.act[r];
     double acc = 0.0;
-    for (int64_t j = jl; j < a.n16; j += 16) {
+    for (int64_t j = jl; j < a.n16; j += ADMM_TPB / 16) {
         const int64_t idx = (tile * a.n16 + j) * 16 + rr;
         double s = a.Sp[idx];
         for (int z = 1; z < a.zs; z++) s += a.Sp[(int64_t)z * a.plane + idx];
@@ -322,23 +326,23 @@ __global__ __launch_bounds__(256) void admm_zupdate_kernel(AdmmZArgs a) {
         __syncthreads();
         if (threadIdx.x < 16) {
             double s = 0.0;
-            for (int g = 0; g < 16; g++) s += red[g * 16 + threadIdx.x];
+            for (int g = 0; g < ADMM_TPB / 16; g++) s += red[g * 16 + threadIdx.x];
             if (tile * 16 + threadIdx.x < a.R) a.dist2[tile * 16 + threadIdx.x] = s;
         }
     }
 }
 
 // dense solve: Znew = Minv rhs came out of the GEMM; Z <- Znew for active restarts, ||Zlast - Znew||^2 per restart
-__global__ __launch_bounds__(256) void admm_take_z_kernel(double *Z, const double *Znew, const double *Zlast,
+__global__ __launch_bounds__(ADMM_TPB) void admm_take_z_kernel(double *Z, const double *Znew, const double *Zlast,
                                                            const uint8_t *act, double *dist2, int64_t n, int64_t n16, int64_t R) {
-    __shared__ double red[256];
+    __shared__ double red[ADMM_TPB];
     const int64_t tile = blockIdx.x;
     const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
     const int64_t r = tile * 16 + rr;
     const bool on = r < R && act[r];
     double acc = 0.0;
     if (on)
-        for (int64_t j = jl; j < n; j += 16) {
+        for (int64_t j = jl; j < n; j += ADMM_TPB / 16) {
             const int64_t idx = (tile * n16 + j) * 16 + rr;
             const double zn = Znew[idx];
             const double d = Zlast[idx] - zn;
@@ -349,19 +353,19 @@ __global__ __launch_bounds__(256) void admm_take_z_kernel(double *Z, const doubl
     __syncthreads();
     if (threadIdx.x < 16) {
         double s = 0.0;
-        for (int g = 0; g < 16; g++) s += red[g * 16 + threadIdx.x];
+        for (int g = 0; g < ADMM_TPB / 16; g++) s += red[g * 16 + threadIdx.x];
         if (tile * 16 + threadIdx.x < R) dist2[tile * 16 + threadIdx.x] = s;
     }
 }
 
 // f0(z) = z.(Y + q0) + r0 with Y = P0 z from the GEMM, or Y_j = d_j z_j for a diagonal P0 (pdiag != nullptr)
-__global__ __launch_bounds__(256) void admm_f0_kernel(const double *Z, const double *Y, const double *pdiag, const double *q0,
+__global__ __launch_bounds__(ADMM_TPB) void admm_f0_kernel(const double *Z, const double *Y, const double *pdiag, const double *q0,
                                                        double r0, double *f0, int64_t n, int64_t n16, int64_t R) {
-    __shared__ double red[256];
+    __shared__ double red[ADMM_TPB];
     const int64_t tile = blockIdx.x;
     const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
     double acc = 0.0;
-    for (int64_t j = jl; j < n; j += 16) {
+    for (int64_t j = jl; j < n; j += ADMM_TPB / 16) {
         const int64_t idx = (tile * n16 + j) * 16 + rr;
         const double z = Z[idx];
         const double y = pdiag ? pdiag[j] * z : Y[idx];
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256) void admm_f0_kernel(const double *Z, const dou
     __syncthreads();
     if (threadIdx.x < 16) {
         double s = 0.0;
-        for (int g = 0; g < 16; g++) s += red[g * 16 + threadIdx.x];
+        for (int g = 0; g < ADMM_TPB / 16; g++) s += red[g * 16 + threadIdx.x];
         if (tile * 16 + threadIdx.x < R) f0[tile * 16 + threadIdx.x] = s + r0;
     }
 }
@@ -392,7 +396,7 @@ struct AdmmBook {
 };
 
 // per-restart control flow of admm_phase1 (qcqp.py:202-204) / admm_phase2 (qcqp.py:240-249); one workgroup per tile
-__global__ __launch_bounds__(256) void admm_book_kernel(AdmmBook b) {
+__global__ __launch_bounds__(ADMM_TPB) void admm_book_kernel(AdmmBook b) {
     __shared__ int take[16], live[16];
     const int64_t tile = blockIdx.x;
     const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(256) void admm_book_kernel(AdmmBook b) {
     __syncthreads();
     if (b.phase == 2 && live[rr]) {
         const bool tk = take[rr] != 0;
-        for (int64_t j = jl; j < b.n; j += 16) {
+        for (int64_t j = jl; j < b.n; j += ADMM_TPB / 16) {
             const int64_t idx = (tile * b.n16 + j) * 16 + rr;
             const double z = b.Z[idx];
             b.Zlast[idx] = z;

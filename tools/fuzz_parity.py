@@ -14,7 +14,7 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(cases):
     fam = rs.choice(['bls', 'bls_scaled', 'maxcut', 'box'])
-    n = int(rs.choice([5, 12, 16, 17, 31, 32, 33, 48]))
+    n = int(rs.choice([5, 12, 16, 17, 31, 32, 33, 48, 64, 80, 96]))     # 48..96: the quad-chain kernel (NB >= 3)
     if fam == 'bls':
         funcs, _, _ = problems.boolean_least_squares(n, max(2, n // 2 + int(rs.randint(0, n))), seed=int(rs.randint(1 << 30)))
     elif fam == 'bls_scaled':     # x_i^2 == d_i with a different d per coordinate (one class per coordinate)
