@@ -28,6 +28,30 @@ def test_library_exports_every_declared_symbol():
     assert L.qcqpmi_device_count() >= 0
 
 
+def test_abi_argument_checks_need_no_gpu():
+    """Every entry point refuses a NULL context / bad arguments with QCQPMI_EINVAL before it touches a device: the error
+    behaviour of the boundary is testable on the build host (no compute call is made)."""
+    from qcqp_amd import _ffi
+    L = _ffi.lib()
+    EINVAL = -1
+    z = np.zeros(4)
+    zi = np.zeros(4, dtype=np.int64)
+    dp = z.ctypes.data_as(_ffi.c_dp)
+    ip = zi.ctypes.data_as(_ffi.c_ip)
+    assert L.qcqpmi_admm_zsolver_device(None, 1.0, 0, dp, ip) == EINVAL
+    assert L.qcqpmi_p0_lambda_min(None, 0, 1e-12, dp, ip) == EINVAL
+    assert L.qcqpmi_debug_trace(None, ip, 4) == EINVAL
+    assert L.qcqpmi_debug_profile(None, 0, None) == EINVAL
+    assert L.qcqpmi_admm_run(None, 1, 10, 1e-2, 1e4, 1.0, None, None, None, None, None) == EINVAL
+    assert L.qcqpmi_pop_sdr_sample(None, None, None, 4, 0, 0, None) != 0
+    assert (L.qcqpmi_last_cd_kernel(None) or b'') == b''
+    assert L.qcqpmi_sync(None) == EINVAL
+    # a context on a machine without a GPU cannot be created: the error is reported, not a crash
+    h = ctypes.c_void_p()
+    if L.qcqpmi_device_count() == 0:
+        assert L.qcqpmi_ctx_create(ctypes.byref(h), 4, 1, 0) != 0
+
+
 def test_engine_fails_loudly_without_gpu():
     from qcqp_amd import _ffi, problems
     from qcqp_amd.form import QCQPForm
