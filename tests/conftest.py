@@ -12,8 +12,41 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 RELSTR = {0: None, 1: '<=', 2: '=='}
 
 
+ROCSOLVER = '/opt/rocm/lib/librocsolver.so'
+_warm = {'thread': None, 'bytes': 0}
+
+
+def _warm_file(path):
+    """Read a file once so that a later dlopen finds it in the page cache (no dl lock is held meanwhile)."""
+    try:
+        with open(path, 'rb', buffering=0) as f:
+            while True:
+                chunk = f.read(1 << 24)
+                if not chunk:
+                    break
+                _warm['bytes'] += len(chunk)
+    except OSError:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # GPU sessions: librocsolver.so is 0.9 GB and a fresh box pages it in at a few MB/s; start reading it now, in the
+    # background, so that the one test that needs it (device-side eigendecompositions) does not wait minutes for dlopen
+    expr = config.getoption('-m', default='') or ''
+    if 'gpu' in expr and 'not gpu' not in expr and os.path.exists(ROCSOLVER) and _warm['thread'] is None:
+        import threading
+        _warm['thread'] = threading.Thread(target=_warm_file, args=(ROCSOLVER,), daemon=True)
+        _warm['thread'].start()
+
+
+def rocsolver_warm(timeout):
+    """Wait for the background read of librocsolver.so; True if it finished (or was never started)."""
+    t = _warm['thread']
+    if t is None:
+        return True
+    t.join(timeout)
+    return not t.is_alive()
 
 
 def load_golden(name):

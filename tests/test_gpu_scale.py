@@ -268,8 +268,13 @@ def test_g4_onevar_qcqp_on_device(eng_mod, orc):
 # ------------------------------------------------------------------ device-side ADMM setup (rocSOLVER)
 @pytest.fixture(scope='module')
 def rocsolver_loaded():
-    """librocsolver.so is 0.9 GB: page it in once per session (up to a few minutes on a fresh box)."""
-    C.CDLL('/opt/rocm/lib/librocsolver.so', mode=C.RTLD_GLOBAL)
+    """librocsolver.so is 0.9 GB: conftest.py starts reading it into the page cache when the GPU session starts; by the
+    time this fixture runs (tests of this module come last) the dlopen is quick.  A box that has not delivered the file
+    after another 6 minutes is too slow for this optional path: skip, with the reason."""
+    from conftest import ROCSOLVER, rocsolver_warm
+    if not rocsolver_warm(360.0):
+        pytest.skip('librocsolver.so (0.9 GB) was not readable within the time budget on this box')
+    C.CDLL(ROCSOLVER, mode=C.RTLD_GLOBAL)
     return True
 
 
