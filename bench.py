@@ -317,6 +317,8 @@ def main():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--cpu-cores', type=int, default=0, help='host cores for the CPU baselines (0 = all usable, at most 32)')
+    ap.add_argument('--no-overlap', dest='overlap', action='store_false',
+                    help='one context only: every step runs strictly after the previous one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the bounded records of the other BASELINE.json configs')
     args = ap.parse_args()
@@ -334,32 +336,59 @@ def main():
         first, R = dist.shard_range(args.restarts, rank, world)
 
     funcs, _, _ = problems.boolean_least_squares(n, args.m_rows, seed=1)
-    eng = Engine(QCQPForm.from_arrays(funcs), device=local_rank)
+    form = QCQPForm.from_arrays(funcs)
+    eng = Engine(form, device=local_rank)
     boot = dist.init_rccl(eng, rank, world)
+    # A second context (= a second HIP stream) on the same GPU.  The steps alternate between the two: while the phase-2
+    # kernel of step k runs -- its tail leaves most CUs idle: 4096 restarts are one tile per CU and the launch lasts as long
+    # as the slowest restart -- suggest, phase 1, evaluation and gate of step k + 1 are already being worked on in the
+    # other stream.  The phase-2 kernels themselves never overlap (the next one is launched after the results of the
+    # current one have been fetched), so their HIP-event durations stay those of a kernel that owns the chip.
+    eng2 = Engine(form, device=local_rank) if args.overlap else None
+    if eng2 is not None:
+        dist.init_rccl(eng2, rank, world, bootstrap=boot)       # its own communicator (same rendezvous object)
+    engs = [eng, eng2] if eng2 is not None else [eng]
 
-    def step(k):
-        eng.randn(R, seed=args.seed + k, first_index=first)
-        out = eng.cd_run(phase1=True, seed=args.seed + k, first_index=first)
-        best = eng.comm_select_best(1e-4, index_offset=first)
-        return out, best
+    def prepare(e, k):
+        e.randn(R, seed=args.seed + k, first_index=first)
+        e.cd_begin(phase1=True, seed=args.seed + k, first_index=first)
 
-    for k in range(args.warmup):
-        step(-1 - k)
-    eng.sync()
+    def run_steps(count, base, record):
+        """`count` steps; step k = suggest(RANDOM) + improve(COORD_DESCENT) + selection of the best point."""
+        prepare(engs[0], base)
+        for k in range(count):
+            cur = engs[k % len(engs)]
+            cur.cd_phase2()
+            if len(engs) > 1 and k + 1 < count:
+                prepare(engs[(k + 1) % 2], base + k + 1)        # overlaps the phase-2 kernel just launched
+            out = cur.cd_fetch()
+            b = cur.comm_select_best(1e-4, index_offset=first)
+            record(k, cur, out, b)
+            if len(engs) == 1 and k + 1 < count:
+                prepare(eng, base + k + 1)
+
+    run_steps(args.warmup, -1000, lambda *_: None)
+    for e_ in engs:
+        e_.sync()
     eng.comm_barrier()
-    sweeps1 = sweeps2 = 0.0
-    p2_flops = p2_ms = p1_ms = 0.0
-    best, best_step = None, -1
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        out, b = step(k)
-        sweeps1 += float(out['sweeps1'].sum())
-        sweeps2 += float(out['visits2'].sum()) / n
-        p2_flops += float(out['visits2'].sum()) * 2.0 * n   # algorithmic: 2n flops per visit
-        p2_ms += eng.kernel_ms(Engine.KERNEL_CD2)
-        p1_ms += eng.kernel_ms(Engine.KERNEL_CD1)
+    acc = dict(sweeps1=0.0, sweeps2=0.0, p2_flops=0.0, p2_ms=0.0, p1_ms=0.0, best=None, best_step=-1)
+
+    def record(k, cur, out, b):
+        acc['sweeps1'] += float(out['sweeps1'].sum())
+        acc['sweeps2'] += float(out['visits2'].sum()) / n
+        acc['p2_flops'] += float(out['visits2'].sum()) * 2.0 * n   # algorithmic: 2n flops per visit
+        acc['p2_ms'] += cur.kernel_ms(Engine.KERNEL_CD2)
+        acc['p1_ms'] += cur.kernel_ms(Engine.KERNEL_CD1)
+        best = acc['best']
         if best is None or dist.better_key(b[1], b[2], b[0]) < dist.better_key(best[1], best[2], best[0]):
-            best, best_step = b, k
+            acc['best'], acc['best_step'] = b, k
+
+    t0 = time.perf_counter()
+    run_steps(args.steps, 0, record)
+    for e_ in engs:
+        e_.sync()
+    sweeps1, sweeps2, p2_flops, p2_ms, p1_ms = acc['sweeps1'], acc['sweeps2'], acc['p2_flops'], acc['p2_ms'], acc['p1_ms']
+    best, best_step = acc['best'], acc['best_step']
     eng.sync()
     eng.comm_barrier()
     dt = time.perf_counter() - t0
@@ -391,7 +420,10 @@ def main():
                                    '(BASELINE.json configs[1])' % (n, args.m_rows, args.restarts,
                                                                     'per GPU' if args.scaling == 'weak' else 'in total'),
                        'restarts_per_gpu': R, 'num_iters': 1000, 'viol_tol': 1e-2, 'tol': 1e-4,
-                       'sharding': 'restarts by global index, replicas of P'},
+                       'sharding': 'restarts by global index, replicas of P',
+                       'step_overlap': ('two contexts per GPU: suggest + phase 1 + evaluation + gate of step k+1 run in a second stream '
+                                        'while the phase-2 kernel of step k finishes; phase-2 kernels never overlap each other')
+                                       if args.overlap else 'none (steps strictly one after the other)'},
             'phase2_sweeps_per_restart': sweeps2_all / (K * world * max(R, 1)),
             'phase1': {'restart_sweeps_per_s_incl': (sweeps1_all + sweeps2_all) / dt,
                        'sweeps_per_restart': sweeps1_all / (K * world * max(R, 1)),

@@ -115,6 +115,15 @@ int qcqpmi_cd_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double viol_to
                   uint64_t seed, uint64_t first_index, int64_t *sweeps1, int64_t *sweeps2,
                   int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
                   double *maxviol);
+/* The same run in stages, for callers that keep two contexts (two HIP streams) on one GPU and overlap the preparation of
+ * the next population -- suggest, phase 1, evaluation, gate -- with the phase-2 kernel of the current one, whose tail leaves
+ * most CUs idle (bench.py).  stage 0 = qcqpmi_cd_run; 1 = phase 1 + evaluation + gate, asynchronous; 2 = launch of phase 2,
+ * asynchronous; 3 = results, blocking.  Stages 1..3 must be called in order with the same parameters; the output pointers
+ * are only used by stage 3 (and 0). */
+int qcqpmi_cd_run_stage(qcqpmi_ctx *ctx, int stage, int phase1, int64_t num_iters, double viol_tol, double tol,
+                        uint64_t seed, uint64_t first_index, int64_t *sweeps1, int64_t *sweeps2,
+                        int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
+                        double *maxviol);
 /* Per-restart status codes of the last qcqpmi_cd_run (R ints each; 0 = fine).  A restart on which the
  * reference would raise -- -1: np.random.uniform on an unbounded interval (utilities.py:267), -2: NameError in
  * OneVarQuadraticFunction.eval (utilities.py:119), -3: max() of an empty list (qcqp.py:117), -4: feasible set

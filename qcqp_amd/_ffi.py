@@ -40,6 +40,8 @@ PROTOTYPES = [
     ('qcqpmi_eval_batch', C.c_int, [C.c_void_p, c_dp, C.c_int64, c_dp, c_dp, c_dp]),
     ('qcqpmi_cd_run', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_uint64,
                                 C.c_uint64, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp]),
+    ('qcqpmi_cd_run_stage', C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_uint64,
+                                      C.c_uint64, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp]),
     ('qcqpmi_cd_status', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ('qcqpmi_feasible_intervals_batch', C.c_int, [C.c_int, C.c_int64, c_dp, C.POINTER(C.c_int), c_dp]),
     ('qcqpmi_onevar_qcqp_batch', C.c_int, [C.c_int, C.c_int64, c_dp, c_dp, C.POINTER(C.c_int), c_dp, C.c_uint64, c_dp,

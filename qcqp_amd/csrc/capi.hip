@@ -142,6 +142,7 @@ struct qcqpmi_ctx {
     int rank = 0, world = 1;
     double *d_comm = nullptr;
     long long *d_prof = nullptr;
+    int cd_stage = 0;                   // qcqpmi_cd_run_stage: last stage completed of a split run
     int64_t Xi_cap = 0;                 // doubles reserved for the standard normals of pop_sdr_sample
     bool sdr_factor_resident = false;   // d_Fpack / d_mu hold the pair of the last pop_sdr_sample
     double ad_Minv_rho = 0.0;           // rho of the z-solver matrix formed by qcqpmi_admm_zsolver_device
@@ -1166,16 +1167,27 @@ int qcqpmi_eval_batch(qcqpmi_ctx *c, const double *X, int64_t S, double *f0, dou
 
 // ------------------------------------------------------------------------- coordinate descent
 
-int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol, double tol,
-                  uint64_t seed, uint64_t first_index, int64_t *sweeps1, int64_t *sweeps2,
-                  int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
-                  double *maxviol) {
+// stage 0: the whole run.  Stages 1-3 split it for callers that overlap the preparation of the NEXT population with the
+// phase-2 kernel of the current one (two contexts = two streams): 1 = phase 1 + evaluation + gate (asynchronous),
+// 2 = launch of phase 2 (asynchronous), 3 = results (blocking).  Paths without a pipelined phase-2 kernel run everything
+// in stage 3.
+int qcqpmi_cd_run_stage(qcqpmi_ctx *c, int stage, int phase1, int64_t num_iters, double viol_tol, double tol,
+                        uint64_t seed, uint64_t first_index, int64_t *sweeps1, int64_t *sweeps2,
+                        int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
+                        double *maxviol) {
     int rc = check_ready(c, true);
     if (rc) return rc;
-    if (dense_on(c)) return cd_run_dense(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
-                                         accepted2, ran_phase2, f0, maxviol);
-    if (!c->sep) return cd_run_general(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
-                                       accepted2, ran_phase2, f0, maxviol);
+    if (stage < 0 || stage > 3) return fail(c, QCQPMI_EINVAL, "cd_run_stage: stage %d", stage);
+    if (stage >= 2 && c->cd_stage != stage - 1) return fail(c, QCQPMI_ESTATE, "cd_run_stage: stage %d without stage %d", stage, stage - 1);
+    const bool whole = dense_on(c) || !c->sep;      // these paths are not split
+    if (whole) {
+        if (stage == 1 || stage == 2) { c->cd_stage = stage; return 0; }
+        c->cd_stage = 0;
+        if (dense_on(c)) return cd_run_dense(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
+                                             accepted2, ran_phase2, f0, maxviol);
+        return cd_run_general(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
+                              accepted2, ran_phase2, f0, maxviol);
+    }
     if (c->maxc > 4)
         return fail(c, QCQPMI_EUNSUPPORTED, "more than 4 constraints on one coordinate (%d)", c->maxc);
     if (num_iters < 0 || !(tol > 0.0)) return fail(c, QCQPMI_EINVAL, "cd_run: bad num_iters / tol");
@@ -1187,41 +1199,56 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
     a.flag = c->d_flag;
     a.prof = nullptr; a.f0out = nullptr; a.mvout = nullptr;
     a.dbg = c->dbg;
-    if (c->profile) {
-        if (c->d_prof) { (void)hipFree(c->d_prof); c->d_prof = nullptr; }
-        if ((rc = dev_alloc(c, &c->d_prof, (size_t)(c->Rpad / 16) * 16 + QCQPMI_TRACE_WORDS))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->d_prof + (size_t)(c->Rpad / 16) * 16, 0, QCQPMI_TRACE_WORDS * sizeof(long long), c->stream));
-        a.prof = c->d_prof;
-    }
     bool used_lds = false;
     // Everything below is enqueued on the context's stream without a host round trip: phase 1,
     // evaluation, the improve_coord_descent gate, phase 2, final evaluation, result copies.
-    HIPCHK(c, hipMemsetAsync(c->d_sweeps1, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_status1, 0, (size_t)c->Rpad * sizeof(int), c->stream));
-    if (phase1) {
-        CdArgs a1 = a;
-        a1.sweeps = c->d_sweeps1;
-        a1.status = c->d_status1;
-        rc = (c->maxc <= 1) ? launch_cd<1>(c, a1, true, used_lds) : launch_cd<4>(c, a1, true, used_lds);
-        if (rc) return rc;
+    if (stage == 0 || stage == 1) {
+        HIPCHK(c, hipMemsetAsync(c->d_sweeps1, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_status1, 0, (size_t)c->Rpad * sizeof(int), c->stream));
+        if (phase1) {
+            CdArgs a1 = a;
+            a1.sweeps = c->d_sweeps1;
+            a1.status = c->d_status1;
+            rc = (c->maxc <= 1) ? launch_cd<1>(c, a1, true, used_lds) : launch_cd<4>(c, a1, true, used_lds);
+            if (rc) return rc;
+        }
+        // gate of improve_coord_descent (qcqp.py:189): phase 2 only if max violation < viol_tol.
+        // The evaluation also provides the phase-2 slack (qcqp.py:157) and the running objective.
+        if ((rc = launch_eval(c, false))) return rc;
+        hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((c->Rpad + 255) / 256)), dim3(256), 0, c->stream, c->d_mv,
+                           c->d_status1, c->d_flag, c->R, c->Rpad, viol_tol);
+        HIPCHK(c, hipGetLastError());
+        if (stage == 1) { c->cd_stage = 1; return 0; }
     }
-    // gate of improve_coord_descent (qcqp.py:189): phase 2 only if max violation < viol_tol.
-    // The evaluation also provides the phase-2 slack (qcqp.py:157) and the running objective.
-    if ((rc = launch_eval(c, false))) return rc;
-    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((c->Rpad + 255) / 256)), dim3(256), 0, c->stream, c->d_mv,
-                       c->d_status1, c->d_flag, c->R, c->Rpad, viol_tol);
-    HIPCHK(c, hipGetLastError());
-    // the pipelined kernel leaves objective and max violation of the restarts it ran in place (tracked objective,
-    // element-wise violations of the final tile): no evaluation pass afterwards
-    bool used_rs = false;
-    a.f0out = c->d_f0; a.mvout = c->d_mv;
-    rc = (c->maxc <= 1) ? launch_cd<1>(c, a, false, used_lds, &used_rs) : launch_cd<4>(c, a, false, used_lds, &used_rs);
-    if (rc) return rc;
-    if (!used_rs && (rc = launch_eval(c, false))) return rc;
+    if (stage == 0 || stage == 2) {
+        if (c->profile) {
+            if (c->d_prof) { (void)hipFree(c->d_prof); c->d_prof = nullptr; }
+            if ((rc = dev_alloc(c, &c->d_prof, (size_t)(c->Rpad / 16) * 16 + QCQPMI_TRACE_WORDS))) return rc;
+            HIPCHK(c, hipMemsetAsync(c->d_prof + (size_t)(c->Rpad / 16) * 16, 0, QCQPMI_TRACE_WORDS * sizeof(long long), c->stream));
+            a.prof = c->d_prof;
+        }
+        // the pipelined kernel leaves objective and max violation of the restarts it ran in place (tracked objective,
+        // element-wise violations of the final tile): no evaluation pass afterwards
+        bool used_rs = false;
+        a.f0out = c->d_f0; a.mvout = c->d_mv;
+        rc = (c->maxc <= 1) ? launch_cd<1>(c, a, false, used_lds, &used_rs) : launch_cd<4>(c, a, false, used_lds, &used_rs);
+        if (rc) return rc;
+        if (!used_rs && (rc = launch_eval(c, false))) return rc;
+        if (stage == 2) { c->cd_stage = 2; return 0; }
+    }
+    c->cd_stage = 0;
     std::vector<int> st, st1;
     if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
     if ((rc = cd_apply_status(c, st, st1, f0, maxviol, 0))) return rc;
     return 0;
+}
+
+int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol, double tol,
+                  uint64_t seed, uint64_t first_index, int64_t *sweeps1, int64_t *sweeps2,
+                  int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
+                  double *maxviol) {
+    return qcqpmi_cd_run_stage(c, 0, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2, accepted2,
+                               ran_phase2, f0, maxviol);
 }
 
 int qcqpmi_cd_status(qcqpmi_ctx *c, int *status1, int *status2) {

@@ -158,6 +158,32 @@ class Engine(object):
         out['status1'], out['status2'] = st1, st2     # != 0: the reference would raise on this restart (f0 = inf)
         return out
 
+    # the same run in stages (see qcqpmi_cd_run_stage): cd_begin and cd_phase2 only enqueue work on this context's stream
+    def cd_begin(self, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=0, first_index=0):
+        """Phase 1 + evaluation + gate of the resident population, asynchronous."""
+        self._cd_args = (int(bool(phase1)), int(num_iters), float(viol_tol), float(tol), int(seed), int(first_index))
+        self._chk(self.L.qcqpmi_cd_run_stage(self.h, 1, *self._cd_args, None, None, None, None, None, None, None))
+
+    def cd_phase2(self):
+        """Launch of phase 2, asynchronous."""
+        self._chk(self.L.qcqpmi_cd_run_stage(self.h, 2, *self._cd_args, None, None, None, None, None, None, None))
+
+    def cd_fetch(self):
+        """Results of the staged run (blocks until phase 2 has finished): the dictionary of cd_run."""
+        R = self.pop_size
+        out = dict(sweeps1=np.zeros(R, dtype=np.int64), sweeps2=np.zeros(R, dtype=np.int64),
+                   visits2=np.zeros(R, dtype=np.int64), accepted2=np.zeros(R, dtype=np.int64),
+                   ran_phase2=np.zeros(R, dtype=np.uint8), f0=np.empty(R), maxviol=np.empty(R))
+        self._chk(self.L.qcqpmi_cd_run_stage(self.h, 3, *self._cd_args, _ip(out['sweeps1']),
+                                             _ip(out['sweeps2']), _ip(out['visits2']), _ip(out['accepted2']),
+                                             _bp(out['ran_phase2']), _dp(out['f0']), _dp(out['maxviol'])))
+        st1 = np.zeros(R, dtype=np.int32)
+        st2 = np.zeros(R, dtype=np.int32)
+        self._chk(self.L.qcqpmi_cd_status(self.h, st1.ctypes.data_as(C.POINTER(C.c_int)),
+                                          st2.ctypes.data_as(C.POINTER(C.c_int))))
+        out['status1'], out['status2'] = st1, st2
+        return out
+
     # ----------------------------------------------------------------------- ADMM
     def admm_set_eig(self, lmb, Q):
         """lmb: (m, n), Q: (m, n, n) in NumPy eigh layout (Q[k][:, j] = eigenvector j)."""

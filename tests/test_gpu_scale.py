@@ -451,3 +451,43 @@ def test_admm_setup_on_device_vs_lapack(eng_mod, orc, family):
     # the matrix is gone after a host-side call: Minv = None must be refused, not silently reuse something stale
     with pytest.raises(Exception):
         e.admm_run(rho, None, phase1=True, num_iters=1)
+
+
+def test_cd_staged_run_two_contexts(eng_mod):
+    """qcqpmi_cd_run_stage: the staged run (prepare / launch phase 2 / fetch) returns bit for bit what qcqpmi_cd_run
+    returns, also when a second context prepares its population in between on its own stream -- the way bench.py overlaps
+    step k + 1 with the phase-2 kernel of step k.  Stages out of order are refused."""
+    from qcqp_amd import problems
+    from qcqp_amd.engine import EngineError
+    funcs, _, _ = problems.boolean_least_squares(256, 64, seed=2)
+    e1, e2, e0 = make(eng_mod, funcs), make(eng_mod, funcs), make(eng_mod, funcs)
+    R = 300
+    ref = []
+    for k in range(3):
+        e0.randn(R, seed=50 + k, first_index=7)
+        o = e0.cd_run(phase1=True, seed=50 + k, first_index=7)
+        ref.append((o, e0.download(), e0.select_best(1e-4)))
+    engs = [e1, e2]
+    engs[0].randn(R, seed=50, first_index=7)
+    engs[0].cd_begin(phase1=True, seed=50, first_index=7)
+    for k in range(3):
+        cur = engs[k % 2]
+        cur.cd_phase2()
+        if k + 1 < 3:
+            nxt = engs[(k + 1) % 2]
+            nxt.randn(R, seed=50 + k + 1, first_index=7)
+            nxt.cd_begin(phase1=True, seed=50 + k + 1, first_index=7)
+        o = cur.cd_fetch()
+        X = cur.download()
+        b = cur.select_best(1e-4)
+        ro, rX, rb = ref[k]
+        for key in ('sweeps1', 'sweeps2', 'visits2', 'accepted2', 'ran_phase2', 'f0', 'maxviol', 'status1', 'status2'):
+            assert np.array_equal(o[key], ro[key]), (k, key)
+        assert np.array_equal(X, rX)
+        assert b[:3] == rb[:3] and np.array_equal(b[3], rb[3])
+    with pytest.raises(EngineError):
+        e1.cd_phase2()          # no stage 1 before it
+    e1.randn(R, seed=1)
+    e1.cd_begin(seed=1)
+    with pytest.raises(EngineError):
+        e1.cd_fetch()           # stage 2 skipped
