@@ -355,17 +355,28 @@ def main():
 
     def run_steps(count, base, record):
         """`count` steps; step k = suggest(RANDOM) + improve(COORD_DESCENT) + selection of the best point."""
+        if count <= 0:
+            return
         prepare(engs[0], base)
+        engs[0].cd_phase2()
         for k in range(count):
             cur = engs[k % len(engs)]
-            cur.cd_phase2()
-            if len(engs) > 1 and k + 1 < count:
-                prepare(engs[(k + 1) % 2], base + k + 1)        # overlaps the phase-2 kernel just launched
-            out = cur.cd_fetch()
-            b = cur.comm_select_best(1e-4, index_offset=first)
+            more = k + 1 < count
+            if len(engs) > 1:
+                nxt = engs[(k + 1) % 2]
+                if more:
+                    prepare(nxt, base + k + 1)          # runs in the tail of the phase-2 kernel in flight
+                out = cur.cd_fetch()
+                if more:
+                    nxt.cd_phase2()                     # launched before the selection of step k is even looked at
+                b = cur.comm_select_best(1e-4, index_offset=first)
+            else:
+                out = cur.cd_fetch()
+                b = cur.comm_select_best(1e-4, index_offset=first)
+                if more:
+                    prepare(cur, base + k + 1)
+                    cur.cd_phase2()
             record(k, cur, out, b)
-            if len(engs) == 1 and k + 1 < count:
-                prepare(eng, base + k + 1)
 
     run_steps(args.warmup, -1000, lambda *_: None)
     for e_ in engs:
