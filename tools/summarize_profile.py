@@ -103,7 +103,10 @@ hdr = ['# rocprofv3 summary %s' % tag, '',
        'Pass 1 `--kernel-trace --stats`; passes 2-4 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc TCC_HIT_sum TCC_MISS_sum`',
        '(separate runs, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled (gfx950 reports half the bytes of',
        'wide coalesced reads); WRITE_SIZE is taken as is (uncalibrated).  Pass 5 `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`:',
-       'fraction of the SIMD-cycles of the launch during which the matrix pipe is busy (all MFMAs issued, useful or not).', '']
+       'fraction of the SIMD-cycles of the launch during which the matrix pipe is busy (all MFMAs issued, useful or not).',
+       'The bench overlaps the preparation of step k+1 and the selection of step k with the phase-2 kernel of the other context:',
+       'small kernels of the other stream (select_best, dense_products<2>, cd_phase1) wait for CUs the phase-2 tiles release, and',
+       'the trace counts that wait as their duration.  Phase-2 kernels never overlap each other.', '']
 open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(hdr + lines) + '\n')
 json.dump(out, open(os.path.join(dst, tag + '_summary.json'), 'w'), indent=1, sort_keys=True)
 print('\n'.join(lines))
