@@ -136,6 +136,8 @@ struct qcqpmi_ctx {
     void *dn_state = nullptr;
     hipStream_t stream2 = nullptr;   // second stream of the dense path: products of block b+1 while the chain walks b
     hipEvent_t dn_ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t dn_evn[2] = {nullptr, nullptr};   // "live count of sweep t copied" (dense path: the host runs one sweep ahead)
+    int *dn_hn = nullptr;                        // pinned: the two live counts in flight
     bool dn_force = false;    // generated functions: the dense path is the only one that holds them
     // comm
     ncclComm_t comm = nullptr;
@@ -598,6 +600,8 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
     for (auto &e : c->dn_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->dn_evn) if (e) (void)hipEventDestroy(e);
+    if (c->dn_hn) (void)hipHostFree(c->dn_hn);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
