@@ -290,6 +290,10 @@ struct AdmmZArgs {
     const double *Zlast;  // phase 2
     double *dist2;        // [R] ||Zlast - Znew||^2 (phase 2, diagonal solve)
     const uint8_t *act;
+    // phase 2, diagonal solve: f0 of the new z in the same pass (same expression and summation order as admm_f0_kernel)
+    const double *pdiag;  // [n16] P0_ii, or nullptr: no f0 here
+    double r0;
+    double *f0z;          // [R]
 };
 
 // one workgroup per tile: sums the planes of the consensus product and performs the z-update that needs no solve
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(ADMM_TPB) void admm_zupdate_kernel(AdmmZArgs a) {
     const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
     const int64_t r = tile * 16 + rr;
     const bool on = r < a.R && a.act[r];
-    double acc = 0.0;
+    double acc = 0.0, accf = 0.0;
     for (int64_t j = jl; j < a.n16; j += ADMM_TPB / 16) {
         const int64_t idx = (tile * a.n16 + j) * 16 + rr;
         double s = a.Sp[idx];
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(ADMM_TPB) void admm_zupdate_kernel(AdmmZArgs a) {
                 const double d = a.Zlast[idx] - zn;
                 acc += d * d;
                 a.Z[idx] = zn;
+                if (a.pdiag) accf += (a.pdiag[j] * zn + a.q0[j]) * zn;
             } else {
                 a.Y[idx] = rhs;
             }
@@ -328,6 +333,17 @@ __global__ __launch_bounds__(ADMM_TPB) void admm_zupdate_kernel(AdmmZArgs a) {
             double s = 0.0;
             for (int g = 0; g < ADMM_TPB / 16; g++) s += red[g * 16 + threadIdx.x];
             if (tile * 16 + threadIdx.x < a.R) a.dist2[tile * 16 + threadIdx.x] = s;
+        }
+        if (a.pdiag) {
+            __syncthreads();
+            red[threadIdx.x] = accf;
+            __syncthreads();
+            if (threadIdx.x < 16) {
+                double s = 0.0;
+                for (int g = 0; g < ADMM_TPB / 16; g++) s += red[g * 16 + threadIdx.x];
+                const int64_t rq = tile * 16 + threadIdx.x;
+                if (rq < a.R && a.act[rq]) a.f0z[rq] = s + a.r0;
+            }
         }
     }
 }
