@@ -309,7 +309,7 @@ def cpu_baseline(n, m_rows, seed, winner, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=250)      # ~1 s of timed work at N = 1
+    ap.add_argument('--steps', type=int, default=320)      # > 1 s of timed work at N = 1
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--n', type=int, default=1024)
     ap.add_argument('--m-rows', type=int, default=256)
