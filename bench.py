@@ -348,9 +348,18 @@ def main():
     # as the slowest restart -- suggest, phase 1, evaluation and gate of step k + 1 are already being worked on in the
     # other stream.  The phase-2 kernels themselves never overlap (the next one is launched after the results of the
     # current one have been fetched), so their HIP-event durations stay those of a kernel that owns the chip.
-    eng2 = Engine(form, device=local_rank) if args.overlap else None
-    if eng2 is not None:
-        dist.init_rccl(eng2, rank, world, bootstrap=boot)       # its own communicator (same rendezvous object)
+    eng2 = None
+    if args.overlap:
+        try:
+            eng2 = Engine(form, device=local_rank)
+            dist.init_rccl(eng2, rank, world, bootstrap=boot)   # its own communicator (same rendezvous object)
+            ok = 1.0
+        except Exception as ex:     # never lose the run over the optimisation: fall back to strictly serial steps
+            sys.stderr.write('bench: second context unavailable (%r): steps will not overlap\n' % (ex,))
+            eng2, ok = None, 0.0
+        if world > 1:               # every rank must take the same path (the collectives alternate between the communicators)
+            if float(eng.comm_allreduce([ok], 'sum')[0]) < world:
+                eng2 = None
     engs = [eng, eng2] if eng2 is not None else [eng]
 
     def prepare(e, k):
@@ -438,7 +447,7 @@ def main():
                        'sharding': 'restarts by global index, replicas of P',
                        'step_overlap': ('two contexts per GPU: suggest + phase 1 + evaluation + gate of step k+1 run in a second stream '
                                         'while the phase-2 kernel of step k finishes; phase-2 kernels never overlap each other')
-                                       if args.overlap else 'none (steps strictly one after the other)'},
+                                       if len(engs) > 1 else 'none (steps strictly one after the other)'},
             'phase2_sweeps_per_restart': sweeps2_all / (K * world * max(R, 1)),
             'phase1': {'restart_sweeps_per_s_incl': (sweeps1_all + sweeps2_all) / dt,
                        'sweeps_per_restart': sweeps1_all / (K * world * max(R, 1)),
