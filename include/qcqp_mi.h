@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QCQPMI_ABI_VERSION 2
+#define QCQPMI_ABI_VERSION 3
 
 enum {
     QCQPMI_OK = 0,
@@ -224,9 +224,18 @@ int qcqpmi_select_best(qcqpmi_ctx *ctx, double tol, int64_t *best_index, double 
  * which: 0 = eval, 1 = cd phase 1, 2 = cd phase 2, 3 = sdr sampling, 4 = admm secular kernel.  Returns the duration of
  * the most recent launch of that kernel in milliseconds. */
 int qcqpmi_last_kernel_ms(qcqpmi_ctx *ctx, int which, double *ms);
-/* name of the phase-2 kernel the most recent qcqpmi_cd_run dispatched to ("cd_phase2_q_kernel", "cd_phase2_rs_kernel",
- * "" for the general / dense paths): static storage */
+/* name of the phase-2 kernel the most recent qcqpmi_cd_run dispatched to: "cd_phase2_q_kernel" (pipelined, Boolean family),
+ * "cd_phase2_rs_kernel" (its predecessor: box families, n not a multiple of 16, n > 1024), "cd_phase2_kernel" (general
+ * separable constraints), "dense_chain_kernel" (constraints that couple coordinates, n > 64 or generated),
+ * "cd_general_kernel" (coupled constraints in the reference's arithmetic); static storage.  The parity tests assert it. */
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *ctx);
+/* Coordinate descent for constraints that couple coordinates IN THE REFERENCE'S SUMMATION ORDER (test / diagnostic mode, any
+ * n): every one-variable coefficient (t2, t1, t0) of get_onevar_func (utilities.py:99-105) is formed by row-sequential sums
+ * like the reference's CSR products -- t0 = f_k(z) afresh per coordinate, O((m+1) n^2) per coordinate visit -- so that
+ * trajectories are comparable with the reference value for value where the MFMA path (different summation order, 1e-13
+ * input noise amplified by the phase-1 bisection) is only comparable as a distribution.  Needs uploaded (not generated)
+ * functions with m n^2 <= 2e9 entries.  enable = 0 restores the default dispatch. */
+int qcqpmi_cd_reference_order(qcqpmi_ctx *ctx, int enable);
 int qcqpmi_sync(qcqpmi_ctx *ctx);
 /* debug: enable in-kernel cycle counters of the phase-2 kernel / read their sums over tiles
  * (slots: 0 mfma, 1 feasible sets, 2 barrier, 3 sequential part, 4 barrier, 5 #blocks) */

@@ -67,6 +67,9 @@ def lib():
         L.orc_philox4x32.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.orc_keyed_normal.restype = C.c_double
         L.orc_keyed_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_generated_eval.restype = None
+        L.orc_generated_eval.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         _dp, C.c_int64, _dp]
         L.orc_eval.restype = C.c_double
         L.orc_eval.argtypes = [C.c_void_p, C.c_int64, _dp]
         L.orc_violation.restype = C.c_double
@@ -353,6 +356,17 @@ def philox4x32(ctr, key):
 
 def keyed_normal(seed, restart, elem):
     return lib().orc_keyed_normal(seed, restart, elem)
+
+
+def generated_eval(spec, k, n, X):
+    """f_k(x) for the columns of X (n, S) of a device-generated function (problems.GeneratedForm.specs[k]) without
+    materialising P_k: n (n + 1) / 2 keyed normals, ~1 s per function at n = 4096."""
+    X = np.asarray(X, dtype=np.float64)
+    Xc = np.ascontiguousarray(X.T)
+    out = np.zeros(Xc.shape[0])
+    lib().orc_generated_eval(int(spec['seed']), int(k), int(n), float(spec['scale']), float(spec['qscale']),
+                             float(spec['diag_add']), float(spec['r']), _d(Xc), Xc.shape[0], _d(out))
+    return out
 
 
 def keyed_normal_matrix(seed, n, R, first_index=0):

@@ -169,6 +169,36 @@ double orc_keyed_normal(uint64_t seed, uint64_t restart, uint64_t elem) {
     return (elem & 1) ? rad * sin(ang) : rad * cos(ang);
 }
 
+/* Values f_k(x_s) = x_s' P_k x_s + q_k' x_s + r_k of a SYNTHETIC function that the engine generates on the device
+ * (qcqpmi_set_quad_generated; BASELINE.json configs[4]: 1025 dense 4096 x 4096 matrices that no host can hold; SURVEY.md
+ * section 8(d) cfg5).  The law is restated here from include/qcqp_mi.h -- P_k[i][j] = scale w_ij N(seed, 2^48 + k,
+ * min(i,j) n + max(i,j)) + diag_add [i == j], w_ii = 1, w_ij = 1/sqrt(2); q_k[j] = qscale N(seed, 2^49 + k, j) -- and
+ * evaluated entry by entry without materialising the matrix (QuadraticFunction.eval, utilities.py:49-50), so that the
+ * full-size tests can check single functions of the 137.6 GB problem.  X: S x n sample-major. */
+void orc_generated_eval(uint64_t seed, int64_t k, int64_t n, double scale, double qscale, double diag_add, double r,
+                        const double *X, int64_t S, double *out) {
+    const double w = 0.70710678118654752440;
+    for (int64_t s = 0; s < S; s++) out[s] = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        for (int64_t j = i; j < n; j++) {
+            double v = (scale != 0.0) ? scale * orc_keyed_normal(seed, ((uint64_t)1 << 48) + (uint64_t)k, (uint64_t)(i * n + j)) : 0.0;
+            if (i == j) {
+                v += diag_add;
+                if (v != 0.0)
+                    for (int64_t s = 0; s < S; s++) out[s] += v * X[s * n + i] * X[s * n + i];
+            } else if (v != 0.0) {
+                v *= w;
+                for (int64_t s = 0; s < S; s++) out[s] += 2.0 * v * X[s * n + i] * X[s * n + j];
+            }
+        }
+        if (qscale != 0.0) {
+            const double q = qscale * orc_keyed_normal(seed, ((uint64_t)2 << 48) + (uint64_t)k, (uint64_t)i);
+            for (int64_t s = 0; s < S; s++) out[s] += q * X[s * n + i];
+        }
+    }
+    for (int64_t s = 0; s < S; s++) out[s] += r;
+}
+
 orc_rng *orc_rng_new(int mode, uint64_t seed) {
     orc_rng *g = (orc_rng *)calloc(1, sizeof(*g));
     g->mode = mode;

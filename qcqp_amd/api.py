@@ -188,7 +188,7 @@ class QCQP(object):
                     else:
                         info['converged'] = None      # slack matrix too large to check on the host
                     # the dual value -y_N is the bound when the slack is PSD; otherwise only the primal value exists
-                    sol = (X, info['dual_value'] if info.get('converged') else primal, info)
+                    sol = (X, info['dual_value'] if info.get('converged') else None, info)
                 if sol is None:
                     fam = _sdr.separable_family(self.qcqp_form)
                     if fam is not None:
@@ -196,14 +196,22 @@ class QCQP(object):
                         X, primal, info = _sdr.solve_sdr_separable(self.engine, self.qcqp_form, seed=sd)
                         lmin, S = _sdr.dual_slack_separable(self.qcqp_form, fam, info['y'], info['yN'])
                         _sdr.certify(info, lmin, 1.0 + float(np.max(np.abs(S))), 'solve_sdr (separable)')
-                        sol = (X, info['dual_value'] if info['converged'] else primal, info)
+                        sol = (X, info['dual_value'] if info['converged'] else None, info)
                 if sol is None:
                     raise Exception("SDR suggest: no built-in SDP solver applies to this problem; pass "
                                     "suggest(SDR, X=...) or set qcqp.sdr_sol / qcqp.sdr_bound first.")
                 self.sdr_sol, bound, self.sdr_info = sol
-                self.sdr_bound = -bound if self.maximize_flag else bound    # qcqp.py:392-393
-                log.info('solve_sdr: bound %.8g (primal %.8g, converged %s)', bound, self.sdr_info.get('primal', bound),
-                         self.sdr_info.get('converged'))
+                # qcqp.py:392-393.  An uncertified solve publishes NO bound (the reference raises unless the solver reports
+                # OPTIMAL, qcqp.py:94-95): the primal value <C, VV'> of an inexact factor is an upper estimate, kept only
+                # in sdr_info['primal'].
+                if bound is None:
+                    self.sdr_bound = None
+                    log.warning('solve_sdr: relaxation not certified (primal value %.8g kept in sdr_info); sdr_bound = None',
+                                self.sdr_info.get('primal', float('nan')))
+                else:
+                    self.sdr_bound = -bound if self.maximize_flag else bound
+                    log.info('solve_sdr: bound %.8g (primal %.8g, converged %s)', bound,
+                             self.sdr_info.get('primal', bound), self.sdr_info.get('converged'))
             if not hasattr(self, 'mu'):
                 X = np.asarray(self.sdr_sol, dtype=np.float64)
                 self.mu = np.asarray(X[:-1, -1]).flatten()
@@ -241,6 +249,9 @@ class QCQP(object):
             seed = kwargs.get('seed', None)
             if seed is None:
                 seed = int(np.random.randint(0, 2 ** 31 - 1))
+            # reference_order=True: constraints that couple coordinates are walked in the reference's summation order
+            # (slow; trajectories comparable with the reference value for value at any n -- qcqpmi_cd_reference_order)
+            self.engine.cd_reference_order(bool(kwargs.get('reference_order', False)))
             out = self.engine.cd_run(phase1=phase1, num_iters=num_iters, viol_tol=viol_tol, tol=tol,
                                      seed=seed)
             self.last_stats = dict(out, method=method, num_restarts=len(out['f0']),

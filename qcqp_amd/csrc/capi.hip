@@ -152,6 +152,7 @@ struct qcqpmi_ctx {
     const char *last_cd2_kernel = "";     // name of the phase-2 kernel of the most recent cd run (bench / profiles)
     bool profile = false;
     int dbg = 0;
+    bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
     std::vector<int> last_st1, last_st2;   // per-restart status codes of the last coordinate-descent run (qcqpmi_cd_status)
 };
@@ -376,7 +377,7 @@ int launch_eval(qcqpmi_ctx *c, bool want_F) {
 template <int MAXC>
 int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool *used_rs = nullptr) {
     if (used_rs) *used_rs = false;
-    if (!phase1) c->last_cd2_kernel = "";
+    if (!phase1) c->last_cd2_kernel = "cd_phase2_kernel";
     dim3 grid((unsigned)(c->Rpad / 16)), block(256);
     if (phase1) {
         tic(c, 1);
@@ -510,7 +511,7 @@ int cd_run_general(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol
     a.visits = c->d_visits; a.accepted = c->d_acc; a.sweeps = c->d_sweeps; a.status = c->d_status;
     a.flag = c->d_flag; a.prof = nullptr; a.dbg = 0; a.f0out = nullptr; a.mvout = nullptr;
     g.gP = c->d_gP; g.Rpad = c->Rpad;
-    g.exact_t0 = (c->n <= 64 && !(c->dbg & 16)) ? 1 : 0;   // small problems: the reference's own arithmetic for t0
+    g.exact_t0 = ((c->n <= 64 || c->cd_ref_order) && !(c->dbg & 16)) ? 1 : 0;   // small problems (or on request): the reference's own arithmetic for t0
     dim3 grid((unsigned)(c->Rpad / 16)), block(256);
     auto k1 = cd_general_kernel<1>;
     auto k2 = cd_general_kernel<2>;
@@ -778,6 +779,12 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
         if (coord < 0) sep = false;  // constant constraint
         coord_of[(size_t)k - 1] = coord;
     }
+    if (sep) {
+        // the per-lane one-variable solver holds at most 4 constraints per coordinate (onevar.h); problems with more go
+        // through the paths for general constraints below, which take any number (utilities.py:241-255 takes any m)
+        std::vector<int> per((size_t)n, 0);
+        for (int64_t k = 0; k < m && sep; k++) sep = ++per[(size_t)coord_of[k]] <= 4;
+    }
     c->sep = sep;
     dp.sep = sep ? 1 : 0;
     int rc;
@@ -996,6 +1003,9 @@ int qcqpmi_pop_sdr_sample(qcqpmi_ctx *c, const double *mu, const double *F, int6
         hipLaunchKernelGGL(pack_A_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_Frow, c->d_Fpack, n16, c->dp.KS);
         c->sdr_factor_resident = true;
+        // the 2D copy may pin the caller's pages and return with the DMA in flight; the caller (Engine.sdr_sample passes
+        // temporaries) may free F / mu as soon as this call returns.  The reuse path (mu = F = NULL) stays asynchronous.
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     if ((rc = pop_reserve(c, S))) return rc;
     // the standard normals: caller-provided (host layout) or device Philox; the buffer is kept across calls
@@ -1031,7 +1041,7 @@ int qcqpmi_pop_sdr_sample(qcqpmi_ctx *c, const double *mu, const double *F, int6
     }
     toc(c, 3);
     HIPCHK(c, hipGetLastError());
-    // host inputs were staged by (synchronous) pageable copies: nothing of the caller's is referenced any more.  The
+    // F / mu were synchronised above; a caller-provided Xi went through a pageable 1D copy (host-synchronous staging).  The
     // samples are in stream order for whatever comes next (evaluation, download); no synchronisation here.
     return 0;
 }
@@ -1187,13 +1197,15 @@ int qcqpmi_cd_run_stage(qcqpmi_ctx *c, int stage, int phase1, int64_t num_iters,
     if (whole) {
         if (stage == 1 || stage == 2) { c->cd_stage = stage; return 0; }
         c->cd_stage = 0;
-        if (dense_on(c)) return cd_run_dense(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
+        c->last_cd2_kernel = (dense_on(c) && !c->cd_ref_order) ? "dense_chain_kernel" : "cd_general_kernel";
+        if (c->cd_ref_order && !c->d_gP)
+            return fail(c, QCQPMI_EUNSUPPORTED, "reference-order coordinate descent needs the row-major constraint matrices "
+                        "(uploaded functions, m n^2 <= 2e9 entries); device-generated functions only exist packed");
+        if (dense_on(c) && !c->cd_ref_order) return cd_run_dense(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
                                              accepted2, ran_phase2, f0, maxviol);
         return cd_run_general(c, phase1, num_iters, viol_tol, tol, seed, first_index, sweeps1, sweeps2, visits2,
                               accepted2, ran_phase2, f0, maxviol);
     }
-    if (c->maxc > 4)
-        return fail(c, QCQPMI_EUNSUPPORTED, "more than 4 constraints on one coordinate (%d)", c->maxc);
     if (num_iters < 0 || !(tol > 0.0)) return fail(c, QCQPMI_EINVAL, "cd_run: bad num_iters / tol");
     HIPCHK(c, hipSetDevice(c->device));
     CdArgs a;
@@ -1294,6 +1306,12 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 }
 
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
+
+int qcqpmi_cd_reference_order(qcqpmi_ctx *c, int enable) {
+    if (!c) return QCQPMI_EINVAL;
+    c->cd_ref_order = enable != 0;
+    return 0;
+}
 
 int qcqpmi_last_kernel_ms(qcqpmi_ctx *c, int which, double *ms) {
     if (!c || which < 0 || which > 4 || !ms) return QCQPMI_EINVAL;

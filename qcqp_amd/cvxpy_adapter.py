@@ -8,7 +8,7 @@ The coefficients are read off by EVALUATION: a quadratic f(x) = x'Px + q'x + r i
 0, +-e_i and e_i + e_j (exact for a quadratic up to rounding -- these are not finite-difference approximations):
     r = f(0),  q_i = (f(e_i) - f(-e_i)) / 2,  P_ii = (f(e_i) + f(-e_i)) / 2 - r,
     P_ij = P_ji = (f(e_i + e_j) - f(e_i) - f(e_j) + r) / 2.
-1 + 2n + n(n-1)/2 evaluations of all expressions at once: meant for the problem sizes one writes by hand in
+1 + 2n + 2(n+1) + (pairs of variables that share a function) <= 3 + 4n + n(n-1)/2 evaluations of all expressions at once: meant for the problem sizes one writes by hand in
 cvxpy (n up to a few hundred); large instances should be passed as raw arrays (qcqp_amd.Problem).
 One QuadraticFunction per SCALAR entry of every constraint, like utilities.py:341-345; P is symmetric by
 construction (utilities.py:333, 345); a maximised objective is negated (utilities.py:335-336).
@@ -154,8 +154,21 @@ def problem_from_cvxpy(prob):
         q = 0.5 * (fp - fm)                                   # (n, K)
         P = np.zeros((K, n, n))
         P[:, np.arange(n), np.arange(n)] = (0.5 * (fp + fm) - f00[None, :]).T
-        # only pairs that can interact: a function whose value does not move with x_i has no P_ij
+        # Only pairs that can interact: function k has no P_ij unless it DEPENDS on both x_i and x_j.  "Depends" is tested
+        # at generic points, not on the axes alone (a bilinear term x_i x_j leaves f unchanged along either axis: the
+        # round-2 test `f(+-e_i) != f(0)` dropped such P_ij silently): f(v + e_i) != f(v) for two fixed pseudo-random v.
+        # An expression that does not contain x_i evaluates bit-identically, so the test has no false negatives except on
+        # a measure-zero set of v (two independent v make that set empty for practical purposes) and no tolerance.
         touched = (fp != f00[None, :]) | (fm != f00[None, :])  # (n, K)
+        prng = np.random.RandomState(0x5eed)
+        for _ in range(2):
+            v = prng.uniform(0.5, 1.5, size=n) * prng.choice([-1.0, 1.0], size=n)
+            fv = evaluate(v)
+            for i in range(n):
+                keep = v[i]
+                v[i] = keep + 1.0
+                touched[i] |= (evaluate(v) != fv)
+                v[i] = keep
         for i in range(n):
             for j in range(i + 1, n):
                 if not np.any(touched[i] & touched[j]):

@@ -14,8 +14,9 @@ Two ways to get N ranks:
   * `spawn_local_ranks(N, argv)` from a plain `python bench.py --gpus N`: the calling process becomes
     rank 0 and N-1 children are started with the same command line.
 """
+import json
 import os
-import pickle
+import stat
 import subprocess
 import sys
 import tempfile
@@ -68,36 +69,102 @@ def _job_key():
                                 os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())
 
 
+def _job_epoch():
+    """Earliest time a message of THIS job can have been written: the start of the launcher (external launcher: the key
+    is predictable, so files of a crashed earlier job with a recycled pid must not be read as messages)."""
+    if os.environ.get(RDZV_ENV):
+        return 0.0                      # uuid key: the directory cannot pre-exist
+    try:
+        return os.stat('/proc/%d' % os.getppid()).st_mtime - 2.0
+    except OSError:
+        return 0.0
+
+
+def _private_dir(path):
+    """mkdir -p with mode 0700, then insist that the directory is ours and closed to group / others (a shared /tmp:
+    another local user must not be able to pre-create the job directory and plant messages)."""
+    try:
+        os.makedirs(path, mode=0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError('rendezvous directory %s is not a private directory of uid %d (mode %o, owner %d)'
+                           % (path, os.getuid(), st.st_mode & 0o7777, st.st_uid))
+    return path
+
+
+def _rdzv_root():
+    base = os.environ.get('XDG_RUNTIME_DIR')
+    if base and os.path.isdir(base) and os.access(base, os.W_OK):
+        return _private_dir(os.path.join(base, 'qcqp_amd_rdzv'))
+    return _private_dir(os.path.join(tempfile.gettempdir(), 'qcqp_amd_rdzv_%d' % os.getuid()))
+
+
+def _encode(obj):
+    """Messages are raw bytes (the 128-byte RCCL id, a point) or small JSON values (keys, None): nothing executable
+    is ever deserialised (round 2 used pickle)."""
+    if isinstance(obj, (bytes, bytearray, memoryview)):
+        return b'B' + bytes(obj)
+    return b'J' + json.dumps(obj).encode('ascii')
+
+
+def _tuplify(v):
+    return tuple(_tuplify(a) for a in v) if isinstance(v, list) else v
+
+
+def _decode(raw):
+    if raw[:1] == b'B':
+        return raw[1:]
+    if raw[:1] == b'J':
+        return _tuplify(json.loads(raw[1:].decode('ascii')))
+    raise RuntimeError('malformed rendezvous message')
+
+
 class FileRendezvous(object):
-    """Moves small Python objects between the ranks of one node through atomically renamed files."""
+    """Moves small messages (bytes / JSON values) between the ranks of one node through atomically renamed files in a
+    directory only this user can enter."""
 
     def __init__(self, rank=None, world=None, key=None, timeout=600.0):
         r, _, w = env_world()
         self.rank = r if rank is None else int(rank)
         self.world = w if world is None else int(world)
         self.timeout = float(timeout)
-        self.dir = os.path.join(tempfile.gettempdir(), 'qcqp_amd_rdzv', key or _job_key())
-        os.makedirs(self.dir, exist_ok=True)
+        key = key or _job_key()
+        if os.sep in key or key in ('.', '..'):
+            raise ValueError('bad rendezvous key %r' % key)
+        self.dir = _private_dir(os.path.join(_rdzv_root(), key))
+        self.epoch = _job_epoch()
         self.seq = 0
 
     def _put(self, name, obj):
         path = os.path.join(self.dir, name)
         tmp = '%s.tmp.%d' % (path, os.getpid())
-        with open(tmp, 'wb') as f:
-            pickle.dump(obj, f, protocol=2)
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        with os.fdopen(fd, 'wb') as f:
+            f.write(_encode(obj))
         os.rename(tmp, path)
+
+    def _fresh(self, path):
+        try:
+            st = os.lstat(path)
+        except OSError:
+            return False
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid():
+            raise RuntimeError('foreign file %s in the rendezvous directory' % path)
+        return st.st_mtime >= self.epoch      # older: left behind by a dead job with the same key -> not a message
 
     def _get(self, name):
         path = os.path.join(self.dir, name)
         t0 = time.time()
         delay = 0.0005
-        while not os.path.exists(path):
+        while not self._fresh(path):
             if time.time() - t0 > self.timeout:
                 raise RuntimeError('rendezvous timeout waiting for %s (rank %d of %d)' % (path, self.rank, self.world))
             time.sleep(delay)
             delay = min(delay * 1.5, 0.05)
         with open(path, 'rb') as f:
-            return pickle.load(f)
+            return _decode(f.read())
 
     def broadcast_bytes(self, payload, src=0):
         self.seq += 1

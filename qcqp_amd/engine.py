@@ -316,8 +316,13 @@ class Engine(object):
         return float(ms[0])
 
     def last_cd_kernel(self):
-        """Name of the phase-2 kernel the most recent cd_run dispatched to ('' for the general / dense paths)."""
+        """Name of the phase-2 kernel the most recent cd_run dispatched to (see qcqpmi_last_cd_kernel)."""
         return (self.L.qcqpmi_last_cd_kernel(self.h) or b'').decode()
+
+    def cd_reference_order(self, enable=True):
+        """Coupled constraints: coordinate descent in the reference's summation order (slow, value-for-value comparable with
+        the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""
+        self._chk(self.L.qcqpmi_cd_reference_order(self.h, 1 if enable else 0))
 
     def sync(self):
         self._chk(self.L.qcqpmi_sync(self.h))

@@ -303,3 +303,49 @@ def test_api_on_device_generated_problem():
     f2, v2 = q.improve(COORD_DESCENT, num_iters=20, seed=1)
     assert v2 < 1e-2 and f2 >= q.sdr_bound - 1e-2 * (1 + abs(q.sdr_bound))
     assert q.prob.variables()[0].value.shape == (40, 1)
+
+
+def test_cvxpy_adapter_drives_the_gpu_path():
+    """SURVEY 8f-2 on the device: a duck-typed cvxpy >= 1 problem -- the README example as one writes it in cvxpy,
+    minimize sum_squares(A x - b) s.t. square(x) == 1 (examples/boolean_least_squares.py:6-15; get_qcqp_form,
+    utilities.py:318-347) -- goes through qcqp_amd.cvxpy_adapter into the HIP engine: QCQP(problem) ->
+    suggest(RANDOM) -> improve(COORD_DESCENT) -> improve([COORD_DESCENT, ADMM], phase1=False) must return what the
+    raw-array path returns BIT FOR BIT (the extracted coefficients are exact for this data up to the rounding of the
+    probe evaluations, so the form is compared first), the reference's golden (f, v) of G10 are met, and the cvxpy
+    variable holds the final point in its own shape."""
+    from duck_cvxpy import Var, Expr, Objective, Equality, Prob
+    from qcqp_amd import QCQP, RANDOM, COORD_DESCENT, ADMM
+    z = load_golden('g10_api_bls10')
+    funcs = funcs_from_npz(z)
+    n = funcs[0][0].shape[0]
+    P0, q0, r0 = np.asarray(funcs[0][0]), np.asarray(funcs[0][1]), float(funcs[0][2])
+    x = Var((n,))
+    obj = Expr(lambda: float(x.value.dot(P0).dot(x.value) + q0.dot(x.value) + r0), ())
+    cons = [Equality(Expr(lambda: x.value ** 2 - 1.0, (n,)))]
+    qa = QCQP(Prob(Objective('minimize', obj), cons, [x]))
+    qr = handler(funcs)
+    fa, fr = qa.qcqp_form, qr.qcqp_form
+    assert (fa.n, fa.m) == (fr.n, fr.m)
+    assert np.max(np.abs(np.asarray(fa.f0.P) - np.asarray(fr.f0.P))) < 1e-12 * np.max(np.abs(P0))
+    # identical coefficients from here on: the comparison below is about the PATH (adapter -> variables -> engine)
+    qa2 = QCQP(Prob(Objective('minimize', obj), cons, [x]))
+    qa2.qcqp_form.f0.P[...] = np.asarray(fr.f0.P)
+    qa2.qcqp_form.f0.qarray[...] = fr.f0.qarray
+    qa2.qcqp_form.f0.r = fr.f0.r
+    qa2 = QCQP(qa2.prob)            # engine rebuilt on the patched form
+    res = []
+    for q in (qa2, qr):
+        np.random.seed(int(z['seed']))
+        out = [q.suggest(RANDOM)]
+        out.append(q.improve(COORD_DESCENT, seed=11))
+        out.append(q.improve([COORD_DESCENT, ADMM], phase1=False, seed=12))
+        res.append((out, np.ravel(q.prob.variables()[0].value, order='F').copy()))
+    (oa, xa), (orr, xr) = res
+    assert oa == orr and np.array_equal(xa, xr)
+    assert abs(oa[0][0] - z['fv'][0, 0]) <= 1e-12 * (1 + abs(oa[0][0])) and abs(oa[0][1] - z['fv'][0, 1]) <= 1e-13
+    assert x.value.shape == (n,) and np.array_equal(x.value, xa)      # the cvxpy variable itself carries the point
+    # the adapter's own extraction (no patching) ends on the same point to rounding
+    np.random.seed(int(z['seed']))
+    qa.suggest(RANDOM)
+    f1, v1 = qa.improve(COORD_DESCENT, seed=11)
+    assert abs(f1 - oa[1][0]) <= 1e-9 * (1 + abs(f1)) and abs(v1 - oa[1][1]) <= 1e-9

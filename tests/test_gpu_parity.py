@@ -57,6 +57,12 @@ def test_cd_phase2_matches_reference_golden(eng_mod, name, generic):
     e.L.qcqpmi_debug_profile(e.h, 2 if generic else 0, None)
     e.upload(z['X0'])
     out = e.cd_run(phase1=False)
+    # which kernel ran (a regression of the pipelined kernel's eligibility test must not hide behind its fallbacks):
+    # n = 64 is the smallest size the pipelined kernel takes (>= 3 blocks of 16), n = 10 / 32 and the zero-diagonal
+    # MAXCUT objective go to its round-1 predecessor
+    want = 'cd_phase2_kernel' if generic else {'bls10': 'cd_phase2_rs_kernel', 'bls32': 'cd_phase2_rs_kernel',
+                                               'bls64': 'cd_phase2_q_kernel', 'maxcut12': 'cd_phase2_rs_kernel'}[name]
+    assert e.last_cd_kernel() == want, (e.last_cd_kernel(), want)
     X = e.download()
     assert rel(X, z['p2_x']) < 1e-9
     assert rel(out['f0'], z['p2_fv'][:, 0]) < 1e-9
@@ -78,6 +84,8 @@ def test_cd_full_driver_vs_oracle_keyed(eng_mod, orc, name, n, m_rows, generic):
     X0 = np.random.RandomState(1).randn(n, R)
     e.upload(X0)
     out = e.cd_run(phase1=True, num_iters=50, seed=seed, first_index=first)
+    want = 'cd_phase2_kernel' if generic else ('cd_phase2_q_kernel' if (name, n) == ('bls', 96) else 'cd_phase2_rs_kernel')
+    assert e.last_cd_kernel() == want, (e.last_cd_kernel(), want)
     X = e.download()
     for r in range(R):
         rng = orc.Rng(orc.RNG_KEYED, seed)
@@ -148,6 +156,7 @@ def test_cd_coupled_constraints_phase2_matches_reference_golden(eng_mod, name):
     assert not e.separable
     e.upload(z['X0'])
     out = e.cd_run(phase1=False)
+    assert e.last_cd_kernel() == 'cd_general_kernel'
     X = e.download()
     assert rel(X, z['p2_x']) < 1e-8
     assert rel(out['f0'], z['p2_fv'][:, 0]) < 1e-8
@@ -192,6 +201,7 @@ def test_full_size_headline_config(eng_mod, orc):
     e.randn(R, seed=seed)
     X0 = e.download()
     out = e.cd_run(seed=seed)
+    assert e.last_cd_kernel() == 'cd_phase2_q_kernel'      # the headline kernel, not one of its fallbacks
     X = e.download()
     ran = out['ran_phase2'].astype(bool)
     # a few restarts get stuck in phase 1 exactly like in the reference: a coordinate whose
@@ -234,8 +244,9 @@ def test_full_size_headline_config(eng_mod, orc):
 # ------------------------------------------------------------------------------------- ADMM
 @pytest.mark.parametrize('name', ['beam10', 'beam40', 'bls10', 'dense16'])
 def test_admm_matches_reference_golden(eng_mod, orc, name):
-    """improve_admm on the GPU (eigenbasis formulation, rocBLAS products + hand-written secular
-    kernel) against the reference's own result (golden G8), fed the reference's eigenpairs."""
+    """improve_admm on the GPU (eigenbasis formulation: the engine's own fp64 MFMA GEMM for the two products per
+    iteration + the hand-written secular kernel; no vendor BLAS) against the reference's own result (golden G8), fed the
+    reference's eigenpairs."""
     z = load_golden('g8_admm_' + name)
     funcs = funcs_from_npz(z)
     e = make(eng_mod, funcs)
@@ -332,6 +343,7 @@ def test_cd_general_separable_vs_oracle(eng_mod, orc, per_coord, objective):
     try:
         out = e.cd_run(phase1=True, num_iters=60, seed=seed, first_index=3)
         gpu_err = None
+        assert e.last_cd_kernel() == 'cd_phase2_kernel'
     except eng_mod.EngineError as err:
         gpu_err = str(err)
     X = e.download()
@@ -399,6 +411,62 @@ def test_cd_coupled_constraints_tracked_mode_quality(eng_mod, orc):
         assert abs(prob.eval(0, X[:, r]) - out['f0'][r]) <= 1e-9 * (1 + abs(out['f0'][r]))
 
 
+@pytest.mark.parametrize('per_coord,n', [(5, 24), (8, 24), (6, 80)])
+def test_cd_more_than_four_constraints_per_coordinate(eng_mod, orc, per_coord, n):
+    """utilities.py:241-255 takes any number of constraints on a coordinate; the per-lane solver of the separable
+    kernels holds four.  Round 2 refused such problems (QCQPMI_EUNSUPPORTED); now they are routed to the paths for
+    general constraints (n <= 64: cd_general_kernel in the reference's arithmetic, trajectories equal to the oracle's;
+    above: the dense path, compared like every run of that path -- reported values exact, same feasibility class)."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(100 + per_coord)
+    G = rs.randn(n, n)
+    funcs = [(G.dot(G.T) / n + 0.5 * np.eye(n), rs.randn(n), 0.3, None)]
+    for i in range(n):
+        E = sp.csr_matrix(([1.0], ([i], [i])), shape=(n, n))
+        funcs.append((E, np.zeros(n), -(2.6 + 0.3 * rs.rand()), '<='))           # disc: keeps the set bounded
+        for kind in rs.choice(3, size=per_coord - 1):
+            q = np.zeros(n)
+            if kind == 0:
+                q[i] = 1.0; funcs.append((sp.csr_matrix((n, n)), q, -(1.5 + 0.1 * rs.rand()), '<='))      # x <= 1.5..1.6
+            elif kind == 1:
+                q[i] = -1.0; funcs.append((sp.csr_matrix((n, n)), q, -(1.5 + 0.1 * rs.rand()), '<='))     # x >= -1.6..-1.5
+            else:
+                funcs.append((-E, q, 0.3 + 0.1 * rs.rand(), '<='))                                         # x^2 >= 0.3..0.4
+    e = make(eng_mod, funcs)
+    assert not e.separable            # more than four per coordinate: handled as general constraints
+    prob = orc.Problem(funcs)
+    R, seed, first, iters = 12, 31, 2, 40 if n <= 64 else 6
+    X0 = 1.3 * np.random.RandomState(6).randn(n, R)
+    e.upload(X0)
+    out = e.cd_run(phase1=True, num_iters=iters, seed=seed, first_index=first)
+    assert e.last_cd_kernel() == ('cd_general_kernel' if n <= 64 else 'dense_chain_kernel')
+    X = e.download()
+    same = 0
+    for r in range(R):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(first + r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+        assert abs(prob.eval(0, X[:, r]) - out['f0'][r]) <= 1e-9 * (1 + abs(out['f0'][r]))
+        assert abs(prob.max_violation(X[:, r]) - out['maxviol'][r]) < 1e-9
+        if n <= 64:
+            assert rel(X[:, r], x) < 1e-9, (r, np.max(np.abs(X[:, r] - x)))
+            assert out['sweeps1'][r] == s1[0] and out['visits2'][r] == s2[1] and out['accepted2'][r] == s2[2], r
+        else:
+            same += rel(X[:, r], x) < 1e-6
+            assert (out['maxviol'][r] < 1e-2) == (prob.max_violation(x) < 1e-2), r
+    if n > 64:
+        print('\n%d constraints per coordinate, n = %d through the dense path: %d of %d restarts on the oracle trajectory' % (per_coord, n, same, R))
+        e.cd_reference_order(True)
+        e.upload(X0)
+        e.cd_run(phase1=True, num_iters=iters, seed=seed, first_index=first)
+        Xr = e.download()
+        for r in range(R):
+            rng = orc.Rng(orc.RNG_KEYED, seed)
+            rng.set_restart(first + r)
+            x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+            assert rel(Xr[:, r], x) < 1e-9, (r, np.max(np.abs(Xr[:, r] - x)))
+
+
 # ------------------------------------------------------- dense-constraint path (matrix cores)
 DENSE_PATH = 32 << 4   # qcqpmi_debug_profile switch: take the dense path on small problems too (default: n > 64)
 
@@ -429,6 +497,7 @@ def test_dense_path_phase2_matches_reference_golden(eng_mod, name):
     e.L.qcqpmi_debug_profile(e.h, DENSE_PATH, None)
     e.upload(z['X0'])
     out = e.cd_run(phase1=False)
+    assert e.last_cd_kernel() == 'dense_chain_kernel'
     X = e.download()
     assert rel(X, z['p2_x']) < 1e-6
     assert rel(out['f0'], z['p2_fv'][:, 0]) < 1e-6
@@ -485,6 +554,7 @@ def test_dense_path_default_dispatch_vs_oracle(eng_mod, orc):
     X0 = 1.5 * np.random.RandomState(2).randn(n, R)
     e.upload(X0)
     out = e.cd_run(phase1=True, num_iters=iters, seed=seed, first_index=first)
+    assert e.last_cd_kernel() == 'dense_chain_kernel'
     X = e.download()
     exact = 0
     for r in range(R):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     L = _ffi.lib()
-    assert L.qcqpmi_abi_version() == 2
+    assert L.qcqpmi_abi_version() == 3
     assert L.qcqpmi_device_count() >= 0
 
 
@@ -302,40 +302,7 @@ def test_cvxpy_adapter_extracts_the_reference_form():
     non-quadratic expressions refused with the reference's messages, variable values restored."""
     from qcqp_amd.cvxpy_adapter import problem_from_cvxpy
 
-    class Var(object):
-        def __init__(self, shape):
-            self.shape, self.value, self.id = shape, None, 7
-
-    class Expr(object):
-        def __init__(self, fn, shape, quad=True):
-            self.fn, self.shape, self.quad = fn, shape, quad
-        value = property(lambda self: self.fn())
-
-        def is_quadratic(self):
-            return self.quad
-
-    class Objective(object):
-        def __init__(self, name, e):
-            self.NAME, self.args = name, [e]
-
-    class Equality(object):
-        def __init__(self, e):
-            self.expr = e
-
-    class Inequality(object):
-        def __init__(self, e):
-            self.expr = e
-
-    class NonNeg(object):
-        def __init__(self, e):
-            self.args = [e]
-
-    class Prob(object):
-        def __init__(self, o, cs, vs):
-            self.objective, self.constraints, self._vs = o, cs, vs
-
-        def variables(self):
-            return self._vs
+    from duck_cvxpy import Var, Expr, Objective, Equality, Inequality, NonNeg, Prob
 
     rs = np.random.RandomState(0)
     n = 6
@@ -371,3 +338,36 @@ def test_cvxpy_adapter_extracts_the_reference_form():
         problem_from_cvxpy(Prob(Objective('minimize', Expr(lambda: 0.0, (), quad=False)), [], [x]))
     with pytest.raises(Exception, match='Not all constraints are quadratic'):
         problem_from_cvxpy(Prob(Objective('minimize', obj), [Equality(Expr(lambda: x.value, (n,), quad=False))], [x]))
+
+
+def test_cvxpy_adapter_keeps_bilinear_only_terms():
+    """a bilinear term x_i x_j does not move f along either axis alone, so a pruning test on
+    f(+-e_i) dropped P_ij silently.  Zero-diagonal objective x'Wx (MAXCUT-like), a constraint x0 x1 - 1 <= 0 and
+    f = x0^2 + x0 x1 must all come back exactly; functions that do not share a variable are still not probed."""
+    from qcqp_amd.cvxpy_adapter import problem_from_cvxpy
+    from duck_cvxpy import Var, Expr, Objective, Equality, Inequality, Prob
+    rs = np.random.RandomState(3)
+    n = 7
+    W = np.triu(rs.randn(n, n), 1)
+    W = W + W.T                                           # zero diagonal, no linear term
+    x = Var((n,))
+    calls = [0]
+
+    def objf():
+        calls[0] += 1
+        return x.value.dot(W).dot(x.value)
+    cons = [Inequality(Expr(lambda: x.value[0] * x.value[1] - 1.0, ())),
+            Inequality(Expr(lambda: x.value[0] ** 2 + x.value[0] * x.value[2] - 2.0, ())),
+            Equality(Expr(lambda: x.value ** 2 - 1.0, (n,)))]
+    f = problem_from_cvxpy(Prob(Objective('minimize', Expr(objf, ())), cons, [x])).qcqp_form
+    assert np.allclose(np.asarray(f.f0.P), W, atol=1e-13) and np.allclose(f.f0.qarray, 0, atol=1e-13)
+    P1 = np.zeros((n, n)); P1[0, 1] = P1[1, 0] = 0.5
+    assert np.allclose(np.asarray(f.fs[0].P), P1, atol=1e-13) and f.fs[0].r == -1.0
+    P2 = np.zeros((n, n)); P2[0, 0] = 1.0; P2[0, 2] = P2[2, 0] = 0.5
+    assert np.allclose(np.asarray(f.fs[1].P), P2, atol=1e-13) and f.fs[1].r == -2.0
+    # a problem whose functions share no pair of variables is extracted without any pair probe
+    calls[0] = 0
+    sep = [Equality(Expr(lambda: x.value ** 2 - 1.0, (n,)))]
+    lin = Expr(lambda: (calls.__setitem__(0, calls[0] + 1), float(x.value[0]))[1], ())
+    problem_from_cvxpy(Prob(Objective('minimize', lin), sep, [x]))
+    assert calls[0] == 1 + 2 * n + 2 * (n + 1)

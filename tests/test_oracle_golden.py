@@ -197,3 +197,19 @@ def test_incremental_cpu_baseline_matches_restatement(orc):
             xb, sb = prob.cd_phase2_incremental(x1, rng=rng)
             assert np.max(np.abs(xa - xb)) < 1e-9
             assert sa[1] == sb[1] and sa[2] == sb[2]
+
+
+def test_generated_eval_matches_materialised_functions(orc):
+    """orc_generated_eval (entry-by-entry values of a device-generated synthetic function, used by the full-size
+    configs[4] test where no matrix can be materialised) against the same functions built as NumPy arrays from the same
+    keyed stream (problems.materialise_generated)."""
+    from qcqp_amd import problems
+    n = 12
+    form = problems.dense_indefinite_generated(n, 5, seed=7)
+    funcs = problems.materialise_generated(form, orc.keyed_normal)
+    X = np.random.RandomState(0).randn(n, 3)
+    for k in range(6):
+        P, q, r, _ = funcs[k]
+        ref = np.array([X[:, s].dot(P).dot(X[:, s]) + q.dot(X[:, s]) + r for s in range(3)])
+        got = orc.generated_eval(form.specs[k], k, n, X)
+        assert np.allclose(ref, got, rtol=1e-13, atol=1e-13), (k, ref, got)
