@@ -186,6 +186,14 @@ int qcqpmi_p0_lambda_min(qcqpmi_ctx *ctx, int64_t max_steps, double tol, double 
 int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, double viol_lim,
                     double rho, const double *Minv, int64_t *iters1, int64_t *iters2, double *f0,
                     double *maxviol);   /* Minv may be NULL if P0 is diagonal or after qcqpmi_admm_zsolver_device(rho) */
+/* With reduced bases (qcqpmi_admm_set_basis, rp <= 8) and a diagonal P0 -- BASELINE.json configs[3] -- qcqpmi_admm_run runs
+ * improve_admm (qcqp.py:254-285: phase 1, better, phase 2 with its bestx bookkeeping, better) inside ONE persistent kernel
+ * per tile of 16 restarts (csrc/admm_fused.hip; a tile may be shared by a cluster of 2..16 workgroups so that few restarts
+ * still fill the chip), no host in the loop.  qcqpmi_admm_fused(ctx, 0) selects the multi-launch path everywhere (the
+ * cross-check; same iteration, other summation order in the two products); default 1.  qcqpmi_last_admm_kernel names the
+ * path the last run took ("admm_fused_kernel" / "admm_multi_launch") and the workgroups per tile it used. */
+int qcqpmi_admm_fused(qcqpmi_ctx *ctx, int enable);
+const char *qcqpmi_last_admm_kernel(qcqpmi_ctx *ctx, int *workgroups_per_tile);
 
 /* Y = (sum_k w_k P_k) X for the resident population (w: m+1 weights, objective first; Y: R x n like
  * qcqpmi_pop_download).  Building block of the general SDP-relaxation solver (qcqp_amd/sdr.py: the gradient of

@@ -1,21 +1,45 @@
-"""Builds libqcqp_mi.so (hand-written HIP for gfx950) in-tree with hipcc."""
+"""Builds libqcqp_mi.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+Several translation units, compiled in parallel and only when one of their sources changed (the big one takes two
+minutes): objects under qcqp_amd/_obj/ (git-ignored), linked into qcqp_amd/libqcqp_mi.so."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(HERE, 'libqcqp_mi.so')
-SOURCES = ['capi.hip', 'capi_admm.inc', 'capi_units.inc', 'kernels.hip', 'kernels.h', 'onevar.h', 'philox.h', 'cd_phase2.h',
-           'cd_phase2_rs.h', 'cd_phase2_q.h', 'admm.h', 'gemm_pk.h', 'cd_general.h', 'cd_dense.h', 'capi_dense.inc', 'sdr_solve.h']
+HEADER = os.path.join(REPO, 'include', 'qcqp_mi.h')
+
+# translation unit -> everything it includes (rebuilt when any of these is newer than its object)
+UNITS = {
+    'capi.hip': ['capi.hip', 'capi_admm.inc', 'capi_units.inc', 'capi_dense.inc', 'kernels.hip', 'kernels.h', 'onevar.h', 'philox.h',
+                 'cd_phase2.h', 'cd_phase2_rs.h', 'cd_phase2_q.h', 'admm.h', 'admm_fused.h', 'gemm_pk.h', 'cd_general.h', 'cd_dense.h',
+                 'sdr_solve.h'],
+    'admm_fused.hip': ['admm_fused.hip', 'admm_fused.h', 'onevar.h', 'philox.h'],
+}
+SOURCES = sorted(set(sum(UNITS.values(), [])))
+
+
+def _obj(unit):
+    return os.path.join(OBJ, os.path.splitext(unit)[0] + '.o')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _unit_deps(unit):
+    return [os.path.join(SRC, s) for s in UNITS[unit]] + [HEADER]
 
 
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(SRC, s) for s in SOURCES] + [os.path.join(REPO, 'include', 'qcqp_mi.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(_stale(_obj(u), _unit_deps(u)) for u in UNITS) or _stale(LIB, [_obj(u) for u in UNITS if os.path.exists(_obj(u))])
 
 
 def build(force=False, verbose=False):
@@ -24,9 +48,19 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-ffp-contract=off', '-I' + os.path.join(REPO, 'include'),
-           '-o', LIB, os.path.join(SRC, 'capi.hip'), '-ldl']
+    os.makedirs(OBJ, exist_ok=True)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-I' + os.path.join(REPO, 'include')]
+
+    def compile_unit(unit):
+        cmd = [hipcc] + flags + ['-c', os.path.join(SRC, unit), '-o', _obj(unit)]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+
+    todo = [u for u in UNITS if force or _stale(_obj(u), _unit_deps(u))]
+    with ThreadPoolExecutor(max_workers=max(1, len(todo))) as ex:
+        list(ex.map(compile_unit, todo))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + [_obj(u) for u in UNITS] + ['-ldl']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
@@ -34,4 +68,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    build(force=True, verbose=True)
+    import sys
+    build(force='--force' in sys.argv, verbose=True)

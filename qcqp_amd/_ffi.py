@@ -55,6 +55,8 @@ PROTOTYPES = [
     ('qcqpmi_p0_lambda_min', C.c_int, [C.c_void_p, C.c_int64, C.c_double, c_dp, c_ip]),
     ('qcqpmi_admm_run', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double, c_dp,
                                   c_ip, c_ip, c_dp, c_dp]),
+    ('qcqpmi_admm_fused', C.c_int, [C.c_void_p, C.c_int]),
+    ('qcqpmi_last_admm_kernel', C.c_char_p, [C.c_void_p, C.POINTER(C.c_int)]),
     ('qcqpmi_select_best', C.c_int, [C.c_void_p, C.c_double, c_ip, c_dp, c_dp, c_dp]),
     ('qcqpmi_last_kernel_ms', C.c_int, [C.c_void_p, C.c_int, c_dp]),
     ('qcqpmi_last_cd_kernel', C.c_char_p, [C.c_void_p]),

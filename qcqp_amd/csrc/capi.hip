@@ -15,6 +15,7 @@
 #include "../../include/qcqp_mi.h"
 #include "kernels.hip"
 #include "admm.h"
+#include "admm_fused.h"
 #include "gemm_pk.h"
 #include "cd_general.h"
 #include "cd_dense.h"
@@ -152,6 +153,12 @@ struct qcqpmi_ctx {
     const char *last_cd2_kernel = "";     // name of the phase-2 kernel of the most recent cd run (bench / profiles)
     bool profile = false;
     int dbg = 0;
+    // fused persistent ADMM kernel (admm_fused.h): one work buffer kept across runs, grown on demand
+    char *af_work = nullptr;
+    size_t af_work_cap = 0;
+    bool ad_fused = true;                 // qcqpmi_admm_fused: use the fused kernel where it applies
+    const char *last_admm_kernel = "";    // "admm_fused_kernel" / "admm_multi_launch"
+    int last_admm_C = 0;                  // workgroups per tile of the last fused run
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
     std::vector<int> last_st1, last_st2;   // per-restart status codes of the last coordinate-descent run (qcqpmi_cd_status)
@@ -596,7 +603,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work};
     if (c->h_out) (void)hipHostFree(c->h_out);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }

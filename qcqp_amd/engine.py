@@ -251,6 +251,16 @@ class Engine(object):
                                          _ip(out['iters2']), _dp(out['f0']), _dp(out['maxviol'])))
         return out
 
+    def admm_fused(self, enable=True):
+        """Fused persistent ADMM kernel on / off (off = the multi-launch path everywhere: the cross-check)."""
+        self._chk(self.L.qcqpmi_admm_fused(self.h, 1 if enable else 0))
+
+    def last_admm_kernel(self):
+        """('admm_fused_kernel' | 'admm_multi_launch', workgroups per tile) of the most recent admm_run."""
+        cw = C.c_int(0)
+        name = self.L.qcqpmi_last_admm_kernel(self.h, C.byref(cw)) or b''
+        return name.decode(), int(cw.value)
+
     def weighted_matrix(self, w):
         """sum_k w_k P_k (n x n) assembled on the device and downloaded."""
         w = np.ascontiguousarray(w, dtype=np.float64)

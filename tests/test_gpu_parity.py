@@ -58,10 +58,11 @@ def test_cd_phase2_matches_reference_golden(eng_mod, name, generic):
     e.upload(z['X0'])
     out = e.cd_run(phase1=False)
     # which kernel ran (a regression of the pipelined kernel's eligibility test must not hide behind its fallbacks):
-    # n = 64 is the smallest size the pipelined kernel takes (>= 3 blocks of 16), n = 10 / 32 and the zero-diagonal
-    # MAXCUT objective go to its round-1 predecessor
-    want = 'cd_phase2_kernel' if generic else {'bls10': 'cd_phase2_rs_kernel', 'bls32': 'cd_phase2_rs_kernel',
-                                               'bls64': 'cd_phase2_q_kernel', 'maxcut12': 'cd_phase2_rs_kernel'}[name]
+    # the pipelined kernel takes n = 48 ... 1024 in multiples of 16 (>= 3 blocks), n = 32 goes to its round-1
+    # predecessor, sizes that are not a multiple of 16 (padding coordinates form a second constraint class) to the
+    # general kernel
+    want = 'cd_phase2_kernel' if generic else {'bls10': 'cd_phase2_kernel', 'bls32': 'cd_phase2_rs_kernel',
+                                               'bls64': 'cd_phase2_q_kernel', 'maxcut12': 'cd_phase2_kernel'}[name]
     assert e.last_cd_kernel() == want, (e.last_cd_kernel(), want)
     X = e.download()
     assert rel(X, z['p2_x']) < 1e-9
@@ -70,7 +71,7 @@ def test_cd_phase2_matches_reference_golden(eng_mod, name, generic):
 
 
 @pytest.mark.parametrize('generic', [False, True])
-@pytest.mark.parametrize('name,n,m_rows', [('bls', 96, 40), ('bls', 250, 100), ('maxcut', 130, 0)])
+@pytest.mark.parametrize('name,n,m_rows', [('bls', 96, 40), ('bls', 250, 100), ('maxcut', 130, 0), ('maxcut', 128, 0)])
 def test_cd_full_driver_vs_oracle_keyed(eng_mod, orc, name, n, m_rows, generic):
     """Phase 1 draws from the keyed Philox stream: oracle (ORC_RNG_KEYED) and GPU consume the same
     draws, so whole improve_coord_descent trajectories are comparable."""
@@ -84,7 +85,8 @@ def test_cd_full_driver_vs_oracle_keyed(eng_mod, orc, name, n, m_rows, generic):
     X0 = np.random.RandomState(1).randn(n, R)
     e.upload(X0)
     out = e.cd_run(phase1=True, num_iters=50, seed=seed, first_index=first)
-    want = 'cd_phase2_kernel' if generic else ('cd_phase2_q_kernel' if (name, n) == ('bls', 96) else 'cd_phase2_rs_kernel')
+    # (bls, 96): the pipelined kernel; (maxcut, 128): zero diagonal, multiple of 16 -> its predecessor; 250 / 130: general
+    want = 'cd_phase2_kernel' if generic else {('bls', 96): 'cd_phase2_q_kernel', ('maxcut', 128): 'cd_phase2_rs_kernel'}.get((name, n), 'cd_phase2_kernel')
     assert e.last_cd_kernel() == want, (e.last_cd_kernel(), want)
     X = e.download()
     for r in range(R):

@@ -528,3 +528,88 @@ def test_cd_staged_run_two_contexts(eng_mod):
     e1.cd_begin(seed=1)
     with pytest.raises(EngineError):
         e1.cd_fetch()           # stage 2 skipped
+
+
+# ------------------------------------------------------------------ the fused persistent ADMM kernel (round 3)
+@pytest.mark.parametrize('nant,mh,ml,R,iters', [(64, 6, 10, 96, 60), (40, 3, 5, 7, 200), (512, 16, 64, 128, 40), (512, 16, 64, 1024, 25)])
+def test_admm_fused_kernel_vs_multi_launch(eng_mod, orc, nant, mh, ml, R, iters):
+    """improve_admm (qcqp.py:254-285) inside ONE persistent kernel per tile of restarts (csrc/admm_fused.hip: phase 1,
+    better, phase 2 with bestx, better -- no host in the loop; a tile shared by a cluster of workgroups when there are few
+    restarts) against the multi-launch path it replaces as the default (same iteration, other summation order in the two
+    products): points, objective, max violation, iteration counts per restart.  Sizes: n = 128 (clusters of 4-16
+    workgroups, ragged split of 16 constraints), n = 80 with 7 restarts (one partial tile), BASELINE.json configs[3]
+    (n = 1024, m = 80) at the 8-GPU share of 128 restarts (clusters of 16) and at 1024 restarts (clusters of 4).  At the
+    smaller sizes two restarts also go through the oracle (full eigenbasis there, reduced bases here: 1e-6)."""
+    from qcqp_amd import lowrank, problems
+    from qcqp_amd.form import QCQPForm
+    funcs, _, _ = problems.beamforming(nant, mh, ml, seed=1)
+    form = QCQPForm.from_arrays(funcs)
+    n, m = form.n, form.m
+    rho = 1.0
+    e = eng_mod.Engine(form)
+    lam, Bv, qhat, info = lowrank.reduced_bases(e, form)
+    e.admm_set_basis(lam, Bv, qhat)
+    X0 = np.random.RandomState(7).randn(n, R)
+    res = []
+    for fused in (True, False):
+        e.admm_fused(fused)
+        e.upload(X0)
+        out = e.admm_run(rho, None, phase1=True, num_iters=iters)
+        name, cw = e.last_admm_kernel()
+        assert name == ('admm_fused_kernel' if fused else 'admm_multi_launch'), name
+        res.append((e.download(), out, cw))
+        f0, mv = e.eval()
+        assert rel(out['f0'], f0) < 1e-9 and np.max(np.abs(out['maxviol'] - mv)) < 1e-9
+    (Xf, of, cw), (Xm, om, _) = res
+    d = np.max(np.abs(Xf - Xm), axis=0) / (1 + np.max(np.abs(Xm), axis=0))
+    same_it = np.mean((of['iters1'] == om['iters1']) & (of['iters2'] == om['iters2']))
+    print('\nADMM fused (clusters of %d) vs multi-launch, n=%d m=%d R=%d: max|dx| median %.2e max %.2e; identical iteration counts '
+          '%.1f %%; feasible %d / %d' % (cw, n, m, R, np.median(d), d.max(), 100 * same_it, int((of['maxviol'] < 1e-2).sum()),
+                                         int((om['maxviol'] < 1e-2).sum())))
+    assert cw >= 1
+    assert np.median(d) < 1e-9 and d.max() < 1e-6, (np.median(d), d.max())
+    assert rel(of['f0'], om['f0']) < 1e-6 and np.max(np.abs(of['maxviol'] - om['maxviol'])) < 1e-6
+    assert same_it > 0.97
+    if n <= 256:
+        prob = orc.Problem(funcs)
+        for r in (0, R - 1):
+            xa = prob.improve_admm(X0[:, r], num_iters=iters, rho=rho)
+            assert rel(Xf[:, r], xa) < 1e-4, r       # reduced vs full basis (test_admm_reduced_basis_vs_full_eigenbasis)
+
+
+def test_admm_fused_kernel_golden_and_phase2_only(eng_mod, orc):
+    """The fused kernel on the reference's own golden run G8 (beamforming n = 40: improve_admm's result `xa` and its
+    (f, v), 1e-6 -- the tolerance of the reference's bisection) through reduced bases of rank 2, and with phase1=False
+    (qcqp.py:279-285) against the multi-launch path."""
+    from conftest import funcs_from_npz
+    from qcqp_amd import lowrank
+    from qcqp_amd.form import QCQPForm
+    z = load_golden('g8_admm_beam40')
+    funcs = funcs_from_npz(z)
+    form = QCQPForm.from_arrays(funcs)
+    e = eng_mod.Engine(form)
+    red = lowrank.reduced_bases(e, form, max_rank=2)
+    assert red is not None
+    lam, Bv, qhat, info = red
+    e.admm_set_basis(lam, Bv, qhat)
+    rho, iters = float(z['rho']), int(z['iters'])
+    X0 = np.stack([z['x0']] * 5, axis=1)
+    for p1 in (True, False):
+        res = []
+        for fused in (True, False):
+            e.admm_fused(fused)
+            e.upload(X0)
+            out = e.admm_run(rho, None, phase1=p1, num_iters=iters)
+            assert e.last_admm_kernel()[0] == ('admm_fused_kernel' if fused else 'admm_multi_launch')
+            res.append((e.download(), out))
+        assert rel(res[0][0], res[1][0]) < 1e-6
+        assert rel(res[0][1]['f0'], res[1][1]['f0']) < 1e-6
+        if p1:
+            # against the reference's own result: reduced bases bracket the multiplier from the NONZERO eigenvalues, the
+            # reference from LAPACK's round-off eigenvalues of the null space as well (SURVEY.md A.12) -- other midpoints,
+            # every multiplier still within the reference's 1e-6 bisection tolerance, points within 1e-4 after ~100
+            # iterations (measured 8.7e-6); the full-eigenbasis path meets 1e-6 (test_admm_matches_reference_golden)
+            for r in range(5):
+                assert rel(res[0][0][:, r], z['xa']) < 1e-4, r
+            assert abs(res[0][1]['f0'][0] - z['fva'][0]) <= 1e-4 * (1 + abs(z['fva'][0]))
+            assert abs(res[0][1]['maxviol'][0] - z['fva'][1]) <= 1e-4

@@ -1,0 +1,30 @@
+"""Throughput of improve(ADMM) at BASELINE.json configs[3] size (n=1024, m=80, rho=1): fused persistent kernel vs the
+multi-launch path.  usage: admm_fused_rate.py [R=1024] [iters=200]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from qcqp_amd import lowrank, problems
+from qcqp_amd.engine import Engine
+from qcqp_amd.form import QCQPForm
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+funcs, _, _ = problems.beamforming(512, 16, 64, seed=1)
+form = QCQPForm.from_arrays(funcs)
+e = Engine(form)
+lam, Bv, qhat, info = lowrank.reduced_bases(e, form)
+e.admm_set_basis(lam, Bv, qhat)
+print('n=%d m=%d rp=%d R=%d num_iters=%d' % (form.n, form.m, info['rp'], R, iters))
+for fused in (True, False, True):
+    e.admm_fused(fused)
+    for rep in range(2):
+        e.randn(R, seed=5)
+        e.sync()
+        t0 = time.time()
+        out = e.admm_run(1.0, None, phase1=True, num_iters=iters)
+        dt = time.time() - t0
+    its = float(out['iters1'].sum() + out['iters2'].sum())
+    name, cw = e.last_admm_kernel()
+    kms = e.kernel_ms(4)
+    print('%-18s C=%2d: %.4f s wall, %.3e restart-iterations -> %.3e /s (wall); iterations of the longest restart %d + %d; feasible %d; '
+          'timer[4] %.3f ms' % (name, cw, dt, its, its / dt, out['iters1'].max(), out['iters2'].max(), int((out['maxviol'] < 1e-2).sum()), kms))
