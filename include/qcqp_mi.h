@@ -248,6 +248,10 @@ int qcqpmi_sync(qcqpmi_ctx *ctx);
 /* debug: enable in-kernel cycle counters of the phase-2 kernel / read their sums over tiles
  * (slots: 0 mfma, 1 feasible sets, 2 barrier, 3 sequential part, 4 barrier, 5 #blocks) */
 int qcqpmi_debug_profile(qcqpmi_ctx *ctx, int enable, int64_t *sums8);
+/* debug: stage cycle counters (s_memtime ticks of member 0 of tile 0) of the last fused ADMM run made while
+ * qcqpmi_debug_profile(ctx, 1, NULL) was on: 0 z-update, 1 partial product, 2 exchange 1, 3 sums, 4 secular solves,
+ * 5 exchange 2, 6 gather, 7 bookkeeping, 9 iterations */
+int qcqpmi_debug_admm_profile(qcqpmi_ctx *ctx, int64_t *out16);
 /* debug: per-wave event trace (cycle stamps) of tile 0 of the last profiled phase-2 run; count <= 2048 words */
 int qcqpmi_debug_trace(qcqpmi_ctx *ctx, int64_t *out, int count);
 

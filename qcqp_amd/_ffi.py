@@ -63,6 +63,7 @@ PROTOTYPES = [
     ('qcqpmi_cd_reference_order', C.c_int, [C.c_void_p, C.c_int]),
     ('qcqpmi_sync', C.c_int, [C.c_void_p]),
     ('qcqpmi_debug_profile', C.c_int, [C.c_void_p, C.c_int, c_ip]),
+    ('qcqpmi_debug_admm_profile', C.c_int, [C.c_void_p, c_ip]),
     ('qcqpmi_debug_trace', C.c_int, [C.c_void_p, c_ip, C.c_int]),
     ('qcqpmi_comm_unique_id', C.c_int, [c_bp]),
     ('qcqpmi_comm_init', C.c_int, [C.c_void_p, C.c_int, C.c_int, c_bp]),

@@ -22,6 +22,7 @@ struct AdmmFusedArgs {
     const int *relop;               // [m]
     const double *q0, *pdiag, *dinv;   // [n16]: linear term, P0_ii, 1 / (2 (P0_ii + rho m))
     double r0, rho;
+    int qzero;                      // every qhat is zero (constraints without linear terms): shorter secular function
     // ---- run parameters (improve_admm's arguments)
     int phase1, num_iters;
     double tol, viol_lim, sec_tol;
@@ -39,6 +40,7 @@ struct AdmmFusedArgs {
     // ---- outputs, R entries each
     int64_t *iters1, *iters2;
     double *f0_out, *mv_out;
+    long long *prof;                // optional: 16 cycle counters of member 0 of the first tile (s_memtime per stage), or nullptr
 };
 
 // dynamic LDS the kernel needs for this geometry (0 if it does not fit 160 KB)

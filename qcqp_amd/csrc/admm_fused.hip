@@ -39,9 +39,11 @@ namespace qcqpmi {
 namespace {
 
 typedef double af_v4d __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const double af_gcd;     // global memory, read-only streams (global_load, not flat)
 
 __device__ inline double ag_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void ag_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __attribute__((always_inline)) inline int af_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // wave-uniform -> SGPR
 
 // num / den through the hardware reciprocal + two Newton steps: the expression of admm.h (admm_div), so that the fused
 // and the multi-launch paths bisect on bit-identical secular functions
@@ -60,6 +62,44 @@ __device__ inline bool better_first(double f1, double v1, double f2, double v2) 
     return f1 < f2;
 }
 
+// acc0 += sum_k A0[k] B[k] (and acc1 += sum_k A1[k] B[k]) over nks k-steps (a multiple of 4): A fragments stream from
+// global memory (L2) 64 doubles apart, B operands from LDS 64 doubles apart.  Groups of 4 k-steps; the fragments of the
+// group after next are requested before this group multiplies (two groups = 8-16 MFMAs of cover for the L2 latency),
+// the B operands of a group are read one group ahead.
+template <bool TWO>
+__device__ __attribute__((always_inline)) inline void af_stream(af_gcd *A0, af_gcd *A1, const double *Bs, int nks, af_v4d &acc0, af_v4d &acc1) {
+    double p0[4], p1[4], q0[4], q1[4], pb[4];
+    const int last = nks - 4;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        p0[u] = A0[u * 64];
+        if (TWO) p1[u] = A1[u * 64];
+        pb[u] = Bs[u * 64];
+    }
+    {
+        const int k1 = 4 < nks ? 4 : last;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { q0[u] = A0[(k1 + u) * 64]; if (TWO) q1[u] = A1[(k1 + u) * 64]; }
+    }
+    for (int kk = 0; kk < nks; kk += 4) {
+        double c0[4], c1[4], cb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { c0[u] = p0[u]; if (TWO) c1[u] = p1[u]; cb[u] = pb[u]; p0[u] = q0[u]; if (TWO) p1[u] = q1[u]; }
+        const int k1 = kk + 4 < nks ? kk + 4 : last, k2 = kk + 8 < nks ? kk + 8 : last;     // clamped: loaded, never multiplied
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            q0[u] = A0[(k2 + u) * 64];
+            if (TWO) q1[u] = A1[(k2 + u) * 64];
+            pb[u] = Bs[(k1 + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[u], cb[u], acc0, 0, 0, 0);
+            if (TWO) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[u], cb[u], acc1, 0, 0, 0);
+        }
+    }
+}
+
 struct AfState {                     // per-tile scalars in LDS
     double dist2[16], f0z[16], mvv[16], best_f0[16], best_mv[16];
     double fx0[16], vx0[16], fx1[16], vx1[16], pd2[16], pf0[16];
@@ -71,22 +111,25 @@ struct AfState {                     // per-tile scalars in LDS
     double scr[512];
 };
 
-// onecons_qcqp on the rp coordinates of a reduced basis for ONE (constraint, restart) pair: admm_secular_small_kernel of
-// admm.h, with the operands in LDS.  zq / uh: column of the pair, rows 16 doubles apart; dout: the same in global memory.
-template <int RP>
-__device__ inline void secular_pair(const AdmmFusedArgs &a, int k, const double *zq, double *uh, int first_iter, int viol_only,
-                                    unsigned long long *mvslot, double *dout) {
-    const double *lm = a.lam + (int64_t)k * RP, *qh = a.qhat + (int64_t)k * RP;
-    const double rk = a.rk[k];
-    const int relop = a.relop[k];
-    double L[RP], Qh[RP], V[RP], Zq[RP], X[RP];
+// onecons_qcqp on the RP coordinates of a reduced basis for ONE (constraint, restart) pair: admm_secular_small_kernel of
+// admm.h with the operands in LDS.  zq / uh: column of the pair, rows 16 doubles apart; dout: the same in global memory.
+// QZ: every qhat is zero (constraints without linear terms, the beamforming family): -(nu 0 - 2 v) = 2 v and + 0 xh
+// drop out of the secular function bit for bit.
+template <int RP, bool QZ>
+__device__ __attribute__((always_inline)) inline void secular_pair(const AdmmFusedArgs &a, int k, const double *zq, double *uh, bool first_iter,
+                                                                   bool viol_only, unsigned long long *mvslot, double *dout) {
+    af_gcd *lm = (af_gcd *)a.lam + (int64_t)k * RP, *qh = (af_gcd *)a.qhat + (int64_t)k * RP;
+    const double rk = ((af_gcd *)a.rk)[k];
+    const int relop = ((__attribute__((address_space(1))) const int *)a.relop)[k];
+    double L[RP], Qh[RP], V[RP], V2[RP], Zq[RP], X[RP];
     double fz = 0.0, fv = 0.0;
 #pragma unroll
     for (int e = 0; e < RP; e++) {
-        L[e] = lm[e]; Qh[e] = qh[e];
+        L[e] = lm[e]; Qh[e] = QZ ? 0.0 : qh[e];
         Zq[e] = zq[e * 16];
         const double u = (!first_iter && !viol_only) ? uh[e * 16] : 0.0;
         V[e] = Zq[e] + u;
+        V2[e] = 2.0 * V[e];
         fz += L[e] * (Zq[e] * Zq[e]) + Qh[e] * Zq[e];
         fv += L[e] * (V[e] * V[e]) + Qh[e] * V[e];
     }
@@ -104,14 +147,14 @@ __device__ inline void secular_pair(const AdmmFusedArgs &a, int k, const double 
             double p = 0.0;
 #pragma unroll
             for (int e = 0; e < RP; e++) {
-                const double num = -(nu * Qh[e] - 2.0 * V[e]);
+                const double num = QZ ? V2[e] : -(nu * Qh[e] - 2.0 * V[e]);
                 const double xh = (L[e] != 0.0) ? af_div(num, 2.0 * (1.0 + nu * L[e])) : num * 0.5;
                 X[e] = xh;
-                p += L[e] * (xh * xh) + Qh[e] * xh;
+                if (QZ) p += L[e] * (xh * xh); else p += L[e] * (xh * xh) + Qh[e] * xh;
             }
             return p + rk;
         };
-        double s = a.slo[k], e_ = a.ehi[k];
+        double s = ((af_gcd *)a.slo)[k], e_ = ((af_gcd *)a.ehi)[k];
         int guard = 0;
         if (s == -QM_INF) { s = -1.0; while (phi(s) <= 0.0 && guard++ < 2000) s *= 2.0; }
         if (e_ == QM_INF) { e_ = 1.0; while (phi(e_) >= 0.0 && guard++ < 4000) e_ *= 2.0; }
@@ -132,42 +175,36 @@ __device__ inline void secular_pair(const AdmmFusedArgs &a, int k, const double 
     }
 }
 
-__device__ inline void secular_dispatch(const AdmmFusedArgs &a, int k, const double *zq, double *uh, int first_iter,
-                                        int viol_only, unsigned long long *mvslot, double *dout) {
-    switch (a.rp) {
-    case 1: secular_pair<1>(a, k, zq, uh, first_iter, viol_only, mvslot, dout); break;
-    case 2: secular_pair<2>(a, k, zq, uh, first_iter, viol_only, mvslot, dout); break;
-    case 3: secular_pair<3>(a, k, zq, uh, first_iter, viol_only, mvslot, dout); break;
-    case 4: secular_pair<4>(a, k, zq, uh, first_iter, viol_only, mvslot, dout); break;
-    case 5: secular_pair<5>(a, k, zq, uh, first_iter, viol_only, mvslot, dout); break;
-    case 6: secular_pair<6>(a, k, zq, uh, first_iter, viol_only, mvslot, dout); break;
-    case 7: secular_pair<7>(a, k, zq, uh, first_iter, viol_only, mvslot, dout); break;
-    default: secular_pair<8>(a, k, zq, uh, first_iter, viol_only, mvslot, dout); break;
-    }
-}
+enum { AF_EVAL0 = 0, AF_PH1 = 1, AF_EVAL1 = 2, AF_PH2 = 3, AF_DONE = 4 };
 
+// One instance of every stage inside one loop that walks EVAL0 -> PH1 iterations -> EVAL1 -> PH2 iterations (the first
+// version instantiated the stages per call site: 120 KB of code against a 64 KB instruction cache).
+template <int RP>
 __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a) {
     extern __shared__ double af_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = af_uni(tid >> 6);
     // block -> (cluster g, member c): the members of a cluster are 8 blocks apart, i.e. on one XCD under round-robin dispatch
     const int C = a.C;
     const int bx = (int)blockIdx.x & 7, brest = (int)blockIdx.x >> 3;
-    const int c = brest % C, g = bx + 8 * (brest / C);
+    const int c = af_uni(brest % C), g = af_uni(bx + 8 * (brest / C));
     if (g >= a.G) return;
     const int KBn = a.n16 / 16, MBh = a.Mh16 / 16, KSn = a.n16 / 4, KSh = a.Mh16 / 4;
-    const int b_lo = (int)((int64_t)c * KBn / C), b_hi = (int)((int64_t)(c + 1) * KBn / C);
+    const int b_lo = af_uni((int)((int64_t)c * KBn / C)), b_hi = af_uni((int)((int64_t)(c + 1) * KBn / C));
     const int NBl = b_hi - b_lo, rows = 16 * NBl, row0 = 16 * b_lo;
-    const int k_lo = (int)((int64_t)c * a.m / C), k_hi = (int)((int64_t)(c + 1) * a.m / C);
-    const int nk = k_hi - k_lo, rp = a.rp, h_lo = k_lo * rp, nh = nk * rp;
-    const int rows_max = 16 * ((KBn + C - 1) / C), nh_max = ((a.m + C - 1) / C) * rp;
+    const int k_lo = af_uni((int)((int64_t)c * a.m / C)), k_hi = af_uni((int)((int64_t)(c + 1) * a.m / C));
+    const int nk = k_hi - k_lo, h_lo = k_lo * RP, nh = nk * RP;
+    const int rows_max = af_uni(16 * ((KBn + C - 1) / C)), nh_max = af_uni(((a.m + C - 1) / C) * RP);
     // ---- LDS
     AfState &S = *reinterpret_cast<AfState *>(af_lds);
     double *Zs = af_lds + (sizeof(AfState) + 7) / 8;
     double *Ds = Zs + (size_t)rows_max * 16;
     double *UHs = Ds + (size_t)a.Mh16 * 16;
     double *ZQs = UHs + (size_t)nh_max * 16;
+    double *Qs = ZQs + (size_t)nh_max * 16, *DIs = Qs + rows_max, *PDs = DIs + rows_max;   // q0, 1/(2(P0_ii + rho m)), P0_ii of the own rows
     const double dm = (double)a.m;
+    af_gcd *WT = (af_gcd *)a.WTpk, *Wp = (af_gcd *)a.Wpk;
+    const bool qz = a.qzero != 0;
 
     for (int tile = g; tile < a.ntiles; tile += a.G) {
         double *Xt = a.X + (int64_t)tile * a.n16 * 16, *Bt = a.BEST + (int64_t)tile * a.n16 * 16;
@@ -175,59 +212,131 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
         double *xb1me = xb1 + (int64_t)c * (a.Mh16 + 2) * 16;
         double *xb2 = a.xb2 + (int64_t)tile * (a.Mh16 + C) * 16;           // [Mh16 + C][16]
         unsigned *fl1 = a.flags + ((int64_t)tile * 2 + 0) * C, *fl2 = a.flags + ((int64_t)tile * 2 + 1) * C;
-        unsigned seq1 = 0, seq2 = 0;
-        bool dead = false;       // abort seen (uniform over the workgroup)
+        unsigned seq = 0;
+        const bool profiling = a.prof != nullptr && tile == 0 && c == 0 && tid == 0;
+        long long pt = profiling ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define AF_TICK(slot) if (profiling) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); a.prof[slot] += now_ - pt; pt = now_; }
 
-        // publish: everything this member wrote for the exchange is ordered before the flag (barrier + release);
-        // collect: wait for every member's flag (bounded), then everybody may read
-        auto publish = [&](unsigned *fl, unsigned seq) {
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(&fl[c], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        auto collect = [&](const unsigned *fl, unsigned seq) {
-            if (tid < C) {
-                unsigned spins = 0;
-                while ((int)(__hip_atomic_load(&fl[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
-                    if ((++spins & 1023u) == 0u &&
-                        (spins > (1u << 24) || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                        __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        S.abort = 1;
-                        break;
+        // Exchanges.  Every shared word is accessed with agent-scope (sc1) atomics, which are coherent across the XCDs on
+        // their own; what a release / acquire pair would add -- buffer_wbl2 (write back the whole L2) per publish and
+        // buffer_inv (drop the L2's lines, the streamed W fragments among them) per poll -- is not needed, only the ORDER
+        // "data complete, then flag": every thread drains its stores (s_waitcnt vmcnt(0): an sc1 store is acknowledged at
+        // device scope), the barrier collects the threads, one relaxed store raises the flag.  The reader polls with relaxed
+        // loads and issues its data loads after the barrier that follows the poll (loads of a wave return in order).
+#define AF_EXCHANGE(fl)                                                                                                         \
+        {                                                                                                                       \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                    \
+            __syncthreads();                                                                                                    \
+            if (tid == 0) __hip_atomic_store(&(fl)[c], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                        \
+            if (tid < C) {                                                                                                      \
+                unsigned spins = 0;                                                                                             \
+                while ((int)(__hip_atomic_load(&(fl)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {           \
+                    if ((++spins & 1023u) == 0u &&                                                                              \
+                        (spins > (1u << 24) || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {  \
+                        __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                        \
+                        S.abort = 1;                                                                                            \
+                        break;                                                                                                  \
+                    }                                                                                                           \
+                    __builtin_amdgcn_s_sleep(1);                                                                                \
+                }                                                                                                               \
+            }                                                                                                                   \
+            asm volatile("" ::: "memory");                                                                                      \
+            __syncthreads();                                                                                                    \
+            if (af_uni(S.abort)) return;                                                                                        \
+        }
+
+        // ================================================================ set-up of the tile
+        if (tid == 0) { S.abort = 0; S.nactive = 0; }
+        if (tid < 16) { S.it1[tid] = 0; S.it2[tid] = 0; S.act[tid] = 0; S.pd2[tid] = 0.0; S.pf0[tid] = 0.0; }
+        for (int idx = tid; idx < rows * 16; idx += AF_THREADS) {
+            const int j = row0 + (idx >> 4);
+            Zs[idx] = (j < a.n) ? Xt[(int64_t)j * 16 + (idx & 15)] : 0.0;
+        }
+        for (int row = tid; row < rows; row += AF_THREADS) {
+            const int j = row0 + row;
+            Qs[row] = j < a.n ? a.q0[j] : 0.0; DIs[row] = j < a.n ? a.dinv[j] : 0.0; PDs[row] = j < a.n ? a.pdiag[j] : 0.0;
+        }
+        __syncthreads();
+
+        int st = AF_EVAL0, t = 0;
+        while (st != AF_DONE) {
+            const bool iter = st == AF_PH1 || st == AF_PH2;
+            const bool ph2 = st == AF_PH2;
+            AF_TICK(8)
+            if (iter) {
+                // ---- z-update of the own rows: T = W[rows, :] d on the matrix cores, element-wise in the accumulators
+                double accd = 0.0, accf = 0.0;
+                const int col = lane & 15;
+                const bool on = S.act[col] != 0;
+                for (int lb0 = wave; lb0 < NBl; lb0 += 16) {
+                    const int lb1 = lb0 + 8;
+                    const bool two = lb1 < NBl;
+                    af_gcd *A0 = Wp + ((int64_t)(b_lo + lb0) * KSh) * 64 + lane;
+                    af_gcd *A1 = Wp + ((int64_t)(b_lo + (two ? lb1 : lb0)) * KSh) * 64 + lane;
+                    af_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                    if (two) af_stream<true>(A0, A1, Ds + lane, KSh, acc0, acc1);
+                    else af_stream<false>(A0, A1, Ds + lane, KSh, acc0, acc1);
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        if (half && !two) break;
+                        const int lb = half ? lb1 : lb0;
+#pragma unroll
+                        for (int v = 0; v < 4; v++) {
+                            const int row = lb * 16 + (lane >> 4) + 4 * v;
+                            if (!on || row0 + row >= a.n) continue;
+                            const double zold = Zs[row * 16 + col];
+                            double s = half ? acc1[v] : acc0[v];
+                            s += dm * zold;                                      // S = m z + W d  (reduced basis)
+                            if (!ph2) {
+                                Zs[row * 16 + col] = s / dm;                     // qcqp.py:205
+                            } else {
+                                const double rhs = 2.0 * a.rho * s - Qs[row];    // qcqp.py:231
+                                const double zn = DIs[row] * rhs;
+                                const double d = zold - zn;
+                                accd += d * d;
+                                accf += (PDs[row] * zn + Qs[row]) * zn;
+                                Zs[row * 16 + col] = zn;
+                            }
+                        }
                     }
-                    __builtin_amdgcn_s_sleep(1);
                 }
+                if (ph2) {
+                    accd += __shfl_xor(accd, 16); accd += __shfl_xor(accd, 32);
+                    accf += __shfl_xor(accf, 16); accf += __shfl_xor(accf, 32);
+                    if (lane < 16) { S.red[wave][0][lane] = accd; S.red[wave][1][lane] = accf; }
+                    __syncthreads();
+                    if (tid < 16) {
+                        double d2 = 0.0, f = 0.0;
+                        for (int w = 0; w < 8; w++) { d2 += S.red[w][0][tid]; f += S.red[w][1][tid]; }
+                        S.pd2[tid] = d2; S.pf0[tid] = f;
+                    }
+                }
+                __syncthreads();
+            } else {
+                // ---- evaluation of the point in Zs: f0 partial over the own rows, sum (P0_ii z + q0) z (admm_f0_kernel)
+                const int col = tid & 15;
+                double acc = 0.0;
+                for (int row = tid >> 4; row < rows; row += AF_THREADS / 16)
+                    if (row0 + row < a.n) { const double z = Zs[row * 16 + col]; acc += (PDs[row] * z + Qs[row]) * z; }
+                S.scr[tid] = acc;
+                __syncthreads();
+                if (tid < 16) {
+                    double s = 0.0;
+                    for (int q = 0; q < AF_THREADS / 16; q++) s += S.scr[q * 16 + tid];
+                    S.pf0[tid] = s; S.pd2[tid] = 0.0;
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            dead = S.abort != 0;
-        };
-
-        // ---- partial ZQ = W[rows, :]^T z[rows] -> this member's slot (hat blocks dealt to the waves, two at a time)
-        auto gemm1 = [&]() {
-            const int nks = 4 * NBl;
+            AF_TICK(0)
+            // ---- partial ZQ = W[rows, :]^T z[rows] -> this member's slot (hat blocks dealt to the waves, two at a time)
             for (int mb0 = wave; mb0 < MBh; mb0 += 16) {
                 const int mb1 = mb0 + 8;
                 const bool two = mb1 < MBh;
-                const double *A0 = a.WTpk + ((int64_t)mb0 * KSn + 4 * b_lo) * 64 + lane;
-                const double *A1 = a.WTpk + ((int64_t)(two ? mb1 : mb0) * KSn + 4 * b_lo) * 64 + lane;
+                af_gcd *A0 = WT + ((int64_t)mb0 * KSn + 4 * b_lo) * 64 + lane;
+                af_gcd *A1 = WT + ((int64_t)(two ? mb1 : mb0) * KSn + 4 * b_lo) * 64 + lane;
                 af_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                double n0[4], n1[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { n0[u] = A0[u * 64]; n1[u] = A1[u * 64]; }
-                for (int kk = 0; kk < nks; kk += 4) {
-                    double c0[4], c1[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { c0[u] = n0[u]; c1[u] = n1[u]; }
-                    if (kk + 4 < nks) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { n0[u] = A0[(kk + 4 + u) * 64]; n1[u] = A1[(kk + 4 + u) * 64]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const double b = Zs[(kk + u) * 64 + lane];
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[u], b, acc0, 0, 0, 0);
-                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[u], b, acc1, 0, 0, 0);
-                    }
-                }
+                if (two) af_stream<true>(A0, A1, Zs + lane, 4 * NBl, acc0, acc1);
+                else af_stream<false>(A0, A1, Zs + lane, 4 * NBl, acc0, acc1);
                 // accumulator layout: register v of lane l = row (l >> 4) + 4 v of the block, column l & 15
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
@@ -237,242 +346,145 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
                 }
             }
             if (tid < 32) ag_store(xb1me + ((int64_t)a.Mh16 + (tid >> 4)) * 16 + (tid & 15), (tid >> 4) ? S.pf0[tid & 15] : S.pd2[tid & 15]);
-        };
-        // ---- sums of the C partials for the own constraints' rows (fixed order), and of the two scalars per restart
-        auto sum1 = [&]() {
-            for (int idx = tid; idx < nh * 16; idx += AF_THREADS) {
-                const int64_t off = ((int64_t)h_lo + (idx >> 4)) * 16 + (idx & 15);
-                double s = ag_load(xb1 + off);
-                for (int cc = 1; cc < C; cc++) s += ag_load(xb1 + (int64_t)cc * (a.Mh16 + 2) * 16 + off);
-                ZQs[idx] = s;
-            }
-            if (tid < 32) {
-                const int64_t off = ((int64_t)a.Mh16 + (tid >> 4)) * 16 + (tid & 15);
-                double s = ag_load(xb1 + off);
-                for (int cc = 1; cc < C; cc++) s += ag_load(xb1 + (int64_t)cc * (a.Mh16 + 2) * 16 + off);
-                if (tid >> 4) S.f0z[tid & 15] = s + a.r0; else S.dist2[tid & 15] = s;
-            }
-            if (tid < 16) S.mvbits[tid] = 0ull;
-            __syncthreads();
-        };
-        // ---- secular solves of the own (constraint, restart) pairs; publishes operand rows and partial max violations
-        auto secular = [&](int first_iter, int viol_only) {
-            for (int idx = tid; idx < nk * 16; idx += AF_THREADS) {
-                const int kl = idx >> 4, r = idx & 15;
-                if (!viol_only && !S.act[r]) continue;
-                secular_dispatch(a, k_lo + kl, ZQs + (size_t)kl * rp * 16 + r, UHs + (size_t)kl * rp * 16 + r, first_iter, viol_only,
-                                 &S.mvbits[r], xb2 + ((int64_t)(k_lo + kl) * rp) * 16 + r);
-            }
-            __syncthreads();
-            if (tid < 16) ag_store(xb2 + ((int64_t)a.Mh16 + c) * 16 + tid, __longlong_as_double((long long)S.mvbits[tid]));
-        };
-        // ---- after exchange 2: all operand rows into LDS (unless only violations were wanted), max violation per restart
-        auto gather2 = [&](int viol_only) {
-            if (!viol_only)
-                for (int idx = tid; idx < a.Mh16 * 16; idx += AF_THREADS) Ds[idx] = ag_load(xb2 + idx);
-            if (tid < 16) {
-                double mv = ag_load(xb2 + ((int64_t)a.Mh16) * 16 + tid);
-                for (int cc = 1; cc < C; cc++) { const double w = ag_load(xb2 + ((int64_t)a.Mh16 + cc) * 16 + tid); mv = w > mv ? w : mv; }
-                S.mvv[tid] = mv;
-            }
-            __syncthreads();
-        };
-        // ---- f0 of the z slice (partial over the own rows): sum (P0_ii z + q0) z, the expression of admm_f0_kernel
-        auto f0_partial = [&]() {
-            const int col = tid & 15, rl = tid >> 4;
-            double acc = 0.0;
-            for (int row = rl; row < rows; row += AF_THREADS / 16) {
-                const int j = row0 + row;
-                if (j < a.n) { const double z = Zs[row * 16 + col]; acc += (a.pdiag[j] * z + a.q0[j]) * z; }
-            }
-            S.scr[tid] = acc;
-            __syncthreads();
-            if (tid < 16) {
-                double s = 0.0;
-                for (int q = 0; q < AF_THREADS / 16; q++) s += S.scr[q * 16 + tid];
-                S.pf0[tid] = s; S.pd2[tid] = 0.0;
-            }
-            __syncthreads();
-        };
-        // ---- (f0, max violation) of the point in Zs for all 16 restarts, in the arithmetic the iteration uses
-        auto evaluate = [&](double *fout, double *vout) {
-            f0_partial();
-            gemm1();
-            publish(fl1, ++seq1);
-            collect(fl1, seq1);
-            if (dead) return;
-            sum1();
-            secular(1, 1);
-            publish(fl2, ++seq2);
-            collect(fl2, seq2);
-            if (dead) return;
-            gather2(1);
-            if (tid < 16) { fout[tid] = S.f0z[tid]; vout[tid] = S.mvv[tid]; }
-            __syncthreads();
-        };
-        // ---- z-update of the own rows: T = W[rows, :] d on the matrix cores, element-wise update in the accumulators
-        auto zupdate = [&](int phase) {
-            double accd[4] = {0.0, 0.0, 0.0, 0.0}, accf[4] = {0.0, 0.0, 0.0, 0.0};   // per accumulator register, then per column
-            const int col = lane & 15;
-            const bool on = S.act[col] != 0;
-            for (int lb0 = wave; lb0 < NBl; lb0 += 16) {
-                const int lb1 = lb0 + 8;
-                const bool two = lb1 < NBl;
-                const double *A0 = a.Wpk + ((int64_t)(b_lo + lb0) * KSh) * 64 + lane;
-                const double *A1 = a.Wpk + ((int64_t)(b_lo + (two ? lb1 : lb0)) * KSh) * 64 + lane;
-                af_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                double n0[4], n1[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { n0[u] = A0[u * 64]; n1[u] = A1[u * 64]; }
-                for (int kk = 0; kk < KSh; kk += 4) {
-                    double c0[4], c1[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { c0[u] = n0[u]; c1[u] = n1[u]; }
-                    if (kk + 4 < KSh) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { n0[u] = A0[(kk + 4 + u) * 64]; n1[u] = A1[(kk + 4 + u) * 64]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const double b = Ds[(kk + u) * 64 + lane];
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[u], b, acc0, 0, 0, 0);
-                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[u], b, acc1, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    if (half && !two) break;
-                    const int lb = half ? lb1 : lb0;
-#pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const int row = lb * 16 + (lane >> 4) + 4 * v, j = row0 + row;
-                        if (!on || j >= a.n) continue;
-                        const double zold = Zs[row * 16 + col];
-                        double s = half ? acc1[v] : acc0[v];
-                        s += dm * zold;                                   // S = m z + W d  (reduced basis)
-                        if (phase == 1) {
-                            Zs[row * 16 + col] = s / dm;                  // qcqp.py:205
-                        } else {
-                            const double rhs = 2.0 * a.rho * s - a.q0[j]; // qcqp.py:231
-                            const double zn = a.dinv[j] * rhs;
-                            const double d = zold - zn;
-                            accd[v] += d * d;
-                            accf[v] += (a.pdiag[j] * zn + a.q0[j]) * zn;
-                            Zs[row * 16 + col] = zn;
-                        }
-                    }
-                }
-            }
-            if (phase == 2) {
-                double sd = (accd[0] + accd[1]) + (accd[2] + accd[3]), sf = (accf[0] + accf[1]) + (accf[2] + accf[3]);
-                sd += __shfl_xor(sd, 16); sd += __shfl_xor(sd, 32);
-                sf += __shfl_xor(sf, 16); sf += __shfl_xor(sf, 32);
-                if (lane < 16) { S.red[wave][0][lane] = sd; S.red[wave][1][lane] = sf; }
-                __syncthreads();
-                if (tid < 16) {
-                    double d2 = 0.0, f = 0.0;
-                    for (int w = 0; w < 8; w++) { d2 += S.red[w][0][tid]; f += S.red[w][1][tid]; }
-                    S.pd2[tid] = d2; S.pf0[tid] = f;
-                }
-            }
-            __syncthreads();
-        };
-        // ---- per-restart control flow (admm_book_kernel of admm.h), redundantly in every member
-        auto book = [&](int phase, int have_last) {
-            if (tid < 16) {
-                int tk = 0, lv = 0;
-                if (S.act[tid]) {
-                    const double mv = S.mvv[tid];
-                    bool stop = false;
-                    if (phase == 1) {
-                        if (mv < a.tol) stop = true;                                   // qcqp.py:203
-                    } else {
-                        if (have_last && sqrt(S.dist2[tid]) < a.tol) stop = true;      // qcqp.py:241-242 (before bestx)
-                        else if (mv > a.viol_lim) stop = true;                         // qcqp.py:248
-                        else if (better_first(S.f0z[tid], mv, S.best_f0[tid], S.best_mv[tid])) {
-                            tk = 1; S.best_f0[tid] = S.f0z[tid]; S.best_mv[tid] = mv;  // bestx = better(z, bestx)
-                        }
-                    }
-                    if (stop) S.act[tid] = 0;
-                    else { if (phase == 1) S.it1[tid]++; else S.it2[tid]++; atomicAdd(&S.nactive, 1); }
-                    lv = 1;
-                }
-                S.take[tid] = tk; S.live[tid] = lv;
-            }
-            __syncthreads();
-            if (phase == 2) {
-                const int col = tid & 15;
-                if (S.take[col])
-                    for (int row = tid >> 4; row < rows; row += AF_THREADS / 16) Bt[(int64_t)(row0 + row) * 16 + col] = Zs[row * 16 + col];
-            }
-        };
-        auto run_phase = [&](int phase) {
-            for (int idx = tid; idx < a.Mh16 * 16; idx += AF_THREADS) Ds[idx] = 0.0;     // xs = x0, us = 0: S = m x0
-            if (tid < 16) { S.act[tid] = (tile * 16 + tid < a.R) ? 1 : 0; S.pd2[tid] = 0.0; S.pf0[tid] = 0.0; }
-            __syncthreads();
-            for (int t = 0; t < a.num_iters; t++) {
-                zupdate(phase);
-                gemm1();
-                publish(fl1, ++seq1);
-                collect(fl1, seq1);
-                if (dead) return;
-                sum1();
-                secular(t == 0, 0);
-                publish(fl2, ++seq2);
-                collect(fl2, seq2);
-                if (dead) return;
-                if (tid == 0) S.nactive = 0;
-                gather2(0);
-                book(phase, t > 0);
-                __syncthreads();
-                if (S.nactive == 0) break;
-                __syncthreads();
-            }
-        };
-
-        // ================================================================ the run for this tile
-        if (tid == 0) { S.abort = 0; S.nactive = 0; }
-        if (tid < 16) { S.it1[tid] = 0; S.it2[tid] = 0; S.act[tid] = 0; }
-        for (int idx = tid; idx < rows * 16; idx += AF_THREADS) {
-            const int j = row0 + (idx >> 4);
-            Zs[idx] = (j < a.n) ? Xt[(int64_t)j * 16 + (idx & 15)] : 0.0;
-        }
-        __syncthreads();
-        evaluate(S.fx0, S.vx0);                                   // (f, v) of x0
-        if (dead) return;
-        if (tid < 16) { S.fx1[tid] = S.fx0[tid]; S.vx1[tid] = S.vx0[tid]; }
-        __syncthreads();
-        if (a.phase1) {
-            run_phase(1);
-            if (dead) return;
-            __syncthreads();
-            evaluate(S.f0z, S.mvv);                               // (f, v) of z1 (evaluate writes the arrays it is handed)
-            if (dead) return;
-            // x1 = better(x0, z1)  (qcqp.py:281)
-            if (tid < 16) {
-                const bool first = better_first(S.fx0[tid], S.vx0[tid], S.f0z[tid], S.mvv[tid]);
-                S.take[tid] = first ? 1 : 0;
-                if (!first) { S.fx1[tid] = S.f0z[tid]; S.vx1[tid] = S.mvv[tid]; }
-            }
-            __syncthreads();
+            AF_TICK(1)
+            ++seq;
+            AF_EXCHANGE(fl1)
+            AF_TICK(2)
+            // ---- sums of the C partials for the own constraints' rows (fixed order), and of the two scalars per restart;
+            // all loads of a thread are issued before the first sum waits (one round trip, not C)
             {
-                const int col = tid & 15;
-                for (int row = tid >> 4; row < rows; row += AF_THREADS / 16) {
-                    const int64_t gi = (int64_t)(row0 + row) * 16 + col;
-                    if (S.take[col]) Zs[row * 16 + col] = (row0 + row < a.n) ? Xt[gi] : 0.0;     // x0 stays
-                    else Xt[gi] = Zs[row * 16 + col];                                           // X now holds x1
+                const int64_t slot = (int64_t)(a.Mh16 + 2) * 16;
+                for (int idx = tid; idx < nh * 16; idx += AF_THREADS) {
+                    const int64_t off = ((int64_t)h_lo + (idx >> 4)) * 16 + (idx & 15);
+                    double pv[AF_MAXC];
+#pragma unroll
+                    for (int cc = 0; cc < AF_MAXC; cc++) pv[cc] = (cc < C) ? ag_load(xb1 + cc * slot + off) : 0.0;
+                    double s = pv[0];
+#pragma unroll
+                    for (int cc = 1; cc < AF_MAXC; cc++) if (cc < C) s += pv[cc];
+                    ZQs[idx] = s;
                 }
+                if (tid < 32) {
+                    const int64_t off = ((int64_t)a.Mh16 + (tid >> 4)) * 16 + (tid & 15);
+                    double pv[AF_MAXC];
+#pragma unroll
+                    for (int cc = 0; cc < AF_MAXC; cc++) pv[cc] = (cc < C) ? ag_load(xb1 + cc * slot + off) : 0.0;
+                    double s = pv[0];
+#pragma unroll
+                    for (int cc = 1; cc < AF_MAXC; cc++) if (cc < C) s += pv[cc];
+                    if (tid >> 4) S.f0z[tid & 15] = s + a.r0; else S.dist2[tid & 15] = s;
+                }
+                if (tid < 16) S.mvbits[tid] = 0ull;
+                __syncthreads();
+            }
+            AF_TICK(3)
+            // ---- secular solves of the own (constraint, restart) pairs; operand rows and partial max violations go out
+            {
+                const bool first_iter = !iter || t == 0, viol_only = !iter;
+                for (int idx = tid; idx < nk * 16; idx += AF_THREADS) {
+                    const int kl = idx >> 4, r = idx & 15;
+                    if (!viol_only && !S.act[r]) continue;
+                    const double *zq = ZQs + (size_t)kl * RP * 16 + r;
+                    double *uh = UHs + (size_t)kl * RP * 16 + r, *dout = xb2 + ((int64_t)(k_lo + kl) * RP) * 16 + r;
+                    if (qz) secular_pair<RP, true>(a, k_lo + kl, zq, uh, first_iter, viol_only, &S.mvbits[r], dout);
+                    else secular_pair<RP, false>(a, k_lo + kl, zq, uh, first_iter, viol_only, &S.mvbits[r], dout);
+                }
+                __syncthreads();
+                if (tid < 16) ag_store(xb2 + ((int64_t)a.Mh16 + c) * 16 + tid, __longlong_as_double((long long)S.mvbits[tid]));
+            }
+            AF_TICK(4)
+            AF_EXCHANGE(fl2)
+            AF_TICK(5)
+            // ---- all operand rows into LDS (iterations only), max violation per restart
+            {
+                if (tid == 0) S.nactive = 0;
+                if (iter) {
+                    for (int idx0 = 0; idx0 < a.Mh16 * 16; idx0 += 4 * AF_THREADS) {     // four loads in flight per thread
+                        double pv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { const int idx = idx0 + u * AF_THREADS + tid; pv[u] = (idx < a.Mh16 * 16) ? ag_load(xb2 + idx) : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { const int idx = idx0 + u * AF_THREADS + tid; if (idx < a.Mh16 * 16) Ds[idx] = pv[u]; }
+                    }
+                }
+                if (tid < 16) {
+                    double mv = ag_load(xb2 + ((int64_t)a.Mh16) * 16 + tid);
+                    for (int cc = 1; cc < C; cc++) { const double w = ag_load(xb2 + ((int64_t)a.Mh16 + cc) * 16 + tid); mv = w > mv ? w : mv; }
+                    S.mvv[tid] = mv;
+                }
+                __syncthreads();
+            }
+            AF_TICK(6)
+            int next = st;
+            if (iter) {
+                // ---- per-restart control flow (admm_book_kernel of admm.h), redundantly in every member
+                if (tid < 16) {
+                    int tk = 0;
+                    if (S.act[tid]) {
+                        const double mv = S.mvv[tid];
+                        bool stop = false;
+                        if (!ph2) {
+                            if (mv < a.tol) stop = true;                                   // qcqp.py:203
+                        } else {
+                            if (t > 0 && sqrt(S.dist2[tid]) < a.tol) stop = true;          // qcqp.py:241-242 (before bestx)
+                            else if (mv > a.viol_lim) stop = true;                         // qcqp.py:248
+                            else if (better_first(S.f0z[tid], mv, S.best_f0[tid], S.best_mv[tid])) {
+                                tk = 1; S.best_f0[tid] = S.f0z[tid]; S.best_mv[tid] = mv;  // bestx = better(z, bestx)
+                            }
+                        }
+                        if (stop) S.act[tid] = 0;
+                        else { if (!ph2) S.it1[tid]++; else S.it2[tid]++; atomicAdd(&S.nactive, 1); }
+                    }
+                    S.take[tid] = tk;
+                }
+                __syncthreads();
+                if (ph2) {
+                    const int col = tid & 15;
+                    if (S.take[col])
+                        for (int row = tid >> 4; row < rows; row += AF_THREADS / 16) Bt[(int64_t)(row0 + row) * 16 + col] = Zs[row * 16 + col];
+                }
+                t++;
+                if (profiling) a.prof[9]++;
+                if (af_uni(S.nactive) == 0 || t >= a.num_iters) next = ph2 ? AF_DONE : AF_EVAL1;
+            } else {
+                // ---- an evaluation has finished: (f, v) of the point in Zs are in f0z / mvv
+                if (st == AF_EVAL0) {
+                    if (tid < 16) { S.fx0[tid] = S.f0z[tid]; S.vx0[tid] = S.mvv[tid]; S.fx1[tid] = S.f0z[tid]; S.vx1[tid] = S.mvv[tid]; }
+                    next = (a.phase1 && a.num_iters > 0) ? AF_PH1 : AF_PH2;
+                } else {
+                    // x1 = better(x0, z1)  (qcqp.py:281)
+                    if (tid < 16) {
+                        const bool first = better_first(S.fx0[tid], S.vx0[tid], S.f0z[tid], S.mvv[tid]);
+                        S.take[tid] = first ? 1 : 0;
+                        if (!first) { S.fx1[tid] = S.f0z[tid]; S.vx1[tid] = S.mvv[tid]; }
+                    }
+                    __syncthreads();
+                    const int col = tid & 15;
+                    for (int row = tid >> 4; row < rows; row += AF_THREADS / 16) {
+                        const int64_t gi = (int64_t)(row0 + row) * 16 + col;
+                        if (S.take[col]) Zs[row * 16 + col] = (row0 + row < a.n) ? Xt[gi] : 0.0;     // x0 stays
+                        else Xt[gi] = Zs[row * 16 + col];                                           // X now holds x1
+                    }
+                    next = AF_PH2;
+                }
+                __syncthreads();
+            }
+            if (next != st && (next == AF_PH1 || next == AF_PH2)) {
+                // ---- start of a phase: xs = x0, us = 0 (S = m x0: no operand rows yet); phase 2 starts with bestx = x1
+                for (int idx = tid; idx < a.Mh16 * 16; idx += AF_THREADS) Ds[idx] = 0.0;
+                if (tid < 16) { S.act[tid] = (tile * 16 + tid < a.R) ? 1 : 0; S.pd2[tid] = 0.0; S.pf0[tid] = 0.0; }
+                if (next == AF_PH2) {
+                    for (int idx = tid; idx < rows * 16; idx += AF_THREADS) Bt[(int64_t)row0 * 16 + idx] = Zs[idx];
+                    if (tid < 16) { S.best_f0[tid] = S.fx1[tid]; S.best_mv[tid] = S.vx1[tid]; }
+                    if (a.num_iters <= 0) next = AF_DONE;
+                }
+                t = 0;
             }
             __syncthreads();
+            AF_TICK(7)
+            st = next;
         }
-        // phase 2 from x1: bestx = x1
-        for (int idx = tid; idx < rows * 16; idx += AF_THREADS) Bt[(int64_t)row0 * 16 + idx] = Zs[idx];
-        if (tid < 16) { S.best_f0[tid] = S.fx1[tid]; S.best_mv[tid] = S.vx1[tid]; }
-        __syncthreads();
-        run_phase(2);
-        if (dead) return;
-        __syncthreads();
-        // x2 = better(x1, bestx)  (qcqp.py:284)
+        // ================================================================ x2 = better(x1, bestx)  (qcqp.py:284)
         if (tid < 16) {
             const bool first = better_first(S.fx1[tid], S.vx1[tid], S.best_f0[tid], S.best_mv[tid]);
             S.take[tid] = first ? 1 : 0;
@@ -494,7 +506,24 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
                 }
         }
         __syncthreads();
+#undef AF_TICK
+#undef AF_EXCHANGE
     }
+}
+
+typedef void (*af_kernel_t)(AdmmFusedArgs);
+af_kernel_t af_kernel_for(int rp) {
+    switch (rp) {
+    case 1: return admm_fused_kernel<1>;
+    case 2: return admm_fused_kernel<2>;
+    case 3: return admm_fused_kernel<3>;
+    case 4: return admm_fused_kernel<4>;
+    case 5: return admm_fused_kernel<5>;
+    case 6: return admm_fused_kernel<6>;
+    case 7: return admm_fused_kernel<7>;
+    case 8: return admm_fused_kernel<8>;
+    }
+    return nullptr;
 }
 
 }  // namespace
@@ -502,17 +531,17 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
 size_t admm_fused_lds_bytes(const AdmmFusedArgs &a) {
     const int KBn = a.n16 / 16;
     const size_t rows_max = 16 * (size_t)((KBn + a.C - 1) / a.C), nh_max = (size_t)((a.m + a.C - 1) / a.C) * a.rp;
-    const size_t doubles = (sizeof(AfState) + 7) / 8 + rows_max * 16 + (size_t)a.Mh16 * 16 + 2 * nh_max * 16;
+    const size_t doubles = (sizeof(AfState) + 7) / 8 + rows_max * 16 + (size_t)a.Mh16 * 16 + 2 * nh_max * 16 + 3 * rows_max;
     const size_t bytes = doubles * sizeof(double);
     return bytes <= 160 * 1024 ? bytes : 0;
 }
 
 int admm_fused_max_clusters(const AdmmFusedArgs &a, int device) {
     const size_t lds = admm_fused_lds_bytes(a);
-    if (!lds) return 0;
-    (void)hipFuncSetAttribute((const void *)admm_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!lds || !af_kernel_for(a.rp)) return 0;
+    (void)hipFuncSetAttribute((const void *)af_kernel_for(a.rp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, admm_fused_kernel, AF_THREADS, lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, af_kernel_for(a.rp), AF_THREADS, lds) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
     const int blocks = per_cu * cus;
     // block index = x + 8 (c + C y): clusters come in groups of 8
@@ -522,13 +551,13 @@ int admm_fused_max_clusters(const AdmmFusedArgs &a, int device) {
 
 int admm_fused_launch(const AdmmFusedArgs &a, hipStream_t st) {
     const size_t lds = admm_fused_lds_bytes(a);
-    if (!lds) return (int)hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void *)admm_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!lds || !af_kernel_for(a.rp)) return (int)hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void *)af_kernel_for(a.rp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int groups = (a.G + 7) / 8;
     AdmmFusedArgs args = a;
     void *params[] = {&args};
-    e = hipLaunchCooperativeKernel((const void *)admm_fused_kernel, dim3((unsigned)(8 * a.C * groups)), dim3(AF_THREADS), params, (unsigned)lds, st);
+    e = hipLaunchCooperativeKernel((const void *)af_kernel_for(a.rp), dim3((unsigned)(8 * a.C * groups)), dim3(AF_THREADS), params, (unsigned)lds, st);
     return (int)e;
 }
 

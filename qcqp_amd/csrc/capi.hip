@@ -117,6 +117,7 @@ struct qcqpmi_ctx {
     int *ad_relop = nullptr;
     int64_t ad_rows = 0, ad_Mh16 = 0;   // hat rows per constraint (n, or rp of a reduced basis); m * rows padded to 16
     int ad_lowrank = 0;
+    bool ad_qzero = false;              // every B_k^T q_k is zero
     void *rb_handle = nullptr;          // rocBLAS handle: only the rocSOLVER setup path needs one
     bool p0_diag = false;               // P0 has no off-diagonal entries (z-update and f0 need no product then)
     std::vector<double> p0_diag_host;
@@ -159,6 +160,7 @@ struct qcqpmi_ctx {
     bool ad_fused = true;                 // qcqpmi_admm_fused: use the fused kernel where it applies
     const char *last_admm_kernel = "";    // "admm_fused_kernel" / "admm_multi_launch"
     int last_admm_C = 0;                  // workgroups per tile of the last fused run
+    long long af_prof[16] = {0};          // stage cycle counters of the last fused run (when qcqpmi_debug_profile enabled them)
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
     std::vector<int> last_st1, last_st2;   // per-restart status codes of the last coordinate-descent run (qcqpmi_cd_status)

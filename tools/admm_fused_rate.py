@@ -15,8 +15,11 @@ e = Engine(form)
 lam, Bv, qhat, info = lowrank.reduced_bases(e, form)
 e.admm_set_basis(lam, Bv, qhat)
 print('n=%d m=%d rp=%d R=%d num_iters=%d' % (form.n, form.m, info['rp'], R, iters))
+import ctypes as C
+prof = '--prof' in sys.argv
 for fused in (True, False, True):
     e.admm_fused(fused)
+    e.L.qcqpmi_debug_profile(e.h, 1 if (prof and fused) else 0, None)
     for rep in range(2):
         e.randn(R, seed=5)
         e.sync()
@@ -28,3 +31,11 @@ for fused in (True, False, True):
     kms = e.kernel_ms(4)
     print('%-18s C=%2d: %.4f s wall, %.3e restart-iterations -> %.3e /s (wall); iterations of the longest restart %d + %d; feasible %d; '
           'timer[4] %.3f ms' % (name, cw, dt, its, its / dt, out['iters1'].max(), out['iters2'].max(), int((out['maxviol'] < 1e-2).sum()), kms))
+    if prof and fused:
+        pr = np.zeros(16, dtype=np.int64)
+        e.L.qcqpmi_debug_admm_profile(e.h, pr.ctypes.data_as(C.POINTER(C.c_int64)))
+        nit = max(1, int(pr[9]))
+        names = ['z-update', 'partial product', 'exchange 1', 'sums', 'secular', 'exchange 2', 'gather', 'book', 'loop top']
+        tot = float(pr[:9].sum())
+        print('   per iteration (s_memtime ticks), %d iterations, total %.0f ticks = %.2f us (timer): ' % (nit, tot / nit, kms * 1e3 / nit)
+              + ', '.join('%s %.0f (%.0f%%)' % (nm, pr[k] / nit, 100 * pr[k] / tot) for k, nm in enumerate(names)))
