@@ -237,6 +237,12 @@ int qcqpmi_last_kernel_ms(qcqpmi_ctx *ctx, int which, double *ms);
  * separable constraints), "dense_chain_kernel" (constraints that couple coordinates, n > 64 or generated),
  * "cd_general_kernel" (coupled constraints in the reference's arithmetic); static storage.  The parity tests assert it. */
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *ctx);
+/* Scheduling of phase 2 for the Boolean family (the headline kernel).  0: a workgroup is bound to a tile of 16 restarts for
+ * the whole launch (cd_phase2_q_kernel: it runs until its slowest restart has converged).  1: a workgroup owns 16 SLOTS; a
+ * restart that is done (qcqp.py:172-176, or num_iters sweeps) is written out at the next sweep boundary and its slot takes the
+ * next restart from a device-side queue (cd_phase2_qs_kernel, csrc/cd_queue.hip).  Per restart the same arithmetic; results
+ * do not depend on the scheduling (every product is summed in one association).  qcqpmi_last_cd_kernel names the kernel. */
+int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);
 /* Coordinate descent for constraints that couple coordinates IN THE REFERENCE'S SUMMATION ORDER (test / diagnostic mode, any
  * n): every one-variable coefficient (t2, t1, t0) of get_onevar_func (utilities.py:99-105) is formed by row-sequential sums
  * like the reference's CSR products -- t0 = f_k(z) afresh per coordinate, O((m+1) n^2) per coordinate visit -- so that

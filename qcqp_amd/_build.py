@@ -16,9 +16,10 @@ HEADER = os.path.join(REPO, 'include', 'qcqp_mi.h')
 # translation unit -> everything it includes (rebuilt when any of these is newer than its object)
 UNITS = {
     'capi.hip': ['capi.hip', 'capi_admm.inc', 'capi_units.inc', 'capi_dense.inc', 'kernels.hip', 'kernels.h', 'onevar.h', 'philox.h',
-                 'cd_phase2.h', 'cd_phase2_rs.h', 'cd_phase2_q.h', 'admm.h', 'admm_fused.h', 'gemm_pk.h', 'cd_general.h', 'cd_dense.h',
+                 'cd_phase2.h', 'cd_phase2_rs.h', 'cd_phase2_q.h', 'admm.h', 'admm_fused.h', 'cd_queue.h', 'gemm_pk.h', 'cd_general.h', 'cd_dense.h',
                  'sdr_solve.h'],
     'admm_fused.hip': ['admm_fused.hip', 'admm_fused.h', 'onevar.h', 'philox.h'],
+    'cd_queue.hip': ['cd_queue.hip', 'cd_queue.h', 'cd_phase2_q.h', 'cd_phase2_rs.h', 'cd_phase2.h', 'kernels.h', 'onevar.h', 'philox.h'],
 }
 SOURCES = sorted(set(sum(UNITS.values(), [])))
 

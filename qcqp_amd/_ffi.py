@@ -61,6 +61,7 @@ PROTOTYPES = [
     ('qcqpmi_last_kernel_ms', C.c_int, [C.c_void_p, C.c_int, c_dp]),
     ('qcqpmi_last_cd_kernel', C.c_char_p, [C.c_void_p]),
     ('qcqpmi_cd_reference_order', C.c_int, [C.c_void_p, C.c_int]),
+    ('qcqpmi_cd_queue', C.c_int, [C.c_void_p, C.c_int]),
     ('qcqpmi_sync', C.c_int, [C.c_void_p]),
     ('qcqpmi_debug_profile', C.c_int, [C.c_void_p, C.c_int, c_ip]),
     ('qcqpmi_debug_admm_profile', C.c_int, [C.c_void_p, c_ip]),

@@ -62,42 +62,59 @@ __device__ inline bool better_first(double f1, double v1, double f2, double v2) 
     return f1 < f2;
 }
 
-// acc0 += sum_k A0[k] B[k] (and acc1 += sum_k A1[k] B[k]) over nks k-steps (a multiple of 4): A fragments stream from
-// global memory (L2) 64 doubles apart, B operands from LDS 64 doubles apart.  Groups of 4 k-steps; the fragments of the
-// group after next are requested before this group multiplies (two groups = 8-16 MFMAs of cover for the L2 latency),
-// the B operands of a group are read one group ahead.
-template <bool TWO>
-__device__ __attribute__((always_inline)) inline void af_stream(af_gcd *A0, af_gcd *A1, const double *Bs, int nks, af_v4d &acc0, af_v4d &acc1) {
-    double p0[4], p1[4], q0[4], q1[4], pb[4];
-    const int last = nks - 4;
+// acc[i] += sum_k A[i][k] B[k], i < NA, over nks k-steps (a multiple of 4): A fragments stream from global memory (L2)
+// 64 doubles apart, B operands from LDS 64 doubles apart (one LDS read serves NA MFMAs).  Groups of 4 k-steps through
+// THREE register stages named statically (the loop is unrolled by three groups: no register rotation, hence no wait on a
+// load issued one group ago): while group i multiplies, the operands of group i + 2 are requested.  The scheduling
+// barriers keep the compiler from sinking the requests next to their uses.
+constexpr int AF_MW = 8;      // waves of a workgroup that multiply (4 = one per SIMD with 4 accumulators measured 5 % slower: the stages are bound by the L2 -> CU fragment stream, 512 B per MFMA, not by the issue slots)
+constexpr int AF_NA = 2;      // accumulators (blocks of 16 rows) a multiplying wave carries at once
+
+template <int NA>
+__device__ __attribute__((always_inline)) inline void af_stream(af_gcd *const (&A)[AF_NA], const double *Bs, int nks, af_v4d (&acc)[AF_NA]) {
+    constexpr int GS = NA >= 3 ? 2 : 4;          // k-steps per group: 8 MFMAs either way
+    double r[3][NA][GS], rb[3][GS];
+    const int last = nks - GS;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        p0[u] = A0[u * 64];
-        if (TWO) p1[u] = A1[u * 64];
-        pb[u] = Bs[u * 64];
-    }
-    {
-        const int k1 = 4 < nks ? 4 : last;
+    for (int j = 0; j < 2; j++) {
+        const int k = GS * j < nks ? GS * j : last;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { q0[u] = A0[(k1 + u) * 64]; if (TWO) q1[u] = A1[(k1 + u) * 64]; }
-    }
-    for (int kk = 0; kk < nks; kk += 4) {
-        double c0[4], c1[4], cb[4];
+        for (int u = 0; u < GS; u++) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) { c0[u] = p0[u]; if (TWO) c1[u] = p1[u]; cb[u] = pb[u]; p0[u] = q0[u]; if (TWO) p1[u] = q1[u]; }
-        const int k1 = kk + 4 < nks ? kk + 4 : last, k2 = kk + 8 < nks ? kk + 8 : last;     // clamped: loaded, never multiplied
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            q0[u] = A0[(k2 + u) * 64];
-            if (TWO) q1[u] = A1[(k2 + u) * 64];
-            pb[u] = Bs[(k1 + u) * 64];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[u], cb[u], acc0, 0, 0, 0);
-            if (TWO) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[u], cb[u], acc1, 0, 0, 0);
+            for (int i = 0; i < NA; i++) r[j][i][u] = A[i][(k + u) * 64];
+            rb[j][u] = Bs[(k + u) * 64];
         }
     }
+    for (int kk = 0; kk < nks; kk += 3 * GS) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int kg = kk + GS * j;
+            const int k2 = kg + 2 * GS < nks ? kg + 2 * GS : last;     // clamped: requested, never multiplied
+            constexpr int J2[3] = {2, 0, 1};
+            const int s2 = J2[j];
+#pragma unroll
+            for (int u = 0; u < GS; u++) {
+#pragma unroll
+                for (int i = 0; i < NA; i++) r[s2][i][u] = A[i][(k2 + u) * 64];
+                rb[s2][u] = Bs[(k2 + u) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kg < nks) {      // wave-uniform
+#pragma unroll
+                for (int u = 0; u < GS; u++)
+#pragma unroll
+                    for (int i = 0; i < NA; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(r[j][i][u], rb[j][u], acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__device__ __attribute__((always_inline)) inline void af_stream_n(int na, af_gcd *const (&A)[AF_NA], const double *Bs, int nks, af_v4d (&acc)[AF_NA]) {
+    if (na >= 4) af_stream<4>(A, Bs, nks, acc);
+    else if (na == 3) af_stream<3>(A, Bs, nks, acc);
+    else if (na == 2) af_stream<2>(A, Bs, nks, acc);
+    else af_stream<1>(A, Bs, nks, acc);
 }
 
 struct AfState {                     // per-tile scalars in LDS
@@ -268,24 +285,28 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
                 double accd = 0.0, accf = 0.0;
                 const int col = lane & 15;
                 const bool on = S.act[col] != 0;
-                for (int lb0 = wave; lb0 < NBl; lb0 += 16) {
-                    const int lb1 = lb0 + 8;
-                    const bool two = lb1 < NBl;
-                    af_gcd *A0 = Wp + ((int64_t)(b_lo + lb0) * KSh) * 64 + lane;
-                    af_gcd *A1 = Wp + ((int64_t)(b_lo + (two ? lb1 : lb0)) * KSh) * 64 + lane;
-                    af_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                    if (two) af_stream<true>(A0, A1, Ds + lane, KSh, acc0, acc1);
-                    else af_stream<false>(A0, A1, Ds + lane, KSh, acc0, acc1);
+                for (int lb0 = wave; wave < AF_MW && lb0 < NBl; lb0 += AF_MW * AF_NA) {
+                    int na = 0;
+                    af_gcd *A[AF_NA];
+                    af_v4d acc[AF_NA];
 #pragma unroll
-                    for (int half = 0; half < 2; half++) {
-                        if (half && !two) break;
-                        const int lb = half ? lb1 : lb0;
+                    for (int i = 0; i < AF_NA; i++) {
+                        const int lb = lb0 + AF_MW * i;
+                        if (lb < NBl) na = i + 1;
+                        A[i] = Wp + ((int64_t)(b_lo + (lb < NBl ? lb : lb0)) * KSh) * 64 + lane;
+                        acc[i] = af_v4d{0.0, 0.0, 0.0, 0.0};
+                    }
+                    af_stream_n(na, A, Ds + lane, KSh, acc);
+#pragma unroll
+                    for (int i = 0; i < AF_NA; i++) {
+                        if (i >= na) break;
+                        const int lb = lb0 + AF_MW * i;
 #pragma unroll
                         for (int v = 0; v < 4; v++) {
                             const int row = lb * 16 + (lane >> 4) + 4 * v;
                             if (!on || row0 + row >= a.n) continue;
                             const double zold = Zs[row * 16 + col];
-                            double s = half ? acc1[v] : acc0[v];
+                            double s = acc[i][v];
                             s += dm * zold;                                      // S = m z + W d  (reduced basis)
                             if (!ph2) {
                                 Zs[row * 16 + col] = s / dm;                     // qcqp.py:205
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
                     __syncthreads();
                     if (tid < 16) {
                         double d2 = 0.0, f = 0.0;
-                        for (int w = 0; w < 8; w++) { d2 += S.red[w][0][tid]; f += S.red[w][1][tid]; }
+                        for (int w = 0; w < AF_MW; w++) { d2 += S.red[w][0][tid]; f += S.red[w][1][tid]; }
                         S.pd2[tid] = d2; S.pf0[tid] = f;
                     }
                 }
@@ -329,20 +350,25 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
             }
             AF_TICK(0)
             // ---- partial ZQ = W[rows, :]^T z[rows] -> this member's slot (hat blocks dealt to the waves, two at a time)
-            for (int mb0 = wave; mb0 < MBh; mb0 += 16) {
-                const int mb1 = mb0 + 8;
-                const bool two = mb1 < MBh;
-                af_gcd *A0 = WT + ((int64_t)mb0 * KSn + 4 * b_lo) * 64 + lane;
-                af_gcd *A1 = WT + ((int64_t)(two ? mb1 : mb0) * KSn + 4 * b_lo) * 64 + lane;
-                af_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                if (two) af_stream<true>(A0, A1, Zs + lane, 4 * NBl, acc0, acc1);
-                else af_stream<false>(A0, A1, Zs + lane, 4 * NBl, acc0, acc1);
+            for (int mb0 = wave; wave < AF_MW && mb0 < MBh; mb0 += AF_MW * AF_NA) {
+                int na = 0;
+                af_gcd *A[AF_NA];
+                af_v4d acc[AF_NA];
+#pragma unroll
+                for (int i = 0; i < AF_NA; i++) {
+                    const int mb = mb0 + AF_MW * i;
+                    if (mb < MBh) na = i + 1;
+                    A[i] = WT + ((int64_t)(mb < MBh ? mb : mb0) * KSn + 4 * b_lo) * 64 + lane;
+                    acc[i] = af_v4d{0.0, 0.0, 0.0, 0.0};
+                }
+                af_stream_n(na, A, Zs + lane, 4 * NBl, acc);
                 // accumulator layout: register v of lane l = row (l >> 4) + 4 v of the block, column l & 15
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int hr = (lane >> 4) + 4 * v, col = lane & 15;
-                    ag_store(xb1me + ((int64_t)(mb0 * 16 + hr)) * 16 + col, acc0[v]);
-                    if (two) ag_store(xb1me + ((int64_t)(mb1 * 16 + hr)) * 16 + col, acc1[v]);
+                for (int i = 0; i < AF_NA; i++) {
+                    if (i >= na) break;
+                    const int mb = mb0 + AF_MW * i;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) ag_store(xb1me + ((int64_t)(mb * 16 + (lane >> 4) + 4 * v)) * 16 + (lane & 15), acc[i][v]);
                 }
             }
             if (tid < 32) ag_store(xb1me + ((int64_t)a.Mh16 + (tid >> 4)) * 16 + (tid & 15), (tid >> 4) ? S.pf0[tid & 15] : S.pd2[tid & 15]);

@@ -16,6 +16,7 @@
 #include "kernels.hip"
 #include "admm.h"
 #include "admm_fused.h"
+#include "cd_queue.h"
 #include "gemm_pk.h"
 #include "cd_general.h"
 #include "cd_dense.h"
@@ -161,6 +162,8 @@ struct qcqpmi_ctx {
     const char *last_admm_kernel = "";    // "admm_fused_kernel" / "admm_multi_launch"
     int last_admm_C = 0;                  // workgroups per tile of the last fused run
     long long af_prof[16] = {0};          // stage cycle counters of the last fused run (when qcqpmi_debug_profile enabled them)
+    int cd_queue = 0;                     // qcqpmi_cd_queue: 1 = restart-level scheduling (cd_phase2_qs_kernel) where it applies
+    int *d_qnext = nullptr;               // its queue head
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
     std::vector<int> last_st1, last_st2;   // per-restart status codes of the last coordinate-descent run (qcqpmi_cd_status)
@@ -407,6 +410,33 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
         cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
         if (cs >= NBq) cs = 0;
         cs &= ~1;
+        if (c->cd_queue && !a1.prof && q_lds <= 160 * 1024 && NBq - cs <= RQ_NSIMD * RQ_MAXU && NBq >= 3 && cd_queue_lds_bytes(dp) != 0 &&
+            c->R < (1LL << 30)) {
+            // restart-level scheduling (cd_queue.h): 16 slots per workgroup, refilled from a device-side queue
+            used_lds = true;
+            if (!c->d_qnext) { int rcq = dev_alloc(c, &c->d_qnext, 4); if (rcq) return rcq; }
+            HIPCHK(c, hipMemsetAsync(c->d_qnext, 0, 4 * sizeof(int), c->stream));
+            HIPCHK(c, hipMemsetAsync(a1.visits, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(a1.accepted, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(a1.sweeps, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(a1.status, 0, (size_t)c->Rpad * sizeof(int), c->stream));
+            CdQueueArgs qa;
+            qa.P = dp; qa.nb = 1; qa.num_iters = a1.num_iters; qa.tol = a1.tol;
+            CdBatch &B = qa.b[0];
+            B.X = a1.X; B.f0cur = a1.f0cur; B.slack = a1.slack; B.flag = a1.flag; B.visits = a1.visits; B.accepted = a1.accepted;
+            B.sweeps = a1.sweeps; B.status = a1.status; B.f0out = a1.f0out; B.mvout = a1.mvout; B.R = a1.R; B.seed = a1.seed;
+            B.first_index = a1.first_index; B.next = c->d_qnext; B.ready = nullptr;
+            qa.b[1] = B; qa.b[1].R = 0;
+            int cus = 0;
+            HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            tic(c, 2);
+            hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, c->stream);
+            toc(c, 2);
+            if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_queue_launch: %s", hipGetErrorString(qe));
+            c->last_cd2_kernel = "cd_phase2_qs_kernel";
+            if (used_rs) *used_rs = true;
+            return 0;
+        }
         if (q_lds <= 160 * 1024 && NBq - cs <= RQ_NSIMD * RQ_MAXU && NBq >= 3) {
             used_lds = true;
             const bool prof_ = a1.prof != nullptr;
@@ -605,7 +635,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext};
     if (c->h_out) (void)hipHostFree(c->h_out);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
@@ -1315,6 +1345,12 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 }
 
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
+
+int qcqpmi_cd_queue(qcqpmi_ctx *c, int mode) {
+    if (!c || mode < 0 || mode > 1) return QCQPMI_EINVAL;
+    c->cd_queue = mode;
+    return 0;
+}
 
 int qcqpmi_cd_reference_order(qcqpmi_ctx *c, int enable) {
     if (!c) return QCQPMI_EINVAL;

@@ -138,11 +138,39 @@ __global__ __launch_bounds__(256) void cd_general_kernel(CdGenArgs ga) {
     int *lcnt = (int *)sp; sp += 16 * GEN_CAP;   // 2 * 16 * CAP ints
     int *ctrl = (int *)sp;                        // [0] live restarts, [1] any restart wants this sweep
 
-    for (int k = slot; k <= m; k += 16) Fk[k * 16 + r] = (gr < a.R) ? ga.F[(int64_t)k * ga.Rpad + gr] : 0.0;
+    // f_k(x) of every function in the reference's own summation order, (P.dot(x) + q).dot(x) + r (utilities.py:49-50): rows and
+    // columns in index order -- bit-identical to the reference / oracle.  Used in the reference-order mode wherever the
+    // reference evaluates afresh: the violations after a phase-1 sweep (qcqp.py:142) and the slack of phase 2 (qcqp.py:157).
+    auto fresh_F = [&]() {
+        for (int k = slot; k <= m; k += 16) {
+            const double *Pk = (k == 0) ? P.P0 : (ga.gP + (int64_t)(k - 1) * n * n);
+            const int64_t ld = (k == 0) ? n16 : n;
+            const double *qv = (k == 0) ? P.q0 : (P.gq + (int64_t)(k - 1) * n16);
+            double acc = 0.0;
+            for (int64_t i2 = 0; i2 < n; i2++) {
+                double rw = 0.0;
+                for (int64_t j = 0; j < n; j++) rw += Pk[i2 * ld + j] * X[j * 16 + r];
+                acc += (rw + qv[i2]) * X[i2 * 16 + r];
+            }
+            Fk[k * 16 + r] = acc + ((k == 0) ? P.r0 : P.gr[k - 1]);
+        }
+    };
+    if (ga.exact_t0) fresh_F();
+    else for (int k = slot; k <= m; k += 16) Fk[k * 16 + r] = (gr < a.R) ? ga.F[(int64_t)k * ga.Rpad + gr] : 0.0;
+    __syncthreads();
     // per-restart state, held by the slot-0 thread of the restart
     const bool owner = slot == 0;
     bool live = owner && gr < a.R && (PHASE == 1 || a.flag[gr]);
-    const double slack = (PHASE == 2 && owner && gr < a.R) ? a.slack[gr] : 0.0;
+    double slack = (PHASE == 2 && owner && gr < a.R) ? a.slack[gr] : 0.0;
+    if (PHASE == 2 && owner && ga.exact_t0) {      // max(prob.violations(x)) afresh (qcqp.py:157), not the evaluation kernel's
+        double v = -QM_INF;
+        for (int k = 1; k <= m; k++) {
+            const double f = Fk[k * 16 + r];
+            const double w = (P.grel[k - 1] == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+            v = w > v ? w : v;
+        }
+        slack = v;
+    }
     int64_t upd_counter = 0, visits = 0, accepted = 0, sweeps = 0;
     double viol_last = QM_INF;
     int status = 0, overflow = 0;
@@ -257,8 +285,13 @@ __global__ __launch_bounds__(256) void cd_general_kernel(CdGenArgs ga) {
             }
             __syncthreads();
         }
+        if (PHASE == 1 && ga.exact_t0) {     // (uniform branch) the reference evaluates the violations afresh after the sweep
+            __syncthreads();
+            fresh_F();
+            __syncthreads();
+        }
         if (PHASE == 1 && owner && live) {
-            // viol = max(prob.violations(x)) (qcqp.py:142) from the tracked f_k
+            // viol = max(prob.violations(x)) (qcqp.py:142) from the tracked f_k (reference-order mode: evaluated afresh above)
             double v = -QM_INF;
             for (int k = 1; k <= m; k++) {
                 const double f = Fk[k * 16 + r];

@@ -1,0 +1,45 @@
+// Coordinate descent phase 2 (qcqp.py:152-178) with RESTART-LEVEL scheduling (round 3): interface between capi.hip and
+// cd_queue.hip (own translation unit).
+//
+// cd_phase2_q_kernel binds 16 restarts to a workgroup for the whole launch: the workgroup runs until its slowest restart
+// has converged (lanes of converged restarts keep multiplying), and the launch until the slowest workgroup has.  Here a
+// workgroup owns 16 SLOTS: a restart that has converged is written out at the next sweep boundary and its slot takes the
+// next restart from a device-side queue -- of this population or, once that one is exhausted, of the NEXT population
+// (the one a second context has prepared meanwhile: suggest, phase 1, evaluation, gate), so the matrix pipes keep
+// working on live columns across the step boundary.  Per restart the arithmetic is that of cd_phase2_q_kernel bit for bit
+// (a column's products depend on that column only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace qcqpmi {
+
+struct CdBatch {                 // one population = the restarts of one improve(COORD_DESCENT) call
+    double *X;                   // tile-major [tile][n16][16], in / out
+    const double *f0cur;         // [Rpad] objective at phase-2 start
+    const double *slack;         // [Rpad] max violation at phase-2 start (the fixed slack of phase 2, qcqp.py:157)
+    const uint8_t *flag;         // [Rpad] passed the gate of improve_coord_descent (qcqp.py:189)
+    int64_t *visits, *accepted, *sweeps;
+    int *status;
+    double *f0out, *mvout;       // tracked objective / max violation of the final point, written for the restarts that ran
+    int64_t R;
+    uint64_t seed, first_index;
+    int *next;                   // queue head: next restart index to hand out (zeroed before the population is offered)
+    const int *ready;            // nullptr: always; else the population may be consumed once *ready != 0
+};
+
+struct CdQueueArgs {
+    DevProblem P;
+    CdBatch b[2];                // b[0]: the population this launch belongs to; b[1]: the next one (pull-ahead), if nb == 2
+    int nb;
+    int64_t num_iters;
+    double tol;
+};
+
+// LDS bytes of the kernel for this problem (0: does not fit / not eligible)
+size_t cd_queue_lds_bytes(const DevProblem &P);
+// launches ceil(R0 / 16) workgroups at most `max_wgs`; cs = blocks of the contraction the chain wave multiplies (0, 2, 4, 6)
+int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st);
+
+}  // namespace qcqpmi

@@ -329,6 +329,11 @@ class Engine(object):
         """Name of the phase-2 kernel the most recent cd_run dispatched to (see qcqpmi_last_cd_kernel)."""
         return (self.L.qcqpmi_last_cd_kernel(self.h) or b'').decode()
 
+    def cd_queue(self, mode=1):
+        """Phase-2 scheduling of the Boolean family: 0 = tile-bound (cd_phase2_q_kernel), 1 = restart-level slots refilled from
+        a device-side queue (cd_phase2_qs_kernel)."""
+        self._chk(self.L.qcqpmi_cd_queue(self.h, int(mode)))
+
     def cd_reference_order(self, enable=True):
         """Coupled constraints: coordinate descent in the reference's summation order (slow, value-for-value comparable with
         the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""

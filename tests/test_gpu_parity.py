@@ -458,6 +458,8 @@ def test_cd_more_than_four_constraints_per_coordinate(eng_mod, orc, per_coord, n
             assert (out['maxviol'][r] < 1e-2) == (prob.max_violation(x) < 1e-2), r
     if n > 64:
         print('\n%d constraints per coordinate, n = %d through the dense path: %d of %d restarts on the oracle trajectory' % (per_coord, n, same, R))
+        if prob.m > 240:
+            return      # the reference-order kernel keeps a coefficient table of (m + 1) x 16 x 4 doubles in LDS: m <= 240
         e.cd_reference_order(True)
         e.upload(X0)
         e.cd_run(phase1=True, num_iters=iters, seed=seed, first_index=first)
