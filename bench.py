@@ -366,6 +366,9 @@ def main():
     ap.add_argument('--cpu-cores', type=int, default=0, help='host cores for the CPU baselines (0 = all usable, at most 32)')
     ap.add_argument('--no-overlap', dest='overlap', action='store_false',
                     help='one context only: every step runs strictly after the previous one')
+    ap.add_argument('--no-chain', dest='chain', action='store_false',
+                    help='two contexts, phase-2 launches never overlap (round-2 scheme) instead of three chained contexts')
+    ap.add_argument('--p2-cus', type=int, default=192, help='chained mode: CUs the phase-2 launches are confined to (0 = no partition)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the bounded records of the other BASELINE.json configs')
     args = ap.parse_args()
@@ -404,6 +407,39 @@ def main():
             if float(eng.comm_allreduce([ok], 'sum')[0]) < world:
                 eng2 = None
     engs = [eng, eng2] if eng2 is not None else [eng]
+    # Chained mode (default): THREE contexts in a ring.  Phase 2 runs through the slot-queue kernel (cd_phase2_qs_kernel): a
+    # workgroup owns 16 slots, a restart that is done is written out at the next sweep boundary and its slot takes the next
+    # restart of the population -- or, once that queue is empty, of the NEXT step's population, which the next context has
+    # prepared meanwhile (qcqpmi_cd_chain).  The launches of consecutive steps therefore overlap and the matrix pipes do not
+    # idle while the last restarts of a step converge.
+    chained = False
+    if args.chain and eng2 is not None:
+        try:
+            eng3 = Engine(form, device=local_rank)
+            dist.init_rccl(eng3, rank, world, bootstrap=boot)
+            ok = 1.0
+        except Exception as ex:
+            sys.stderr.write('bench: third context unavailable (%r): steps will not be chained\n' % (ex,))
+            eng3, ok = None, 0.0
+        if world > 1 and float(eng.comm_allreduce([ok], 'sum')[0]) < world:
+            eng3 = None
+        eng4 = None
+        if eng3 is not None:
+            try:
+                eng4 = Engine(form, device=local_rank)
+                dist.init_rccl(eng4, rank, world, bootstrap=boot)
+                ok = 1.0
+            except Exception as ex:
+                sys.stderr.write('bench: fourth context unavailable (%r): steps will not be chained\n' % (ex,))
+                eng4, ok = None, 0.0
+            if world > 1 and float(eng.comm_allreduce([ok], 'sum')[0]) < world:
+                eng4 = None
+        if eng4 is not None:
+            engs = [eng, eng2, eng3, eng4]
+            chained = True
+            for e_ in engs:
+                e_.cd_queue(1)
+                e_.cd_partition(args.p2_cus)
 
     def prepare(e, k):
         e.randn(R, seed=args.seed + k, first_index=first)
@@ -412,6 +448,28 @@ def main():
     def run_steps(count, base, record):
         """`count` steps; step k = suggest(RANDOM) + improve(COORD_DESCENT) + selection of the best point."""
         if count <= 0:
+            return
+        if chained:
+            NC = len(engs)      # 4: steps k (launched), k + 1 (prepared, being run ahead), k + 2 (in preparation), k - 1 (being fetched)
+
+            def finish(j):
+                e = engs[j % NC]
+                out = e.cd_fetch()          # waits for launch j and for launch j - 1 (which may have run restarts of step j)
+                record(j, e, out, e.comm_select_best(1e-4, index_offset=first))
+            prepare(engs[0], base)
+            if count > 1:
+                prepare(engs[1], base + 1)
+            for k in range(count):
+                cur, nxt = engs[k % NC], engs[(k + 1) % NC]
+                cur.cd_chain(nxt if k + 1 < count else None, R, args.seed + base + k + 1, first)
+                cur.cd_phase2()
+                if k + 2 < count:
+                    prepare(engs[(k + 2) % NC], base + k + 2)   # two steps ahead: ready before the launch of step k + 1 runs dry
+                if k >= 1:
+                    finish(k - 1)
+            finish(count - 1)
+            for e in engs:
+                e.cd_chain(None)
             return
         prepare(engs[0], base)
         engs[0].cd_phase2()
@@ -468,6 +526,9 @@ def main():
     if rank == 0:
         K = max(args.steps, 1)
         achieved = (p2_flops / 1e12) / (p2_ms / 1e3) if p2_ms > 0 else 0.0      # rank 0's GPU, its own launches
+        if chained:
+            # the launches of consecutive steps overlap: the busy time of the phase-2 kernels is the timed region itself
+            achieved = (p2_flops / 1e12) / dt
         pmc = profiled_counters()
         res = {
             'metric': 'restarts x coord-sweeps / sec (improve COORD_DESCENT, phase-2 coordinate sweeps of 2 n^2 flops; '
@@ -488,7 +549,11 @@ def main():
                                                                     'per GPU' if args.scaling == 'weak' else 'in total'),
                        'restarts_per_gpu': R, 'num_iters': 1000, 'viol_tol': 1e-2, 'tol': 1e-4,
                        'sharding': 'restarts by global index, replicas of P',
-                       'step_overlap': ('two contexts per GPU: suggest + phase 1 + evaluation + gate of step k+1 run in a second stream '
+                       'step_overlap': ('four chained contexts per GPU (populations prepared two steps ahead; phase-2 launches confined to %d CUs): the phase-2 launch of step k (slot-queue kernel: 16 restart slots '
+                                        'per workgroup) takes restarts of step k+1 -- prepared meanwhile in the next context: suggest, '
+                                        'phase 1, evaluation, gate -- once its own queue is empty; results per restart do not depend on '
+                                        'the scheduling' % (args.p2_cus or 256)) if chained else
+                                       ('two contexts per GPU: suggest + phase 1 + evaluation + gate of step k+1 run in a second stream '
                                         'while the phase-2 kernel of step k finishes; phase-2 kernels never overlap each other')
                                        if len(engs) > 1 else 'none (steps strictly one after the other)'},
             'phase2_sweeps_per_restart': sweeps2_all / (K * world * max(R, 1)),
@@ -509,7 +574,10 @@ def main():
                          'algorithmic_flops_per_restart_sweep': 2.0 * n * n,
                          'algorithmic_flops_per_launch': p2_flops / K,
                          'kernel_ms_per_launch': p2_ms / K,
-                         'timing': 'HIP events on the engine stream around every phase-2 launch of the timed steps'},
+                         'restarts_run_ahead_per_step': (sum(e_.cd_pulled() for e_ in engs) / float(args.steps + args.warmup)) if chained else None,
+                         'timing': ('chained launches overlap each other: flops of all timed steps / wall time of the timed region (%.4f s); '
+                                    'the sum of the HIP-event durations of the launches is %.1f ms per step' % (dt, p2_ms / K)) if chained
+                                   else 'HIP events on the engine stream around every phase-2 launch of the timed steps'},
         }
         if world > 1:
             res['roofline']['kernel_ms_per_launch_max_over_ranks'] = p2_ms_max / K

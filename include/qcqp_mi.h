@@ -242,7 +242,22 @@ const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *ctx);
  * restart that is done (qcqp.py:172-176, or num_iters sweeps) is written out at the next sweep boundary and its slot takes the
  * next restart from a device-side queue (cd_phase2_qs_kernel, csrc/cd_queue.hip).  Per restart the same arithmetic; results
  * do not depend on the scheduling (every product is summed in one association).  qcqpmi_last_cd_kernel names the kernel. */
-int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);
+int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);     /* 0 off, 1 on wherever it applies, 2 (default) auto: more tiles than CUs, or chained */
+/* Chain two contexts of the same problem on one GPU (the staged run above, bench.py): the phase-2 launch of `ctx` (stage 2) may
+ * also take restarts of the NEXT population of `next` -- the one `next` is preparing in its own stream meanwhile (stage 1:
+ * suggest, phase 1, evaluation, gate; the population is published to the running kernel when stage 1 has been enqueued and
+ * executed) -- once its own queue is empty, so that the matrix pipes do not idle while the last restarts of a population
+ * converge (4096 restarts are one tile per CU: a launch lasts as long as its slowest restart, the average one needs half).
+ * next_R / next_seed / next_first_index: size, seed and first global index `next` will pass to its stage 1 / 2 calls (they key
+ * the random draws of restarts that are run ahead).  Results of a population are complete when both its own launch and the
+ * launch that could pull from it are: stage 3 waits for both.  next = NULL removes the link. */
+int qcqpmi_cd_chain(qcqpmi_ctx *ctx, qcqpmi_ctx *next, int64_t next_R, uint64_t next_seed, uint64_t next_first_index);
+/* Confine the slot-queue launches of this context to `phase2_cus` compute units (a stream with a CU mask; 0 = whole chip):
+ * its workgroups are persistent and hold a CU each (LDS), so with chained contexts the kernels that prepare the next
+ * populations would otherwise find no free CU until workgroups run out of work. */
+int qcqpmi_cd_partition(qcqpmi_ctx *ctx, int phase2_cus);
+/* statistics: restarts of this context's populations that were run by the launches of the context chained to it (total) */
+int qcqpmi_debug_cd_pulled(qcqpmi_ctx *ctx, int64_t *out);
 /* Coordinate descent for constraints that couple coordinates IN THE REFERENCE'S SUMMATION ORDER (test / diagnostic mode, any
  * n): every one-variable coefficient (t2, t1, t0) of get_onevar_func (utilities.py:99-105) is formed by row-sequential sums
  * like the reference's CSR products -- t0 = f_k(z) afresh per coordinate, O((m+1) n^2) per coordinate visit -- so that

@@ -162,8 +162,19 @@ struct qcqpmi_ctx {
     const char *last_admm_kernel = "";    // "admm_fused_kernel" / "admm_multi_launch"
     int last_admm_C = 0;                  // workgroups per tile of the last fused run
     long long af_prof[16] = {0};          // stage cycle counters of the last fused run (when qcqpmi_debug_profile enabled them)
-    int cd_queue = 0;                     // qcqpmi_cd_queue: 1 = restart-level scheduling (cd_phase2_qs_kernel) where it applies
-    int *d_qnext = nullptr;               // its queue head
+    int cd_queue = 2;                     // qcqpmi_cd_queue: 0 off, 1 restart-level scheduling (cd_phase2_qs_kernel) wherever it applies,
+                                          // 2 auto: when there are more tiles than CUs, or the context is chained to another one
+    int *d_qnext = nullptr;               // [0] queue head, [1] generation of the population that is ready to be consumed
+    int qgen = 0;                         // generation of the resident population (stage 1 of a run publishes it)
+    qcqpmi_ctx *chain_next = nullptr;     // qcqpmi_cd_chain: the phase-2 launch of this context may pull restarts of that context's NEXT population
+    qcqpmi_ctx *chained_by = nullptr;     // ... and the context whose launch may have pulled from this one's population
+    hipEvent_t ev_p2 = nullptr;           // recorded after this context's phase-2 launch
+    bool q_prepared = false;              // the queue of the resident population has been reset and published
+    int p2_cus = 0;                       // qcqpmi_cd_partition: CUs the slot-queue launches are confined to (0: no partition)
+    hipStream_t stream_p2 = nullptr;      // ... the stream with that CU mask
+    hipEvent_t ev_prep = nullptr;         // "everything phase 2 needs has been enqueued on the main stream"
+    uint64_t chain_seed = 0, chain_first = 0;   // seed / first index / size of the chained context's next population (qcqpmi_cd_chain)
+    int64_t chain_R = 0;
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
     std::vector<int> last_st1, last_st2;   // per-restart status codes of the last coordinate-descent run (qcqpmi_cd_status)
@@ -227,6 +238,8 @@ int pop_reserve(qcqpmi_ctx *c, int64_t R) {
     int64_t Rpad = (R + 15) / 16 * 16;
     if (Rpad > c->Rcap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->chained_by && c->chained_by->ev_p2) HIPCHK(c, hipEventSynchronize(c->chained_by->ev_p2));   // a launch may hold these buffers
+        c->qgen += 2;      // ... and no launch that expected the next generation in the old buffers will ever see it published
         free_population(c);
         int rc = 0;
         size_t xe = (size_t)Rpad * (size_t)c->n16;
@@ -386,6 +399,45 @@ int launch_eval(qcqpmi_ctx *c, bool want_F) {
     return 0;
 }
 
+__global__ void cd_queue_publish_kernel(int *q, int gen) { q[0] = 0; __hip_atomic_store(q + 1, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// does phase 2 of the resident population go through the slot-queue kernel?
+bool cd_queue_eligible(qcqpmi_ctx *c, bool profiling) {      // the problem's shape and the context's switches allow the kernel
+    if (profiling || c->force_generic || (c->dbg & 64) || !c->sep || c->maxc > 1 || c->cd_queue == 0) return false;
+    if (!(c->K == 1 && c->objclass == 1 && c->symcls && c->n % 16 == 0)) return false;
+    return cd_queue_lds_bytes(c->dp) != 0 && c->R < (1LL << 30);
+}
+
+bool cd_queue_applies(qcqpmi_ctx *c, bool profiling) {
+    if (!cd_queue_eligible(c, profiling)) return false;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) return false;
+    if (c->cd_queue == 1) return true;
+    if (c->cd_queue == 2) return c->Rpad / 16 > cus || c->chain_next != nullptr || c->chained_by != nullptr;
+    return false;
+}
+
+// reset the queue of the resident population and the per-restart outputs the kernel only writes for the restarts it runs,
+// then publish the population (generation number) to whoever may pull from it
+int cd_queue_prepare(qcqpmi_ctx *c) {
+    if (!c->d_qnext) { int rcq = dev_alloc(c, &c->d_qnext, 4); if (rcq) return rcq; }
+    HIPCHK(c, hipMemsetAsync(c->d_visits, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_sweeps, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, (size_t)c->Rpad * sizeof(int), c->stream));
+    c->qgen++;
+    hipLaunchKernelGGL(cd_queue_publish_kernel, dim3(1), dim3(1), 0, c->stream, c->d_qnext, c->qgen);
+    HIPCHK(c, hipGetLastError());
+    c->q_prepared = true;
+    return 0;
+}
+
+void cd_queue_fill_batch(qcqpmi_ctx *c, CdBatch &B, uint64_t seed, uint64_t first_index) {
+    B.X = c->X; B.f0cur = c->d_f0; B.slack = c->d_mv; B.flag = c->d_flag; B.visits = c->d_visits; B.accepted = c->d_acc;
+    B.sweeps = c->d_sweeps; B.status = c->d_status; B.f0out = c->d_f0; B.mvout = c->d_mv; B.R = c->R; B.seed = seed;
+    B.first_index = first_index; B.next = c->d_qnext; B.ready = nullptr; B.ready_gen = 0;
+}
+
 template <int MAXC>
 int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool *used_rs = nullptr) {
     if (used_rs) *used_rs = false;
@@ -410,29 +462,50 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
         cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
         if (cs >= NBq) cs = 0;
         cs &= ~1;
-        if (c->cd_queue && !a1.prof && q_lds <= 160 * 1024 && NBq - cs <= RQ_NSIMD * RQ_MAXU && NBq >= 3 && cd_queue_lds_bytes(dp) != 0 &&
-            c->R < (1LL << 30)) {
-            // restart-level scheduling (cd_queue.h): 16 slots per workgroup, refilled from a device-side queue
+        if (cd_queue_applies(c, a1.prof != nullptr) && NBq - cs <= RQ_NSIMD * RQ_MAXU && NBq >= 3) {
+            // restart-level scheduling (cd_queue.h): 16 slots per workgroup, refilled from a device-side queue -- of this
+            // population and, when the context is chained, of the next population of the other context once that is ready
             used_lds = true;
-            if (!c->d_qnext) { int rcq = dev_alloc(c, &c->d_qnext, 4); if (rcq) return rcq; }
-            HIPCHK(c, hipMemsetAsync(c->d_qnext, 0, 4 * sizeof(int), c->stream));
-            HIPCHK(c, hipMemsetAsync(a1.visits, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
-            HIPCHK(c, hipMemsetAsync(a1.accepted, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
-            HIPCHK(c, hipMemsetAsync(a1.sweeps, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
-            HIPCHK(c, hipMemsetAsync(a1.status, 0, (size_t)c->Rpad * sizeof(int), c->stream));
+            int rcq;
+            if (!c->q_prepared && (rcq = cd_queue_prepare(c))) return rcq;
+            c->q_prepared = false;
             CdQueueArgs qa;
             qa.P = dp; qa.nb = 1; qa.num_iters = a1.num_iters; qa.tol = a1.tol;
-            CdBatch &B = qa.b[0];
-            B.X = a1.X; B.f0cur = a1.f0cur; B.slack = a1.slack; B.flag = a1.flag; B.visits = a1.visits; B.accepted = a1.accepted;
-            B.sweeps = a1.sweeps; B.status = a1.status; B.f0out = a1.f0out; B.mvout = a1.mvout; B.R = a1.R; B.seed = a1.seed;
-            B.first_index = a1.first_index; B.next = c->d_qnext; B.ready = nullptr;
-            qa.b[1] = B; qa.b[1].R = 0;
+            cd_queue_fill_batch(c, qa.b[0], a1.seed, a1.first_index);
+            qa.b[1] = qa.b[0]; qa.b[1].R = 0;
+            qcqpmi_ctx *nx = c->chain_next;
+            if (nx && nx->finalized && nx->X && nx->n == c->n && nx->device == c->device && nx->R > 0 && cd_queue_eligible(nx, nx->profile) &&
+                ((c->chain_R > 0 ? c->chain_R : nx->R) + 15) / 16 * 16 <= nx->Rcap) {
+                if (!nx->d_qnext) { hipStream_t keep = nx->stream; (void)keep; if ((rcq = dev_alloc(nx, &nx->d_qnext, 4))) return fail(c, rcq, "cd chain: %s", nx->err.c_str()); HIPCHK(c, hipStreamSynchronize(nx->stream)); }
+                // the NEXT population of that context: same buffers (a context keeps them), seed / first index as the caller
+                // announced them with qcqpmi_cd_chain, generation = the one its next stage 1 will publish
+                cd_queue_fill_batch(nx, qa.b[1], c->chain_seed, c->chain_first);
+                qa.b[1].R = c->chain_R > 0 ? c->chain_R : nx->R;
+                qa.b[1].ready = nx->d_qnext + 1;
+                qa.b[1].ready_gen = nx->q_prepared ? nx->qgen : nx->qgen + 1;     // already published (prepared ahead), or its next stage 1 will
+                qa.nb = 2;
+                nx->chained_by = c;
+            }
             int cus = 0;
             HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-            tic(c, 2);
-            hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, c->stream);
-            toc(c, 2);
+            if (!c->ev_p2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_p2, hipEventDisableTiming));
+            hipStream_t ls = c->stream;
+            if (c->p2_cus > 0 && c->stream_p2) {
+                // partitioned chip: the persistent workgroups of phase 2 stay on `p2_cus` CUs (stream with a CU mask), the
+                // other CUs are always free for the kernels that prepare the next populations (phase 1, evaluation, ...)
+                if (!c->ev_prep) HIPCHK(c, hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
+                HIPCHK(c, hipEventRecord(c->ev_prep, c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream_p2, c->ev_prep, 0));
+                ls = c->stream_p2;
+                cus = c->p2_cus;
+            }
+            (void)hipEventRecord(c->timers[2].beg, ls);
+            hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, ls);
+            (void)hipEventRecord(c->timers[2].end, ls);
+            c->timers[2].valid = true;
             if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_queue_launch: %s", hipGetErrorString(qe));
+            HIPCHK(c, hipEventRecord(c->ev_p2, ls));
+            if (ls != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_p2, 0));    // results are fetched on the main stream
             c->last_cd2_kernel = "cd_phase2_qs_kernel";
             if (used_rs) *used_rs = true;
             return 0;
@@ -631,6 +704,11 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->comm);
+    if (c->stream_p2) { (void)hipStreamSynchronize(c->stream_p2); (void)hipStreamDestroy(c->stream_p2); }
+    if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+    if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
+    if (c->chain_next && c->chain_next->chained_by == c) c->chain_next->chained_by = nullptr;
+    if (c->chained_by && c->chained_by->chain_next == c) c->chained_by->chain_next = nullptr;
     free_population(c);
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
@@ -1273,6 +1351,8 @@ int qcqpmi_cd_run_stage(qcqpmi_ctx *c, int stage, int phase1, int64_t num_iters,
         hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((c->Rpad + 255) / 256)), dim3(256), 0, c->stream, c->d_mv,
                            c->d_status1, c->d_flag, c->R, c->Rpad, viol_tol);
         HIPCHK(c, hipGetLastError());
+        c->q_prepared = false;
+        if (cd_queue_applies(c, c->profile) && (rc = cd_queue_prepare(c))) return rc;     // queue reset + population published
         if (stage == 1) { c->cd_stage = 1; return 0; }
     }
     if (stage == 0 || stage == 2) {
@@ -1292,9 +1372,22 @@ int qcqpmi_cd_run_stage(qcqpmi_ctx *c, int stage, int phase1, int64_t num_iters,
         if (stage == 2) { c->cd_stage = 2; return 0; }
     }
     c->cd_stage = 0;
+    if (c->chained_by && c->chained_by->ev_p2) {
+        // the other context's launch may have run restarts of this population: its results are complete only when that
+        // kernel is (its stores are visible once its completion has been observed)
+        HIPCHK(c, hipEventSynchronize(c->chained_by->ev_p2));
+    }
     std::vector<int> st, st1;
     if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
     if ((rc = cd_apply_status(c, st, st1, f0, maxviol, 0))) return rc;
+    return 0;
+}
+
+int qcqpmi_cd_chain(qcqpmi_ctx *c, qcqpmi_ctx *next, int64_t next_R, uint64_t next_seed, uint64_t next_first_index) {
+    if (!c) return QCQPMI_EINVAL;
+    if (c->chain_next && c->chain_next->chained_by == c && c->chain_next != next) c->chain_next->chained_by = nullptr;
+    c->chain_next = next;
+    c->chain_R = next_R; c->chain_seed = next_seed; c->chain_first = next_first_index;
     return 0;
 }
 
@@ -1346,8 +1439,35 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
 
+int qcqpmi_debug_cd_pulled(qcqpmi_ctx *c, int64_t *out) {
+    if (!c || !out) return QCQPMI_EINVAL;
+    *out = 0;
+    if (!c->d_qnext) return 0;
+    int v = 0;
+    HIPCHK(c, hipMemcpy(&v, c->d_qnext + 2, sizeof(int), hipMemcpyDeviceToHost));
+    *out = v;
+    return 0;
+}
+
+int qcqpmi_cd_partition(qcqpmi_ctx *c, int phase2_cus) {
+    if (!c) return QCQPMI_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    int cus = 0;
+    HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    if (phase2_cus < 0 || phase2_cus > cus) return fail(c, QCQPMI_EINVAL, "cd_partition: %d CUs of %d", phase2_cus, cus);
+    if (c->stream_p2) { HIPCHK(c, hipStreamSynchronize(c->stream_p2)); (void)hipStreamDestroy(c->stream_p2); c->stream_p2 = nullptr; }
+    c->p2_cus = 0;
+    if (phase2_cus == 0 || phase2_cus == cus) return 0;
+    // the bits of the mask are dealt round-robin to the XCDs (measured: tools/ubench/cumask.hip): the first k bits = k / 8 CUs of each
+    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+    for (int i = 0; i < phase2_cus; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+    HIPCHK(c, hipExtStreamCreateWithCUMask(&c->stream_p2, (uint32_t)mask.size(), mask.data()));
+    c->p2_cus = phase2_cus;
+    return 0;
+}
+
 int qcqpmi_cd_queue(qcqpmi_ctx *c, int mode) {
-    if (!c || mode < 0 || mode > 1) return QCQPMI_EINVAL;
+    if (!c || mode < 0 || mode > 2) return QCQPMI_EINVAL;
     c->cd_queue = mode;
     return 0;
 }

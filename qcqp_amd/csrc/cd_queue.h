@@ -26,7 +26,8 @@ struct CdBatch {                 // one population = the restarts of one improve
     int64_t R;
     uint64_t seed, first_index;
     int *next;                   // queue head: next restart index to hand out (zeroed before the population is offered)
-    const int *ready;            // nullptr: always; else the population may be consumed once *ready != 0
+    const int *ready;            // nullptr: always; else the population may be consumed once *ready == ready_gen
+    int ready_gen;               // generation number the owner of that population publishes when it has prepared it
 };
 
 struct CdQueueArgs {

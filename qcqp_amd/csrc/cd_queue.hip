@@ -102,12 +102,15 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             if (id < 0) {
                 for (int q = 0; q < a.nb && id < 0; q++) {
                     const CdBatch &B = q ? a.b[1] : a.b[0];
-                    if (q == 1 && B.ready && qs_load_int(B.ready) == 0) break;
+                    if (q == 1 && B.ready && qs_load_int(B.ready) != B.ready_gen) break;
                     for (;;) {
-                        if (qs_load_int(B.next) >= (int)B.R) break;          // (saves the atomic once the queue is empty)
-                        const int idx = atomicAdd(B.next, 1);
+                        const int idx = atomicAdd(B.next, 1);      // (runs past R by at most 16 per workgroup and episode: harmless)
                         if (idx >= (int)B.R) break;
-                        if (__hip_atomic_load(B.flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { id = idx; bt = q; nw = 1; break; }
+                        if (__hip_atomic_load(B.flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            id = idx; bt = q; nw = 1;
+                            if (q == 1) atomicAdd(B.next + 2, 1);      // statistics: restarts of the next population run ahead by this launch
+                            break;
+                        }
                     }
                 }
             }
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                     if (finm == ~0ull) break;
                     if (finm != 0ull) {
                         bool more = __hip_atomic_load(a.b[0].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)a.b[0].R;
-                        if (!more && a.nb > 1 && (!a.b[1].ready || __hip_atomic_load(a.b[1].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+                        if (!more && a.nb > 1 && (!a.b[1].ready || __hip_atomic_load(a.b[1].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.b[1].ready_gen))
                             more = __hip_atomic_load(a.b[1].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)a.b[1].R;
                         if (more) break;
                     }

@@ -334,6 +334,21 @@ class Engine(object):
         a device-side queue (cd_phase2_qs_kernel)."""
         self._chk(self.L.qcqpmi_cd_queue(self.h, int(mode)))
 
+    def cd_pulled(self):
+        """Restarts of this engine's populations run ahead by the launches of the engine chained to it (running total)."""
+        v = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.qcqpmi_debug_cd_pulled(self.h, _ip(v)))
+        return int(v[0])
+
+    def cd_partition(self, phase2_cus):
+        """Confine the slot-queue launches of this engine to `phase2_cus` CUs (0 = whole chip); see qcqpmi_cd_partition."""
+        self._chk(self.L.qcqpmi_cd_partition(self.h, int(phase2_cus)))
+
+    def cd_chain(self, nxt, next_R=0, next_seed=0, next_first_index=0):
+        """The phase-2 launch of this engine may run restarts of the NEXT population of engine `nxt` (same problem, same GPU) once
+        its own queue is empty (qcqpmi_cd_chain).  nxt=None removes the link."""
+        self._chk(self.L.qcqpmi_cd_chain(self.h, nxt.h if nxt is not None else None, int(next_R), int(next_seed), int(next_first_index)))
+
     def cd_reference_order(self, enable=True):
         """Coupled constraints: coordinate descent in the reference's summation order (slow, value-for-value comparable with
         the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""

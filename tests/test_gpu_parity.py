@@ -663,3 +663,98 @@ def test_dense_path_edge_shapes(eng_mod, orc, n, m, R, iters, p1):
         assert np.max(np.abs(X[:, r] - x)) < 1e-3, r             # O(tol) at most (threshold flips), usually 1e-12
         assert abs(prob.eval(0, X[:, r]) - out['f0'][r]) <= 1e-9 * (1 + abs(out['f0'][r]))
         assert abs(prob.max_violation(X[:, r]) - out['maxviol'][r]) < 1e-9
+
+
+# ------------------------------------------------------- restart-level scheduling of phase 2 (round 3)
+def test_cd_queue_kernel_vs_tile_bound(eng_mod, orc):
+    """cd_phase2_qs_kernel (16 slots per workgroup, refilled from a device-side queue at sweep boundaries) against the
+    tile-bound cd_phase2_q_kernel and the oracle: 2000 restarts of Boolean least squares n = 256 (125 tiles -> with the
+    queue forced on, 125 workgroups that each see several refills... and a second run on 40 workgroups' worth of
+    restarts so that every slot is refilled many times is covered by R = 2000 / few CUs not being controllable here; the
+    bench covers many generations).  Asserted: same points (1e-12; in practice bit-identical), identical visit / accept /
+    sweep counters, tracked objective to 1e-12; a repeat is bit-identical (results do not depend on the scheduling); a
+    slice of the restarts run alone with its global index offset is bit-identical (sharding invariance); three restarts
+    follow the oracle trajectory."""
+    from qcqp_amd import problems
+    n, R, seed = 256, 2000, 77
+    funcs, _, _ = problems.boolean_least_squares(n, 64, seed=4)
+    e = make(eng_mod, funcs)
+    res = []
+    for mode in (0, 1, 1):
+        e.cd_queue(mode)
+        e.randn(R, seed=seed)
+        X0 = e.download()
+        out = e.cd_run(seed=seed)
+        assert e.last_cd_kernel() == ('cd_phase2_qs_kernel' if mode else 'cd_phase2_q_kernel')
+        res.append((e.download(), out))
+    (Xt, ot), (Xq, oq), (Xq2, oq2) = res
+    assert np.array_equal(Xq, Xq2) and np.array_equal(oq['f0'], oq2['f0']) and np.array_equal(oq['maxviol'], oq2['maxviol'])
+    assert rel(Xq, Xt) < 1e-12
+    for key in ('sweeps1', 'sweeps2', 'visits2', 'accepted2', 'ran_phase2', 'status1', 'status2'):
+        assert np.array_equal(oq[key], ot[key]), key
+    assert rel(oq['f0'], ot['f0']) < 1e-12 and np.array_equal(oq['maxviol'], ot['maxviol'])
+    f0, mv = e.eval()
+    assert rel(oq['f0'], f0) < 1e-11 and np.array_equal(mv, oq['maxviol'])
+    # sharding invariance in queue mode
+    e.randn(512, seed=seed, first_index=512)
+    o2 = e.cd_run(seed=seed, first_index=512)
+    assert e.last_cd_kernel() == 'cd_phase2_qs_kernel'
+    assert np.array_equal(e.download(), Xq[:, 512:1024]) and np.array_equal(o2['f0'], oq['f0'][512:1024])
+    # oracle trajectories
+    prob = orc.Problem(funcs)
+    for r in (0, 777, R - 1):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], rng=rng)
+        assert rel(Xq[:, r], x) < 1e-9, r
+        assert oq['visits2'][r] == s2[1] and oq['accepted2'][r] == s2[2]
+
+
+def test_cd_chained_contexts_match_serial_runs(eng_mod):
+    """qcqpmi_cd_chain: three contexts in a ring, the phase-2 launch of step k may run restarts of step k + 1 (prepared
+    meanwhile in the next context) once its own queue is empty -- the way bench.py runs its steps.  Every step's results
+    (points, counters, objective, max violation, best restart) must equal those of the same step run alone on a fresh
+    engine with the tile-bound kernel: per restart the scheduling changes nothing."""
+    from qcqp_amd import problems
+    n, R, steps, seed, first = 256, 700, 5, 31, 11
+    funcs, _, _ = problems.boolean_least_squares(n, 64, seed=2)
+    ref = []
+    e0 = make(eng_mod, funcs)
+    e0.cd_queue(0)
+    for k in range(steps):
+        e0.randn(R, seed=seed + k, first_index=first)
+        o = e0.cd_run(seed=seed + k, first_index=first)
+        ref.append((e0.download(), o, e0.select_best(1e-4)[:3]))
+    engs = [make(eng_mod, funcs) for _ in range(3)]
+    got = {}
+
+    def prepare(e, k):
+        e.randn(R, seed=seed + k, first_index=first)
+        e.cd_begin(phase1=True, seed=seed + k, first_index=first)
+
+    def finish(j):
+        e = engs[j % 3]
+        o = e.cd_fetch()
+        got[j] = (e.download(), o, e.select_best(1e-4)[:3], e.last_cd_kernel())
+    prepare(engs[0], 0)
+    for k in range(steps):
+        cur, nxt = engs[k % 3], engs[(k + 1) % 3]
+        more = k + 1 < steps
+        cur.cd_chain(nxt if more else None, R, seed + k + 1, first)
+        cur.cd_phase2()
+        if more:
+            prepare(nxt, k + 1)
+        if k >= 1:
+            finish(k - 1)
+    finish(steps - 1)
+    pulled = sum(e.cd_pulled() for e in engs)
+    print('\nchained contexts: %d restarts of %d were run ahead by the previous step\'s launch' % (pulled, steps * R))
+    for k in range(steps):
+        X, o, b, name = got[k]
+        rX, ro, rb = ref[k]
+        assert name == 'cd_phase2_qs_kernel', (k, name)
+        assert rel(X, rX) < 1e-12, k
+        for key in ('sweeps1', 'sweeps2', 'visits2', 'accepted2', 'ran_phase2', 'status1', 'status2'):
+            assert np.array_equal(o[key], ro[key]), (k, key)
+        assert rel(o['f0'], ro['f0']) < 1e-12 and np.array_equal(o['maxviol'], ro['maxviol']), k
+        assert b[0] == rb[0] and abs(b[1] - rb[1]) <= 1e-12 * (1 + abs(rb[1])), k
