@@ -366,9 +366,10 @@ def main():
     ap.add_argument('--cpu-cores', type=int, default=0, help='host cores for the CPU baselines (0 = all usable, at most 32)')
     ap.add_argument('--no-overlap', dest='overlap', action='store_false',
                     help='one context only: every step runs strictly after the previous one')
-    ap.add_argument('--no-chain', dest='chain', action='store_false',
-                    help='two contexts, phase-2 launches never overlap (round-2 scheme) instead of three chained contexts')
-    ap.add_argument('--p2-cus', type=int, default=192, help='chained mode: CUs the phase-2 launches are confined to (0 = no partition)')
+    ap.add_argument('--chain', dest='chain', action='store_true',
+                    help='experimental: ring of chained contexts, phase 2 through the slot-queue kernel, launches run restarts of the next '
+                         'populations (qcqpmi_cd_chain); default: two contexts, phase-2 launches never overlap (DESIGN.md section 4.1c)')
+    ap.add_argument('--p2-cus', type=int, default=0, help='chained mode: CUs the phase-2 launches are confined to (0 = no partition)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the bounded records of the other BASELINE.json configs')
     args = ap.parse_args()
@@ -413,29 +414,23 @@ def main():
     # prepared meanwhile (qcqpmi_cd_chain).  The launches of consecutive steps therefore overlap and the matrix pipes do not
     # idle while the last restarts of a step converge.
     chained = False
+    LA = 2          # a launch may run restarts of the next LA populations
+    DL = 2          # results of step k are fetched DL steps after its launch (its launch ends when population k + LA is exhausted)
     if args.chain and eng2 is not None:
+        ring = [eng, eng2]
         try:
-            eng3 = Engine(form, device=local_rank)
-            dist.init_rccl(eng3, rank, world, bootstrap=boot)
+            while len(ring) < LA + DL + 2:
+                ex_ = Engine(form, device=local_rank)
+                dist.init_rccl(ex_, rank, world, bootstrap=boot)
+                ring.append(ex_)
             ok = 1.0
         except Exception as ex:
-            sys.stderr.write('bench: third context unavailable (%r): steps will not be chained\n' % (ex,))
-            eng3, ok = None, 0.0
+            sys.stderr.write('bench: contexts for the chained mode unavailable (%r): steps will not be chained\n' % (ex,))
+            ok = 0.0
         if world > 1 and float(eng.comm_allreduce([ok], 'sum')[0]) < world:
-            eng3 = None
-        eng4 = None
-        if eng3 is not None:
-            try:
-                eng4 = Engine(form, device=local_rank)
-                dist.init_rccl(eng4, rank, world, bootstrap=boot)
-                ok = 1.0
-            except Exception as ex:
-                sys.stderr.write('bench: fourth context unavailable (%r): steps will not be chained\n' % (ex,))
-                eng4, ok = None, 0.0
-            if world > 1 and float(eng.comm_allreduce([ok], 'sum')[0]) < world:
-                eng4 = None
-        if eng4 is not None:
-            engs = [eng, eng2, eng3, eng4]
+            ok = 0.0
+        if ok:
+            engs = ring
             chained = True
             for e_ in engs:
                 e_.cd_queue(1)
@@ -450,26 +445,28 @@ def main():
         if count <= 0:
             return
         if chained:
-            NC = len(engs)      # 4: steps k (launched), k + 1 (prepared, being run ahead), k + 2 (in preparation), k - 1 (being fetched)
+            NC = len(engs)
 
             def finish(j):
                 e = engs[j % NC]
-                out = e.cd_fetch()          # waits for launch j and for launch j - 1 (which may have run restarts of step j)
+                out = e.cd_fetch()          # waits for launch j and for the launches j - LA .. j - 1 (they may have run restarts of step j)
                 record(j, e, out, e.comm_select_best(1e-4, index_offset=first))
-            prepare(engs[0], base)
-            if count > 1:
-                prepare(engs[1], base + 1)
+            for j in range(min(LA + 1, count)):
+                prepare(engs[j % NC], base + j)
             for k in range(count):
-                cur, nxt = engs[k % NC], engs[(k + 1) % NC]
-                cur.cd_chain(nxt if k + 1 < count else None, R, args.seed + base + k + 1, first)
+                cur = engs[k % NC]
+                for p_ in range(1, LA + 1):
+                    cur.cd_chain(engs[(k + p_) % NC] if k + p_ < count else None, R, args.seed + base + k + p_, first, pos=p_)
                 cur.cd_phase2()
-                if k + 2 < count:
-                    prepare(engs[(k + 2) % NC], base + k + 2)   # two steps ahead: ready before the launch of step k + 1 runs dry
-                if k >= 1:
-                    finish(k - 1)
-            finish(count - 1)
+                if k + LA + 1 < count:
+                    prepare(engs[(k + LA + 1) % NC], base + k + LA + 1)   # ready long before the launches reach it
+                if k >= DL:
+                    finish(k - DL)
+            for j in range(max(count - DL, 0), count):
+                finish(j)
             for e in engs:
-                e.cd_chain(None)
+                for p_ in range(1, 4):
+                    e.cd_chain(None, pos=p_)
             return
         prepare(engs[0], base)
         engs[0].cd_phase2()
@@ -549,10 +546,10 @@ def main():
                                                                     'per GPU' if args.scaling == 'weak' else 'in total'),
                        'restarts_per_gpu': R, 'num_iters': 1000, 'viol_tol': 1e-2, 'tol': 1e-4,
                        'sharding': 'restarts by global index, replicas of P',
-                       'step_overlap': ('four chained contexts per GPU (populations prepared two steps ahead; phase-2 launches confined to %d CUs): the phase-2 launch of step k (slot-queue kernel: 16 restart slots '
+                       'step_overlap': ('%d chained contexts per GPU (populations prepared %d steps ahead, a launch may run restarts of the next %d populations; phase-2 launches confined to %d CUs): the phase-2 launch of step k (slot-queue kernel: 16 restart slots '
                                         'per workgroup) takes restarts of step k+1 -- prepared meanwhile in the next context: suggest, '
                                         'phase 1, evaluation, gate -- once its own queue is empty; results per restart do not depend on '
-                                        'the scheduling' % (args.p2_cus or 256)) if chained else
+                                        'the scheduling' % (len(engs), LA + 1, LA, args.p2_cus or 256)) if chained else
                                        ('two contexts per GPU: suggest + phase 1 + evaluation + gate of step k+1 run in a second stream '
                                         'while the phase-2 kernel of step k finishes; phase-2 kernels never overlap each other')
                                        if len(engs) > 1 else 'none (steps strictly one after the other)'},

@@ -243,15 +243,16 @@ const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *ctx);
  * next restart from a device-side queue (cd_phase2_qs_kernel, csrc/cd_queue.hip).  Per restart the same arithmetic; results
  * do not depend on the scheduling (every product is summed in one association).  qcqpmi_last_cd_kernel names the kernel. */
 int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);     /* 0 off, 1 on wherever it applies, 2 (default) auto: more tiles than CUs, or chained */
-/* Chain two contexts of the same problem on one GPU (the staged run above, bench.py): the phase-2 launch of `ctx` (stage 2) may
- * also take restarts of the NEXT population of `next` -- the one `next` is preparing in its own stream meanwhile (stage 1:
- * suggest, phase 1, evaluation, gate; the population is published to the running kernel when stage 1 has been enqueued and
- * executed) -- once its own queue is empty, so that the matrix pipes do not idle while the last restarts of a population
- * converge (4096 restarts are one tile per CU: a launch lasts as long as its slowest restart, the average one needs half).
- * next_R / next_seed / next_first_index: size, seed and first global index `next` will pass to its stage 1 / 2 calls (they key
- * the random draws of restarts that are run ahead).  Results of a population are complete when both its own launch and the
- * launch that could pull from it are: stage 3 waits for both.  next = NULL removes the link. */
-int qcqpmi_cd_chain(qcqpmi_ctx *ctx, qcqpmi_ctx *next, int64_t next_R, uint64_t next_seed, uint64_t next_first_index);
+/* Chain contexts of the same problem on one GPU (the staged run above, bench.py): the phase-2 launch of `ctx` (stage 2) may
+ * also run restarts of the NEXT populations of up to three other contexts -- pos = 1: the population that follows ctx's own,
+ * pos = 2: the one after that, pos = 3 -- which those contexts prepare in their own streams (stage 1: suggest, phase 1,
+ * evaluation, gate; a population is published to the running kernels when its stage 1 has executed), once the queues before
+ * them are empty: the matrix pipes do not idle while the last restarts of a population converge (4096 restarts are one tile
+ * per CU: a launch lasts as long as its slowest restart, the average one needs half).  next_R / next_seed /
+ * next_first_index: size, seed and first global index `next` passes to its stage 1 / 2 calls for that population (they key
+ * the random draws of restarts that are run ahead).  A population is complete when its own launch and the launches that
+ * could run its restarts are: stage 3 waits for all of them.  next = NULL ends the chain at pos. */
+int qcqpmi_cd_chain(qcqpmi_ctx *ctx, int pos, qcqpmi_ctx *next, int64_t next_R, uint64_t next_seed, uint64_t next_first_index);
 /* Confine the slot-queue launches of this context to `phase2_cus` compute units (a stream with a CU mask; 0 = whole chip):
  * its workgroups are persistent and hold a CU each (LDS), so with chained contexts the kernels that prepare the next
  * populations would otherwise find no free CU until workgroups run out of work. */

@@ -64,7 +64,7 @@ PROTOTYPES = [
     ('qcqpmi_cd_queue', C.c_int, [C.c_void_p, C.c_int]),
     ('qcqpmi_debug_cd_pulled', C.c_int, [C.c_void_p, c_ip]),
     ('qcqpmi_cd_partition', C.c_int, [C.c_void_p, C.c_int]),
-    ('qcqpmi_cd_chain', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]),
+    ('qcqpmi_cd_chain', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]),
     ('qcqpmi_sync', C.c_int, [C.c_void_p]),
     ('qcqpmi_debug_profile', C.c_int, [C.c_void_p, C.c_int, c_ip]),
     ('qcqpmi_debug_admm_profile', C.c_int, [C.c_void_p, c_ip]),

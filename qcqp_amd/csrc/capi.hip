@@ -166,15 +166,16 @@ struct qcqpmi_ctx {
                                           // 2 auto: when there are more tiles than CUs, or the context is chained to another one
     int *d_qnext = nullptr;               // [0] queue head, [1] generation of the population that is ready to be consumed
     int qgen = 0;                         // generation of the resident population (stage 1 of a run publishes it)
-    qcqpmi_ctx *chain_next = nullptr;     // qcqpmi_cd_chain: the phase-2 launch of this context may pull restarts of that context's NEXT population
-    qcqpmi_ctx *chained_by = nullptr;     // ... and the context whose launch may have pulled from this one's population
+    qcqpmi_ctx *chain_nx[3] = {nullptr, nullptr, nullptr};   // qcqpmi_cd_chain: the phase-2 launch of this context may run restarts of the NEXT
+                                          // populations of these contexts (in this order) once its own queue is empty
+    qcqpmi_ctx *chained_by[3] = {nullptr, nullptr, nullptr}; // ... and the contexts whose launches may have run restarts of this one's population
     hipEvent_t ev_p2 = nullptr;           // recorded after this context's phase-2 launch
     bool q_prepared = false;              // the queue of the resident population has been reset and published
     int p2_cus = 0;                       // qcqpmi_cd_partition: CUs the slot-queue launches are confined to (0: no partition)
     hipStream_t stream_p2 = nullptr;      // ... the stream with that CU mask
     hipEvent_t ev_prep = nullptr;         // "everything phase 2 needs has been enqueued on the main stream"
-    uint64_t chain_seed = 0, chain_first = 0;   // seed / first index / size of the chained context's next population (qcqpmi_cd_chain)
-    int64_t chain_R = 0;
+    uint64_t chain_seed[3] = {0, 0, 0}, chain_first[3] = {0, 0, 0};   // seed / first index / size of those populations (qcqpmi_cd_chain)
+    int64_t chain_R[3] = {0, 0, 0};
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
     std::vector<int> last_st1, last_st2;   // per-restart status codes of the last coordinate-descent run (qcqpmi_cd_status)
@@ -238,7 +239,7 @@ int pop_reserve(qcqpmi_ctx *c, int64_t R) {
     int64_t Rpad = (R + 15) / 16 * 16;
     if (Rpad > c->Rcap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->chained_by && c->chained_by->ev_p2) HIPCHK(c, hipEventSynchronize(c->chained_by->ev_p2));   // a launch may hold these buffers
+        for (qcqpmi_ctx *pb : c->chained_by) if (pb && pb->ev_p2) HIPCHK(c, hipEventSynchronize(pb->ev_p2));   // a launch may hold these buffers
         c->qgen += 2;      // ... and no launch that expected the next generation in the old buffers will ever see it published
         free_population(c);
         int rc = 0;
@@ -413,7 +414,7 @@ bool cd_queue_applies(qcqpmi_ctx *c, bool profiling) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) return false;
     if (c->cd_queue == 1) return true;
-    if (c->cd_queue == 2) return c->Rpad / 16 > cus || c->chain_next != nullptr || c->chained_by != nullptr;
+    if (c->cd_queue == 2) return c->Rpad / 16 > cus || c->chain_nx[0] != nullptr || c->chained_by[0] != nullptr || c->chained_by[1] != nullptr || c->chained_by[2] != nullptr;
     return false;
 }
 
@@ -472,19 +473,28 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
             CdQueueArgs qa;
             qa.P = dp; qa.nb = 1; qa.num_iters = a1.num_iters; qa.tol = a1.tol;
             cd_queue_fill_batch(c, qa.b[0], a1.seed, a1.first_index);
-            qa.b[1] = qa.b[0]; qa.b[1].R = 0;
-            qcqpmi_ctx *nx = c->chain_next;
-            if (nx && nx->finalized && nx->X && nx->n == c->n && nx->device == c->device && nx->R > 0 && cd_queue_eligible(nx, nx->profile) &&
-                ((c->chain_R > 0 ? c->chain_R : nx->R) + 15) / 16 * 16 <= nx->Rcap) {
-                if (!nx->d_qnext) { hipStream_t keep = nx->stream; (void)keep; if ((rcq = dev_alloc(nx, &nx->d_qnext, 4))) return fail(c, rcq, "cd chain: %s", nx->err.c_str()); HIPCHK(c, hipStreamSynchronize(nx->stream)); }
+            for (int q = 1; q < CDQ_MAXB; q++) { qa.b[q] = qa.b[0]; qa.b[q].R = 0; }
+            for (int q = 0; q < 3; q++) {
+                qcqpmi_ctx *nx = c->chain_nx[q];
+                const int64_t nR = nx ? (c->chain_R[q] > 0 ? c->chain_R[q] : nx->R) : 0;
+                if (!(nx && nx != c && nx->finalized && nx->X && nx->n == c->n && nx->device == c->device && nx->R > 0 &&
+                      cd_queue_eligible(nx, nx->profile) && (nR + 15) / 16 * 16 <= nx->Rcap)) break;     // the chain ends at the first gap
+                if (!nx->d_qnext) { if ((rcq = dev_alloc(nx, &nx->d_qnext, 4))) return fail(c, rcq, "cd chain: %s", nx->err.c_str()); HIPCHK(c, hipStreamSynchronize(nx->stream)); }
                 // the NEXT population of that context: same buffers (a context keeps them), seed / first index as the caller
-                // announced them with qcqpmi_cd_chain, generation = the one its next stage 1 will publish
-                cd_queue_fill_batch(nx, qa.b[1], c->chain_seed, c->chain_first);
-                qa.b[1].R = c->chain_R > 0 ? c->chain_R : nx->R;
-                qa.b[1].ready = nx->d_qnext + 1;
-                qa.b[1].ready_gen = nx->q_prepared ? nx->qgen : nx->qgen + 1;     // already published (prepared ahead), or its next stage 1 will
-                qa.nb = 2;
-                nx->chained_by = c;
+                // announced them with qcqpmi_cd_chain, generation = the one it has published already (prepared ahead) or the one
+                // its next stage 1 will publish
+                CdBatch &B = qa.b[q + 1];
+                cd_queue_fill_batch(nx, B, c->chain_seed[q], c->chain_first[q]);
+                B.R = nR;
+                B.ready = nx->d_qnext + 1;
+                B.ready_gen = nx->q_prepared ? nx->qgen : nx->qgen + 1;
+                qa.nb = q + 2;
+                bool known = false;
+                for (qcqpmi_ctx *pb : nx->chained_by) known = known || pb == c;
+                if (!known) {
+                    for (auto &pb : nx->chained_by) if (!pb) { pb = c; known = true; break; }
+                    if (!known) { qa.nb = q + 1; break; }      // more than three launches would have to be waited for: not chained
+                }
             }
             int cus = 0;
             HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -707,8 +717,8 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     if (c->stream_p2) { (void)hipStreamSynchronize(c->stream_p2); (void)hipStreamDestroy(c->stream_p2); }
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
-    if (c->chain_next && c->chain_next->chained_by == c) c->chain_next->chained_by = nullptr;
-    if (c->chained_by && c->chained_by->chain_next == c) c->chained_by->chain_next = nullptr;
+    for (qcqpmi_ctx *nx : c->chain_nx) if (nx) for (auto &pb : nx->chained_by) if (pb == c) pb = nullptr;
+    for (qcqpmi_ctx *pb : c->chained_by) if (pb) for (auto &nx : pb->chain_nx) if (nx == c) nx = nullptr;
     free_population(c);
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
@@ -1372,10 +1382,10 @@ int qcqpmi_cd_run_stage(qcqpmi_ctx *c, int stage, int phase1, int64_t num_iters,
         if (stage == 2) { c->cd_stage = 2; return 0; }
     }
     c->cd_stage = 0;
-    if (c->chained_by && c->chained_by->ev_p2) {
-        // the other context's launch may have run restarts of this population: its results are complete only when that
+    for (qcqpmi_ctx *pb : c->chained_by) {
+        // another context's launch may have run restarts of this population: its results are complete only when that
         // kernel is (its stores are visible once its completion has been observed)
-        HIPCHK(c, hipEventSynchronize(c->chained_by->ev_p2));
+        if (pb && pb->ev_p2) HIPCHK(c, hipEventSynchronize(pb->ev_p2));
     }
     std::vector<int> st, st1;
     if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
@@ -1383,11 +1393,17 @@ int qcqpmi_cd_run_stage(qcqpmi_ctx *c, int stage, int phase1, int64_t num_iters,
     return 0;
 }
 
-int qcqpmi_cd_chain(qcqpmi_ctx *c, qcqpmi_ctx *next, int64_t next_R, uint64_t next_seed, uint64_t next_first_index) {
-    if (!c) return QCQPMI_EINVAL;
-    if (c->chain_next && c->chain_next->chained_by == c && c->chain_next != next) c->chain_next->chained_by = nullptr;
-    c->chain_next = next;
-    c->chain_R = next_R; c->chain_seed = next_seed; c->chain_first = next_first_index;
+int qcqpmi_cd_chain(qcqpmi_ctx *c, int pos, qcqpmi_ctx *next, int64_t next_R, uint64_t next_seed, uint64_t next_first_index) {
+    if (!c || pos < 1 || pos > 3) return QCQPMI_EINVAL;
+    const int q = pos - 1;
+    qcqpmi_ctx *old = c->chain_nx[q];
+    c->chain_nx[q] = next;
+    if (old && old != next) {
+        bool still = false;
+        for (qcqpmi_ctx *nx : c->chain_nx) still = still || nx == old;
+        if (!still) for (auto &pb : old->chained_by) if (pb == c) pb = nullptr;
+    }
+    c->chain_R[q] = next_R; c->chain_seed[q] = next_seed; c->chain_first[q] = next_first_index;
     return 0;
 }
 

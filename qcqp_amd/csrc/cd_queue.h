@@ -30,9 +30,11 @@ struct CdBatch {                 // one population = the restarts of one improve
     int ready_gen;               // generation number the owner of that population publishes when it has prepared it
 };
 
+constexpr int CDQ_MAXB = 4;      // populations a launch can see: its own and the next three
+
 struct CdQueueArgs {
     DevProblem P;
-    CdBatch b[2];                // b[0]: the population this launch belongs to; b[1]: the next one (pull-ahead), if nb == 2
+    CdBatch b[4];                // b[0]: the population this launch belongs to; b[1..nb-1]: the next ones (run ahead), in order
     int nb;
     int64_t num_iters;
     double tol;

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
     int *ost = (int *)sp; sp += 8;
     int *ctl = (int *)sp; sp += 8;                 // [0] occupied slots
     long long *cst = (long long *)sp; sp += 64 * 8; // the chain wave's per-lane state between episodes: [field][lane]
+    CdBatch *Bt = (CdBatch *)sp; sp += (CDQ_MAXB * sizeof(CdBatch) + 7) / 8;   // the populations this launch may draw from (dynamic indexing: LDS, not kernel arguments)
 
     // ---- the chain wave's per-restart state (lane 4 r + g: restart slot r) is parked in LDS between episodes: fields
     // 0 upd_counter, 1 visits, 2 accepted, 3 sweeps, 4 conv, 5 status, 6 fpart (bits); inside an episode it lives in the
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
         for (int f = 0; f < 8; f++) cst[f * 64 + tid0] = (f == 4) ? 1 : 0;
     }
     if (tid0 < 16) { sid[tid0] = -1; sbt[tid0] = 0; sfin[tid0] = 0; }
+    if (tid0 == 0) { Bt[0] = a.b[0]; Bt[1] = a.b[1]; Bt[2] = a.b[2]; Bt[3] = a.b[3]; }
     __syncthreads();
     const int64_t gmax = (int64_t)1 << 40;         // the roles end through RQ_STOP
 
@@ -101,14 +103,14 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             int id = sid[tid], bt = sbt[tid], nw = 0;
             if (id < 0) {
                 for (int q = 0; q < a.nb && id < 0; q++) {
-                    const CdBatch &B = q ? a.b[1] : a.b[0];
-                    if (q == 1 && B.ready && qs_load_int(B.ready) != B.ready_gen) break;
+                    const CdBatch &B = Bt[q];
+                    if (B.ready && qs_load_int(B.ready) != B.ready_gen) break;     // not published yet (nor are the ones after it)
                     for (;;) {
                         const int idx = atomicAdd(B.next, 1);      // (runs past R by at most 16 per workgroup and episode: harmless)
                         if (idx >= (int)B.R) break;
                         if (__hip_atomic_load(B.flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                             id = idx; bt = q; nw = 1;
-                            if (q == 1) atomicAdd(B.next + 2, 1);      // statistics: restarts of the next population run ahead by this launch
+                            if (q >= 1) atomicAdd(B.next + 2, 1);      // statistics: restarts of the next population run ahead by this launch
                             break;
                         }
                     }
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             }
             sid[tid] = id; sbt[tid] = bt; snew[tid] = nw;
             if (nw) {
-                const CdBatch &B = bt ? a.b[1] : a.b[0];
+                const CdBatch &B = Bt[bt];
                 slk[tid] = qs_load_d(B.slack + id);
                 f0new[tid] = qs_load_d(B.f0cur + id);
                 FeasSet<MAXC> C;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                 // eight loads in flight per thread; the own population was complete before this launch (plain loads), the
                 // next one was written by kernels of another stream while this one was running (sc1 loads)
                 const bool nxt = sbt[col] != 0;
-                const double *src = (nxt ? a.b[1].X : a.b[0].X) + ((int64_t)(id >> 4) * n16) * 16 + (id & 15);
+                const double *src = Bt[sbt[col]].X + ((int64_t)(id >> 4) * n16) * 16 + (id & 15);
                 for (int64_t j0 = tid >> 4; j0 < n16; j0 += 32 * 8) {
                     double pv[8];
 #pragma unroll
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                         S.fcur = rq_quad_sum(fpart);
                         double *Gsc = fixp;
                         const int bsel = sbt[r];
-                        const uint64_t dseed = bsel ? a.b[1].seed : a.b[0].seed, dfirst = bsel ? a.b[1].first_index : a.b[0].first_index;
+                        const uint64_t dseed = Bt[bsel].seed, dfirst = Bt[bsel].first_index;
 #pragma unroll
                         for (int v = 0; v < 4; v++) Gsc[(4 * v + gq) * 16 + r] = g0[v];
                         for (int c = 0; c < 16; c++) {
@@ -533,9 +535,12 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                     const unsigned long long finm = __builtin_amdgcn_ballot_w64(fin);
                     if (finm == ~0ull) break;
                     if (finm != 0ull) {
-                        bool more = __hip_atomic_load(a.b[0].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)a.b[0].R;
-                        if (!more && a.nb > 1 && (!a.b[1].ready || __hip_atomic_load(a.b[1].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.b[1].ready_gen))
-                            more = __hip_atomic_load(a.b[1].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)a.b[1].R;
+                        bool more = false;
+                        for (int q = 0; q < a.nb && !more; q++) {
+                            const CdBatch &B = Bt[q];
+                            if (B.ready && qs_load_int(B.ready) != B.ready_gen) break;
+                            more = qs_load_int(B.next) < (int)B.R;
+                        }
                         if (more) break;
                     }
                 }
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             const int col = tid & 15, slot = tid >> 4;
             double v = -QM_INF;
             if (sfin[col]) {
-                double *dst = (sbt[col] ? a.b[1].X : a.b[0].X) + ((int64_t)(sid[col] >> 4) * n16) * 16 + (sid[col] & 15);
+                double *dst = Bt[sbt[col]].X + ((int64_t)(sid[col] >> 4) * n16) * 16 + (sid[col] & 15);
                 for (int64_t i = slot; i < n16; i += 32) {
                     const double x = Xs[i * 16 + col];
                     dst[i * 16] = x;
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             if (tid < 16 && sfin[tid]) {
                 double m = -QM_INF;
                 for (int s2 = 0; s2 < 32; s2++) { const double w = red[s2 * 16 + tid]; m = w > m ? w : m; }
-                const CdBatch &B = sbt[tid] ? a.b[1] : a.b[0];
+                const CdBatch &B = Bt[sbt[tid]];
                 const int id = sid[tid];
                 B.visits[id] = ovis[tid]; B.accepted[id] = oacc[tid]; B.sweeps[id] = oswp[tid]; B.status[id] = ost[tid];
                 if (B.f0out) B.f0out[id] = of0[tid];
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
 size_t cd_queue_lds_bytes(const DevProblem &P) {
     const int NB = (int)P.NB;
     if (P.n % 16 != 0 || NB < 3) return 0;
-    size_t bytes = ((size_t)RQ_LDS_COMMON + 8 + 16 * 5 + 8 * 6 + 64 * 8 + (size_t)P.n16 * 16) * sizeof(double);
+    size_t bytes = ((size_t)RQ_LDS_COMMON + 8 + 16 * 5 + 8 * 6 + 64 * 8 + (CDQ_MAXB * sizeof(CdBatch) + 7) / 8 + (size_t)P.n16 * 16) * sizeof(double);
     if (bytes < RQ_LDS_MIN + 1024) bytes = RQ_LDS_MIN + 1024;
     return bytes <= 160 * 1024 ? bytes : 0;
 }

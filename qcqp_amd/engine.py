@@ -344,10 +344,12 @@ class Engine(object):
         """Confine the slot-queue launches of this engine to `phase2_cus` CUs (0 = whole chip); see qcqpmi_cd_partition."""
         self._chk(self.L.qcqpmi_cd_partition(self.h, int(phase2_cus)))
 
-    def cd_chain(self, nxt, next_R=0, next_seed=0, next_first_index=0):
+    def cd_chain(self, nxt, next_R=0, next_seed=0, next_first_index=0, pos=1):
         """The phase-2 launch of this engine may run restarts of the NEXT population of engine `nxt` (same problem, same GPU) once
-        its own queue is empty (qcqpmi_cd_chain).  nxt=None removes the link."""
-        self._chk(self.L.qcqpmi_cd_chain(self.h, nxt.h if nxt is not None else None, int(next_R), int(next_seed), int(next_first_index)))
+        the queues before it are empty; pos = 1 the population after this engine's own, 2 / 3 the ones after that
+        (qcqpmi_cd_chain).  nxt=None ends the chain at pos."""
+        self._chk(self.L.qcqpmi_cd_chain(self.h, int(pos), nxt.h if nxt is not None else None, int(next_R), int(next_seed),
+                                         int(next_first_index)))
 
     def cd_reference_order(self, enable=True):
         """Coupled constraints: coordinate descent in the reference's summation order (slow, value-for-value comparable with

@@ -710,13 +710,15 @@ def test_cd_queue_kernel_vs_tile_bound(eng_mod, orc):
         assert oq['visits2'][r] == s2[1] and oq['accepted2'][r] == s2[2]
 
 
-def test_cd_chained_contexts_match_serial_runs(eng_mod):
-    """qcqpmi_cd_chain: three contexts in a ring, the phase-2 launch of step k may run restarts of step k + 1 (prepared
-    meanwhile in the next context) once its own queue is empty -- the way bench.py runs its steps.  Every step's results
-    (points, counters, objective, max violation, best restart) must equal those of the same step run alone on a fresh
-    engine with the tile-bound kernel: per restart the scheduling changes nothing."""
+@pytest.mark.parametrize('NC,LA,DL', [(4, 1, 1), (6, 2, 2)])    # a context is reused after LA + DL + 2 steps
+def test_cd_chained_contexts_match_serial_runs(eng_mod, NC, LA, DL):
+    """qcqpmi_cd_chain: contexts in a ring, the phase-2 launch of step k may run restarts of the next LA steps (prepared
+    ahead in the next contexts) once the queues before them are empty -- the way bench.py runs its steps; results are
+    fetched DL steps after the launch.  Every step's results (points, counters, objective, max violation, best restart)
+    must equal those of the same step run alone on a fresh engine with the tile-bound kernel: per restart the scheduling
+    changes nothing."""
     from qcqp_amd import problems
-    n, R, steps, seed, first = 256, 700, 5, 31, 11
+    n, R, steps, seed, first = 256, 700, 9, 31, 11
     funcs, _, _ = problems.boolean_least_squares(n, 64, seed=2)
     ref = []
     e0 = make(eng_mod, funcs)
@@ -725,7 +727,9 @@ def test_cd_chained_contexts_match_serial_runs(eng_mod):
         e0.randn(R, seed=seed + k, first_index=first)
         o = e0.cd_run(seed=seed + k, first_index=first)
         ref.append((e0.download(), o, e0.select_best(1e-4)[:3]))
-    engs = [make(eng_mod, funcs) for _ in range(3)]
+    engs = [make(eng_mod, funcs) for _ in range(NC)]
+    for e in engs:
+        e.cd_queue(1)
     got = {}
 
     def prepare(e, k):
@@ -733,22 +737,24 @@ def test_cd_chained_contexts_match_serial_runs(eng_mod):
         e.cd_begin(phase1=True, seed=seed + k, first_index=first)
 
     def finish(j):
-        e = engs[j % 3]
+        e = engs[j % NC]
         o = e.cd_fetch()
         got[j] = (e.download(), o, e.select_best(1e-4)[:3], e.last_cd_kernel())
-    prepare(engs[0], 0)
+    for j in range(min(LA + 1, steps)):
+        prepare(engs[j % NC], j)
     for k in range(steps):
-        cur, nxt = engs[k % 3], engs[(k + 1) % 3]
-        more = k + 1 < steps
-        cur.cd_chain(nxt if more else None, R, seed + k + 1, first)
+        cur = engs[k % NC]
+        for p_ in range(1, LA + 1):
+            cur.cd_chain(engs[(k + p_) % NC] if k + p_ < steps else None, R, seed + k + p_, first, pos=p_)
         cur.cd_phase2()
-        if more:
-            prepare(nxt, k + 1)
-        if k >= 1:
-            finish(k - 1)
-    finish(steps - 1)
+        if k + LA + 1 < steps:
+            prepare(engs[(k + LA + 1) % NC], k + LA + 1)
+        if k >= DL:
+            finish(k - DL)
+    for j in range(max(steps - DL, 0), steps):
+        finish(j)
     pulled = sum(e.cd_pulled() for e in engs)
-    print('\nchained contexts: %d restarts of %d were run ahead by the previous step\'s launch' % (pulled, steps * R))
+    print('\nchained contexts (%d, depth %d): %d restarts of %d were run ahead by earlier launches' % (NC, LA, pulled, steps * R))
     for k in range(steps):
         X, o, b, name = got[k]
         rX, ro, rb = ref[k]

@@ -24,19 +24,23 @@ def finish(j):
     stamp('fetch>', j); o = e.cd_fetch(); stamp('fetch<', j)
     e.select_best(1e-4); stamp('best<', j)
     return o
-count = 24
-prepare(engs[0], 0); prepare(engs[1], 1)
+count = 32
+LA, DL = 2, NC - 4
+for j in range(LA + 1):
+    prepare(engs[j % NC], j)
 for k in range(count):
-    cur, nxt = engs[k % NC], engs[(k + 1) % NC]
-    cur.cd_chain(nxt if k + 1 < count else None, R, seed + k + 1, 0)
+    cur = engs[k % NC]
+    for p_ in range(1, LA + 1):
+        cur.cd_chain(engs[(k + p_) % NC] if k + p_ < count else None, R, seed + k + p_, 0, pos=p_)
     stamp('launch>', k); cur.cd_phase2(); stamp('launch<', k)
-    if k + 2 < count:
-        prepare(engs[(k + 2) % NC], k + 2); stamp('prep<', k + 2)
-    if k >= 1:
-        finish(k - 1)
-finish(count - 1)
+    if k + LA + 1 < count:
+        prepare(engs[(k + LA + 1) % NC], k + LA + 1); stamp('prep<', k + LA + 1)
+    if k >= DL:
+        finish(k - DL)
+for j in range(max(count - DL, 0), count):
+    finish(j)
 tot = time.perf_counter() - T0
 for t, tag, k in log:
-    if 10 <= k <= 13:
+    if 14 <= k <= 17:
         print('%9.3f ms  %-8s %d' % (t * 1e3, tag, k))
-print('total %.1f ms for %d steps = %.3f ms/step; run ahead %d' % (tot * 1e3, count, tot * 1e3 / count, sum(e.cd_pulled() for e in engs)))
+print('p2 cus %d, %d contexts: total %.1f ms for %d steps = %.3f ms/step; run ahead %d' % (p2, NC, tot * 1e3, count, tot * 1e3 / count, sum(e.cd_pulled() for e in engs)))
