@@ -65,26 +65,37 @@ def secondary_records(device):
     # the headline family with 4 tiles per CU: the hardware's workgroup queue refills a CU as soon as its tile of 16 restarts
     # has converged, so the 1-workgroup-per-CU straggler effect of the headline (kernel time = slowest tile) is amortised
     try:
-        n, R = 1024, 16384
+        n = 1024
         funcs, _, _ = problems.boolean_least_squares(n, 256, seed=1)
         e = Engine(QCQPForm.from_arrays(funcs), device=device)
-        e.randn(R, seed=90)
-        e.cd_run(phase1=True, seed=90)
-        sw = ms = 0.0
-        e.sync()
-        t0 = time.perf_counter()
-        for k in range(5):
-            e.randn(R, seed=91 + k)
-            out = e.cd_run(phase1=True, seed=91 + k)
-            sw += float(out['visits2'].sum()) / n
-            ms += e.kernel_ms(Engine.KERNEL_CD2)
-        e.sync()
-        dt = time.perf_counter() - t0
-        recs.append({'config': 'headline family (Boolean LS n=1024 m=256) with 16384 restarts on one GPU: 1024 tiles queued on 256 CUs',
-                     'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': sw / dt, 'unit': 'restart-sweeps/s',
-                     'roofline': {'bound': 'mfma', 'kernel': e.last_cd_kernel(), 'achieved': sw * 2.0 * n * n / 1e12 / (ms / 1e3),
-                                  'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': sw * 2.0 * n * n / 1e12 / (ms / 1e3) / FP64_PEAK_TFLOPS,
-                                  'kernel_ms_per_launch': ms / 5}})
+        pts = []
+        for R, reps in ((16384, 4), (65536, 2)):
+            for mode in (0, 2):          # 0: tile-bound cd_phase2_q_kernel; 2 (default dispatch): slot-queue kernel when tiles > CUs
+                e.cd_queue(mode)
+                e.randn(R, seed=90)
+                e.cd_run(phase1=True, seed=90)
+                sw = ms = 0.0
+                e.sync()
+                t0 = time.perf_counter()
+                for k in range(reps):
+                    e.randn(R, seed=91 + k)
+                    out = e.cd_run(phase1=True, seed=91 + k)
+                    sw += float(out['visits2'].sum()) / n
+                    ms += e.kernel_ms(Engine.KERNEL_CD2)
+                e.sync()
+                dt = time.perf_counter() - t0
+                pts.append({'restarts': R, 'kernel': e.last_cd_kernel(), 'value': sw / dt, 'kernel_ms_per_launch': ms / reps,
+                            'achieved': sw * 2.0 * n * n / 1e12 / (ms / 1e3), 'frac': sw * 2.0 * n * n / 1e12 / (ms / 1e3) / FP64_PEAK_TFLOPS})
+        head = [p_ for p_ in pts if p_['restarts'] == 16384 and p_['kernel'] == 'cd_phase2_qs_kernel'][0]
+        recs.append({'config': 'headline family (Boolean LS n=1024 m=256) with 16384 / 65536 restarts on one GPU (1024 / 4096 tiles on 256 CUs): '
+                               'tile-bound kernel (a workgroup runs a tile of 16 restarts until the slowest has converged) against the '
+                               'slot-queue kernel (a converged restart is replaced at the next sweep boundary); first figures: 16384 restarts, '
+                               'slot queue',
+                     'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': head['value'], 'unit': 'restart-sweeps/s',
+                     'by_restarts_and_kernel': pts,
+                     'roofline': {'bound': 'mfma', 'kernel': head['kernel'], 'achieved': head['achieved'],
+                                  'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': head['frac'],
+                                  'kernel_ms_per_launch': head['kernel_ms_per_launch']}})
         del e
     except Exception as ex:
         recs.append({'config': 'headline family, 16384 restarts', 'error': repr(ex)})

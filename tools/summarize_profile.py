@@ -20,7 +20,7 @@ def find(sub, suffix):
 
 
 def short(name):
-    return name.split('(')[0].replace('void ', '').replace('qcqpmi::', '')[:60]
+    return name.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('qcqpmi::', '')[:60]
 
 
 import datetime
