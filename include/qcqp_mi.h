@@ -257,6 +257,24 @@ int qcqpmi_cd_chain(qcqpmi_ctx *ctx, int pos, qcqpmi_ctx *next, int64_t next_R, 
  * its workgroups are persistent and hold a CU each (LDS), so with chained contexts the kernels that prepare the next
  * populations would otherwise find no free CU until workgroups run out of work. */
 int qcqpmi_cd_partition(qcqpmi_ctx *ctx, int phase2_cus);
+/* Ring mode: ONE persistent slot-queue launch (on `phase2_cus` CUs; 0 = all) serves the populations of 2..4 contexts of the
+ * same problem in turn -- population j of a run lives in member j mod count -- until qcqpmi_cd_ring_stop: no launch per
+ * step, no exposed tail between steps (a slot whose restart is done takes the next restart of whatever population is
+ * published), and the kernels that prepare populations always find the remaining CUs free.  Every member must hold a
+ * resident population of the final size and have run one ordinary qcqpmi_cd_run before (all buffers exist: nothing may be
+ * allocated or freed on the device while the launch is resident).
+ *   qcqpmi_cd_ring_submit   phase 1 + evaluation + gate of the member's resident population on its own stream, then the
+ *                            population is published to the launch (asynchronous)
+ *   qcqpmi_cd_ring_collect  waits until every restart of that population is done, returns what qcqpmi_cd_run returns
+ * Per restart the results are those of qcqpmi_cd_run (they do not depend on the scheduling). */
+int qcqpmi_cd_ring_start(qcqpmi_ctx **members, int count, int phase2_cus, int64_t num_iters, double tol);
+int qcqpmi_cd_ring_submit(qcqpmi_ctx *member, int phase1, int64_t num_iters, double viol_tol, double tol, uint64_t seed,
+                          uint64_t first_index);
+int qcqpmi_cd_ring_collect(qcqpmi_ctx *member, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
+                           uint8_t *ran_phase2, double *f0, double *maxviol);
+int qcqpmi_cd_ring_stop(qcqpmi_ctx *owner);      /* owner = members[0] */
+/* debug: the 9 queue-state words of the context's population (see csrc/cd_queue.h) and hipStreamQuery of the ring's launch */
+int qcqpmi_debug_cd_ring_state(qcqpmi_ctx *ctx, int64_t *out10);
 /* statistics: restarts of this context's populations that were run by the launches of the context chained to it (total) */
 int qcqpmi_debug_cd_pulled(qcqpmi_ctx *ctx, int64_t *out);
 /* Coordinate descent for constraints that couple coordinates IN THE REFERENCE'S SUMMATION ORDER (test / diagnostic mode, any

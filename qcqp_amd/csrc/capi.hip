@@ -171,6 +171,12 @@ struct qcqpmi_ctx {
     qcqpmi_ctx *chained_by[3] = {nullptr, nullptr, nullptr}; // ... and the contexts whose launches may have run restarts of this one's population
     hipEvent_t ev_p2 = nullptr;           // recorded after this context's phase-2 launch
     bool q_prepared = false;              // the queue of the resident population has been reset and published
+    // ring mode (qcqpmi_cd_ring_*): ONE persistent slot-queue launch serves the populations of up to four contexts in turn
+    qcqpmi_ctx *ring_owner = nullptr;     // the context that holds the launch (member 0); set on every member
+    std::vector<qcqpmi_ctx *> ring_members;   // owner only
+    int *d_rctl = nullptr;                // owner only: [0] quit
+    hipStream_t ring_stream = nullptr;    // owner only: the (CU-masked) stream of the persistent launch
+    bool ring_running = false;
     int p2_cus = 0;                       // qcqpmi_cd_partition: CUs the slot-queue launches are confined to (0: no partition)
     hipStream_t stream_p2 = nullptr;      // ... the stream with that CU mask
     hipEvent_t ev_prep = nullptr;         // "everything phase 2 needs has been enqueued on the main stream"
@@ -400,6 +406,15 @@ int launch_eval(qcqpmi_ctx *c, bool want_F) {
     return 0;
 }
 
+// ring mode: everything a running launch needs to know about the population, then (last) its generation number
+__global__ void cd_ring_publish_kernel(int *q, int gen, int R, unsigned long long seed, unsigned long long first) {
+    q[0] = 0; q[3] = 0; q[4] = R;
+    q[5] = (int)(unsigned)(seed & 0xffffffffull); q[6] = (int)(unsigned)(seed >> 32);
+    q[7] = (int)(unsigned)(first & 0xffffffffull); q[8] = (int)(unsigned)(first >> 32);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    __hip_atomic_store(q + 1, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void cd_queue_publish_kernel(int *q, int gen) { q[0] = 0; __hip_atomic_store(q + 1, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // does phase 2 of the resident population go through the slot-queue kernel?
@@ -421,7 +436,7 @@ bool cd_queue_applies(qcqpmi_ctx *c, bool profiling) {
 // reset the queue of the resident population and the per-restart outputs the kernel only writes for the restarts it runs,
 // then publish the population (generation number) to whoever may pull from it
 int cd_queue_prepare(qcqpmi_ctx *c) {
-    if (!c->d_qnext) { int rcq = dev_alloc(c, &c->d_qnext, 4); if (rcq) return rcq; }
+    if (!c->d_qnext) { int rcq = dev_alloc(c, &c->d_qnext, 16); if (rcq) return rcq; }
     HIPCHK(c, hipMemsetAsync(c->d_visits, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_sweeps, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
@@ -471,7 +486,7 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
             if (!c->q_prepared && (rcq = cd_queue_prepare(c))) return rcq;
             c->q_prepared = false;
             CdQueueArgs qa;
-            qa.P = dp; qa.nb = 1; qa.num_iters = a1.num_iters; qa.tol = a1.tol;
+            qa.P = dp; qa.nb = 1; qa.num_iters = a1.num_iters; qa.tol = a1.tol; qa.ring = 0; qa.rctl = nullptr; qa.ring_limit = 0;
             cd_queue_fill_batch(c, qa.b[0], a1.seed, a1.first_index);
             for (int q = 1; q < CDQ_MAXB; q++) { qa.b[q] = qa.b[0]; qa.b[q].R = 0; }
             for (int q = 0; q < 3; q++) {
@@ -479,7 +494,7 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
                 const int64_t nR = nx ? (c->chain_R[q] > 0 ? c->chain_R[q] : nx->R) : 0;
                 if (!(nx && nx != c && nx->finalized && nx->X && nx->n == c->n && nx->device == c->device && nx->R > 0 &&
                       cd_queue_eligible(nx, nx->profile) && (nR + 15) / 16 * 16 <= nx->Rcap)) break;     // the chain ends at the first gap
-                if (!nx->d_qnext) { if ((rcq = dev_alloc(nx, &nx->d_qnext, 4))) return fail(c, rcq, "cd chain: %s", nx->err.c_str()); HIPCHK(c, hipStreamSynchronize(nx->stream)); }
+                if (!nx->d_qnext) { if ((rcq = dev_alloc(nx, &nx->d_qnext, 16))) return fail(c, rcq, "cd chain: %s", nx->err.c_str()); HIPCHK(c, hipStreamSynchronize(nx->stream)); }
                 // the NEXT population of that context: same buffers (a context keeps them), seed / first index as the caller
                 // announced them with qcqpmi_cd_chain, generation = the one it has published already (prepared ahead) or the one
                 // its next stage 1 will publish
@@ -714,6 +729,10 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->comm);
+    if (c->ring_running) (void)qcqpmi_cd_ring_stop(c);
+    if (c->ring_owner && c->ring_owner != c) (void)qcqpmi_cd_ring_stop(c->ring_owner);
+    if (c->ring_stream) (void)hipStreamDestroy(c->ring_stream);
+    if (c->d_rctl) (void)hipFree(c->d_rctl);
     if (c->stream_p2) { (void)hipStreamSynchronize(c->stream_p2); (void)hipStreamDestroy(c->stream_p2); }
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
@@ -1454,6 +1473,141 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 }
 
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
+
+// ---- ring mode: one persistent launch for the populations of up to four contexts --------------------------------------
+int qcqpmi_cd_ring_start(qcqpmi_ctx **ctxs, int count, int phase2_cus, int64_t num_iters, double tol) {
+    if (!ctxs || count < 2 || count > CDQ_MAXB || !ctxs[0]) return QCQPMI_EINVAL;
+    qcqpmi_ctx *o = ctxs[0];
+    if (o->ring_running || o->ring_owner) return fail(o, QCQPMI_ESTATE, "cd_ring_start: a ring is already running on this context");
+    HIPCHK(o, hipSetDevice(o->device));
+    int cus = 0;
+    HIPCHK(o, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, o->device));
+    if (phase2_cus <= 0 || phase2_cus > cus) phase2_cus = cus;
+    for (int i = 0; i < count; i++) {
+        qcqpmi_ctx *c = ctxs[i];
+        if (!c || !c->finalized || c->n != o->n || c->device != o->device || !c->X || c->R != o->R || c->ring_owner ||
+            !cd_queue_eligible(c, false) || c->R <= 0)
+            return fail(o, QCQPMI_EINVAL, "cd_ring_start: member %d is not a context of the same problem with a resident population of the "
+                        "same size, or its problem does not take the slot-queue kernel", i);
+    }
+    if (!(tol > 0.0) || num_iters < 0) return fail(o, QCQPMI_EINVAL, "cd_ring_start: bad num_iters / tol");
+    int rc;
+    if (!o->d_rctl && (rc = dev_alloc(o, &o->d_rctl, 4))) return rc;
+    HIPCHK(o, hipMemsetAsync(o->d_rctl, 0, 4 * sizeof(int), o->stream));
+    CdQueueArgs qa;
+    qa.P = o->dp; qa.nb = count; qa.num_iters = num_iters; qa.tol = tol; qa.ring = 1; qa.rctl = o->d_rctl;
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, o->device) != hipSuccess || khz <= 0) khz = 100000;
+        qa.ring_limit = (long long)khz * 1000ll * 600ll;      // ten minutes of the wall clock: a forgotten ring does not hold the GPU forever
+    }
+    for (int i = 0; i < CDQ_MAXB; i++) {
+        qcqpmi_ctx *c = ctxs[i < count ? i : 0];
+        if (i < count) {
+            if (!c->d_qnext && (rc = dev_alloc(c, &c->d_qnext, 16))) return fail(o, rc, "cd_ring_start: %s", c->err.c_str());
+            HIPCHK(o, hipMemsetAsync(c->d_qnext, 0, 16 * sizeof(int), c->stream));
+            HIPCHK(o, hipStreamSynchronize(c->stream));
+            c->qgen = 0;
+        }
+        cd_queue_fill_batch(c, qa.b[i], 0, 0);
+    }
+    HIPCHK(o, hipStreamSynchronize(o->stream));
+    if (o->ring_stream) { (void)hipStreamDestroy(o->ring_stream); o->ring_stream = nullptr; }
+    if (phase2_cus < cus) {
+        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);      // bits are dealt round-robin to the XCDs (tools/ubench/cumask.hip)
+        for (int i = 0; i < phase2_cus; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+        HIPCHK(o, hipExtStreamCreateWithCUMask(&o->ring_stream, (uint32_t)mask.size(), mask.data()));
+    } else {
+        HIPCHK(o, hipStreamCreateWithFlags(&o->ring_stream, hipStreamNonBlocking));
+    }
+    int cs = (o->dbg & 128) ? ((o->dbg >> 8) & 7) : 4;
+    (void)hipEventRecord(o->timers[2].beg, o->ring_stream);
+    hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, phase2_cus, o->ring_stream);
+    if (qe != hipSuccess) return fail(o, QCQPMI_EHIP, "cd_ring_start: %s", hipGetErrorString(qe));
+    (void)hipEventRecord(o->timers[2].end, o->ring_stream);
+    o->timers[2].valid = true;
+    o->ring_members.assign(ctxs, ctxs + count);
+    for (int i = 0; i < count; i++) { ctxs[i]->ring_owner = o; ctxs[i]->last_cd2_kernel = "cd_phase2_qs_kernel"; }
+    o->ring_running = true;
+    return 0;
+}
+
+// stage 1 of a run (suggest is the caller's; phase 1, evaluation, gate) on the member's own stream, then the population is
+// handed to the persistent launch
+int qcqpmi_cd_ring_submit(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol, double tol, uint64_t seed, uint64_t first_index) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!c->ring_owner || !c->ring_owner->ring_running) return fail(c, QCQPMI_ESTATE, "cd_ring_submit: the context is not a member of a running ring");
+    c->cd_stage = 0;
+    const int keep = c->cd_queue;
+    c->cd_queue = 0;                       // (stage 1 must not publish in the chained way)
+    rc = qcqpmi_cd_run_stage(c, 1, phase1, num_iters, viol_tol, tol, seed, first_index, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    c->cd_queue = keep;
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_visits, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_sweeps, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, (size_t)c->Rpad * sizeof(int), c->stream));
+    c->qgen++;
+    hipLaunchKernelGGL(cd_ring_publish_kernel, dim3(1), dim3(1), 0, c->stream, c->d_qnext, c->qgen, (int)c->R,
+                       (unsigned long long)seed, (unsigned long long)first_index);
+    HIPCHK(c, hipGetLastError());
+    c->cd_stage = 2;                       // "phase 2 is under way"
+    return 0;
+}
+
+// waits until every restart of the member's population is done, then fetches the results like stage 3
+int qcqpmi_cd_ring_collect(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
+                           uint8_t *ran_phase2, double *f0, double *maxviol) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!c->ring_owner || c->cd_stage != 2) return fail(c, QCQPMI_ESTATE, "cd_ring_collect: nothing submitted");
+    HIPCHK(c, hipSetDevice(c->device));
+    int done = 0;
+    for (int64_t spin = 0;; spin++) {
+        HIPCHK(c, hipMemcpyAsync(&done, c->d_qnext + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (done >= (int)c->R) break;
+        if (spin > 300000) return fail(c, QCQPMI_EHIP, "cd_ring_collect: the population did not complete (%d of %lld restarts done)", done, (long long)c->R);
+    }
+    c->cd_stage = 0;
+    c->evaluated = true;                   // d_f0 / d_mv hold the values of the final points
+    std::vector<int> st, st1;
+    if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
+    if ((rc = cd_apply_status(c, st, st1, f0, maxviol, 0))) return rc;
+    return 0;
+}
+
+int qcqpmi_cd_ring_stop(qcqpmi_ctx *o) {
+    if (!o) return QCQPMI_EINVAL;
+    if (!o->ring_running) return 0;
+    HIPCHK(o, hipSetDevice(o->device));
+    const int one = 1;
+    HIPCHK(o, hipMemcpyAsync(o->d_rctl, &one, sizeof(int), hipMemcpyHostToDevice, o->stream));
+    HIPCHK(o, hipStreamSynchronize(o->stream));
+    HIPCHK(o, hipStreamSynchronize(o->ring_stream));
+    for (qcqpmi_ctx *m_ : o->ring_members) m_->ring_owner = nullptr;
+    o->ring_members.clear();
+    o->ring_running = false;
+    return 0;
+}
+
+int qcqpmi_debug_cd_ring_state(qcqpmi_ctx *c, int64_t *out10) {
+    if (!c || !out10) return QCQPMI_EINVAL;
+    for (int k = 0; k < 10; k++) out10[k] = -1;
+    int q[9] = {0};
+    if (c->d_qnext) {
+        hipStream_t side = nullptr;
+        HIPCHK(c, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIPCHK(c, hipMemcpyAsync(q, c->d_qnext, sizeof(q), hipMemcpyDeviceToHost, side));
+        HIPCHK(c, hipStreamSynchronize(side));
+        (void)hipStreamDestroy(side);
+        for (int k = 0; k < 9; k++) out10[k] = q[k];
+    }
+    qcqpmi_ctx *o = c->ring_owner;
+    if (o && o->ring_stream) out10[9] = (int64_t)hipStreamQuery(o->ring_stream);     // 0 = the launch has ended, 600 = still running
+    return 0;
+}
 
 int qcqpmi_debug_cd_pulled(qcqpmi_ctx *c, int64_t *out) {
     if (!c || !out) return QCQPMI_EINVAL;

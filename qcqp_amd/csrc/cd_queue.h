@@ -32,17 +32,24 @@ struct CdBatch {                 // one population = the restarts of one improve
 
 constexpr int CDQ_MAXB = 4;      // populations a launch can see: its own and the next three
 
+// Ring mode: the queue state of a population lives in 16 device ints of its context (`next` points at them):
+//   [0] queue head  [1] generation published  [2] restarts run ahead (statistics)  [3] restarts done  [4] R
+//   [5,6] seed  [7,8] first global index       (the fields of CdBatch with the same names are ignored)
+// Population number j of a run (j = 0, 1, ...) lives in entry j % nb with generation j / nb + 1.
 struct CdQueueArgs {
     DevProblem P;
     CdBatch b[4];                // b[0]: the population this launch belongs to; b[1..nb-1]: the next ones (run ahead), in order
     int nb;
     int64_t num_iters;
     double tol;
+    int ring;                    // 1: ONE persistent launch serves the populations of nb contexts in turn until *rctl != 0
+    int *rctl;                   // [0] quit
+    long long ring_limit;        // safety: the launch ends after this many ticks of wall_clock64() whatever happens
 };
 
 // LDS bytes of the kernel for this problem (0: does not fit / not eligible)
 size_t cd_queue_lds_bytes(const DevProblem &P);
 // launches ceil(R0 / 16) workgroups at most `max_wgs`; cs = blocks of the contraction the chain wave multiplies (0, 2, 4, 6)
-int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st);
+int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st);     // ring mode: exactly max_wgs workgroups
 
 }  // namespace qcqpmi

@@ -75,7 +75,9 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
     int *ost = (int *)sp; sp += 8;
     int *ctl = (int *)sp; sp += 8;                 // [0] occupied slots
     long long *cst = (long long *)sp; sp += 64 * 8; // the chain wave's per-lane state between episodes: [field][lane]
-    CdBatch *Bt = (CdBatch *)sp; sp += (CDQ_MAXB * sizeof(CdBatch) + 7) / 8;   // the populations this launch may draw from (dynamic indexing: LDS, not kernel arguments)
+    CdBatch *Bt = (CdBatch *)sp; sp += (CDQ_MAXB * sizeof(CdBatch) + 7) / 8;
+    unsigned long long *sseed = (unsigned long long *)sp; sp += 16;     // ring mode: seed / first global index of the slot's population
+    unsigned long long *sfirst = (unsigned long long *)sp; sp += 16;   // the populations this launch may draw from (dynamic indexing: LDS, not kernel arguments)
 
     // ---- the chain wave's per-restart state (lane 4 r + g: restart slot r) is parked in LDS between episodes: fields
     // 0 upd_counter, 1 visits, 2 accepted, 3 sweeps, 4 conv, 5 status, 6 fpart (bits); inside an episode it lives in the
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
         for (int f = 0; f < 8; f++) cst[f * 64 + tid0] = (f == 4) ? 1 : 0;
     }
     if (tid0 < 16) { sid[tid0] = -1; sbt[tid0] = 0; sfin[tid0] = 0; }
-    if (tid0 == 0) { Bt[0] = a.b[0]; Bt[1] = a.b[1]; Bt[2] = a.b[2]; Bt[3] = a.b[3]; }
+    if (tid0 == 0) { Bt[0] = a.b[0]; Bt[1] = a.b[1]; Bt[2] = a.b[2]; Bt[3] = a.b[3]; ctl[1] = 0; ctl[2] = 0; }
+    const long long ring_t0 = a.ring ? (long long)wall_clock64() : 0;
     __syncthreads();
     const int64_t gmax = (int64_t)1 << 40;         // the roles end through RQ_STOP
 
@@ -97,11 +100,36 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, r = lane >> 2, gq = lane & 3;
         // ================================================================ refill: free slots take the next restarts
-        if (tid == 0) ctl[0] = 0;
+        if (tid == 0) {
+            ctl[0] = 0;
+            // ring mode: leave when the host asks to, or after the safety limit (60 s of the 100 MHz wall clock)
+            ctl[3] = !a.ring ? 0 : ((long long)wall_clock64() - ring_t0 > a.ring_limit) ? 2 : (qs_load_int(a.rctl) != 0 ? 1 : 0);
+        }
         __syncthreads();
         if (tid < 16) {
             int id = sid[tid], bt = sbt[tid], nw = 0;
-            if (id < 0) {
+            if (id < 0 && a.ring) {
+                // ring mode: this workgroup's cursor j walks the populations of the run in order (entry j % nb, generation
+                // j / nb + 1); it moves on when a queue is exhausted and stops at the first population not published yet
+                int j = ctl[1];
+                for (;;) {
+                    const int e = j % a.nb;
+                    int *qe = Bt[e].next;
+                    const int want = j / a.nb + 1, gen = qs_load_int(qe + 1);
+                    if (gen < want) break;
+                    if (gen > want) { j++; continue; }              // that population was complete long ago (entry reused)
+                    const int idx = atomicAdd(qe, 1);
+                    if (idx >= qs_load_int(qe + 4)) { j++; continue; }
+                    if (__hip_atomic_load(Bt[e].flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        id = idx; bt = e; nw = 1;
+                        sseed[tid] = (unsigned long long)(unsigned)qs_load_int(qe + 5) | ((unsigned long long)(unsigned)qs_load_int(qe + 6) << 32);
+                        sfirst[tid] = (unsigned long long)(unsigned)qs_load_int(qe + 7) | ((unsigned long long)(unsigned)qs_load_int(qe + 8) << 32);
+                        break;
+                    }
+                    atomicAdd(qe + 3, 1);                            // did not pass the gate (qcqp.py:189): nothing to run, done
+                }
+                atomicMax(&ctl[2], j);
+            } else if (id < 0) {
                 for (int q = 0; q < a.nb && id < 0; q++) {
                     const CdBatch &B = Bt[q];
                     if (B.ready && qs_load_int(B.ready) != B.ready_gen) break;     // not published yet (nor are the ones after it)
@@ -110,6 +138,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                         if (idx >= (int)B.R) break;
                         if (__hip_atomic_load(B.flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                             id = idx; bt = q; nw = 1;
+                            sseed[tid] = B.seed; sfirst[tid] = B.first_index;
                             if (q >= 1) atomicAdd(B.next + 2, 1);      // statistics: restarts of the next population run ahead by this launch
                             break;
                         }
@@ -135,7 +164,16 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
         }
         if (tid < 16) *(volatile rq_lds_int *)(sy + tid) = (tid >= RQ_PARTS && tid < RQ_PARTS + 3) ? -1 : 0;   // words of the even-product waves start odd
         __syncthreads();
-        if (ctl[0] == 0) break;                    // nothing left anywhere: done
+        if (tid == 0 && ctl[2] > ctl[1]) ctl[1] = ctl[2];
+        if (ctl[3] == 2) break;                    // safety limit of a persistent launch: leave whatever is in flight
+        if (ctl[0] == 0) {
+            if (!a.ring) break;                    // nothing left anywhere: done
+            // ring mode: idle until a population is published, the host asks to quit, or the safety limit passes
+            if (ctl[3]) break;
+            __builtin_amdgcn_s_sleep(127);
+            __syncthreads();
+            continue;
+        }
         {
             // columns of the restarts just taken (sc1 loads: the next population was written by kernels of another stream
             // while this one was running), zero columns for empty slots
@@ -144,7 +182,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             if (snew[col]) {
                 // eight loads in flight per thread; the own population was complete before this launch (plain loads), the
                 // next one was written by kernels of another stream while this one was running (sc1 loads)
-                const bool nxt = sbt[col] != 0;
+                const bool nxt = a.ring || sbt[col] != 0;
                 const double *src = Bt[sbt[col]].X + ((int64_t)(id >> 4) * n16) * 16 + (id & 15);
                 for (int64_t j0 = tid >> 4; j0 < n16; j0 += 32 * 8) {
                     double pv[8];
@@ -499,7 +537,8 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                         S.fcur = rq_quad_sum(fpart);
                         double *Gsc = fixp;
                         const int bsel = sbt[r];
-                        const uint64_t dseed = Bt[bsel].seed, dfirst = Bt[bsel].first_index;
+                        const uint64_t dseed = sseed[r], dfirst = sfirst[r];
+                        (void)bsel;
 #pragma unroll
                         for (int v = 0; v < 4; v++) Gsc[(4 * v + gq) * 16 + r] = g0[v];
                         for (int c = 0; c < 16; c++) {
@@ -528,6 +567,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                 rq_sync_write(sy, RQ_COMMIT, (int)g + 1, lane);   // block b is in the X tile; its staged operands are free
                 const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv);
                 if (livem == 0ull) break;
+                if (b == NB - 1 && a.ring && (long long)wall_clock64() - ring_t0 > a.ring_limit) break;
                 if (b == NB - 1) {
                     // sweep boundary: slots whose restart is done (converged, or at the sweep limit) can take a new restart --
                     // end the episode if the queue has one
@@ -536,7 +576,15 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                     if (finm == ~0ull) break;
                     if (finm != 0ull) {
                         bool more = false;
-                        for (int q = 0; q < a.nb && !more; q++) {
+                        if (a.ring) {
+                            for (int j = ctl[1], tries = 0; tries < 2 && !more; j++, tries++) {
+                                int *qe = Bt[j % a.nb].next;
+                                const int want = j / a.nb + 1, gen = qs_load_int(qe + 1);
+                                if (gen < want) break;
+                                more = gen == want && qs_load_int(qe) < qs_load_int(qe + 4);
+                            }
+                        }
+                        for (int q = 0; q < a.nb && !more && !a.ring; q++) {
                             const CdBatch &B = Bt[q];
                             if (B.ready && qs_load_int(B.ready) != B.ready_gen) break;
                             more = qs_load_int(B.next) < (int)B.R;
@@ -597,7 +645,8 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                 double *dst = Bt[sbt[col]].X + ((int64_t)(sid[col] >> 4) * n16) * 16 + (sid[col] & 15);
                 for (int64_t i = slot; i < n16; i += 32) {
                     const double x = Xs[i * 16 + col];
-                    dst[i * 16] = x;
+                    if (a.ring) __hip_atomic_store(dst + i * 16, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // read by other kernels while this one runs
+                    else dst[i * 16] = x;
                     if (i < P.n) {
                         const double f = (cp * x + cq) * x + cr;
                         const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
@@ -607,15 +656,27 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             }
             double *red = part2;                 // 512 doubles of the partial-tile area, free between episodes
             red[tid] = v;
+            if (a.ring) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the columns are in memory before `done` counts them
             __syncthreads();
             if (tid < 16 && sfin[tid]) {
                 double m = -QM_INF;
                 for (int s2 = 0; s2 < 32; s2++) { const double w = red[s2 * 16 + tid]; m = w > m ? w : m; }
                 const CdBatch &B = Bt[sbt[tid]];
                 const int id = sid[tid];
-                B.visits[id] = ovis[tid]; B.accepted[id] = oacc[tid]; B.sweeps[id] = oswp[tid]; B.status[id] = ost[tid];
-                if (B.f0out) B.f0out[id] = of0[tid];
-                if (B.mvout) B.mvout[id] = m;
+                if (a.ring) {
+                    __hip_atomic_store((long long *)B.visits + id, ovis[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((long long *)B.accepted + id, oacc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((long long *)B.sweeps + id, oswp[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(B.status + id, ost[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (B.f0out) __hip_atomic_store(B.f0out + id, of0[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (B.mvout) __hip_atomic_store(B.mvout + id, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    atomicAdd(B.next + 3, 1);                              // one more restart of that population is complete
+                } else {
+                    B.visits[id] = ovis[tid]; B.accepted[id] = oacc[tid]; B.sweeps[id] = oswp[tid]; B.status[id] = ost[tid];
+                    if (B.f0out) B.f0out[id] = of0[tid];
+                    if (B.mvout) B.mvout[id] = m;
+                }
                 sid[tid] = -1; sfin[tid] = 0;
             }
             __syncthreads();
@@ -628,7 +689,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
 size_t cd_queue_lds_bytes(const DevProblem &P) {
     const int NB = (int)P.NB;
     if (P.n % 16 != 0 || NB < 3) return 0;
-    size_t bytes = ((size_t)RQ_LDS_COMMON + 8 + 16 * 5 + 8 * 6 + 64 * 8 + (CDQ_MAXB * sizeof(CdBatch) + 7) / 8 + (size_t)P.n16 * 16) * sizeof(double);
+    size_t bytes = ((size_t)RQ_LDS_COMMON + 8 + 16 * 5 + 8 * 6 + 64 * 8 + (CDQ_MAXB * sizeof(CdBatch) + 7) / 8 + 32 + (size_t)P.n16 * 16) * sizeof(double);
     if (bytes < RQ_LDS_MIN + 1024) bytes = RQ_LDS_MIN + 1024;
     return bytes <= 160 * 1024 ? bytes : 0;
 }
@@ -645,7 +706,7 @@ int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int64_t wgs = (a.b[0].R + 15) / 16;
-    if (wgs > max_wgs) wgs = max_wgs;
+    if (wgs > max_wgs || a.ring) wgs = max_wgs;
     if (wgs < 1) wgs = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3(512), lds, st, a);
     return (int)hipGetLastError();

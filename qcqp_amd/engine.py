@@ -334,6 +334,37 @@ class Engine(object):
         a device-side queue (cd_phase2_qs_kernel)."""
         self._chk(self.L.qcqpmi_cd_queue(self.h, int(mode)))
 
+    # ring mode: one persistent phase-2 launch for the populations of several engines (qcqpmi_cd_ring_*)
+    @staticmethod
+    def ring_start(engines, phase2_cus=0, num_iters=1000, tol=1e-4):
+        """Start the persistent slot-queue launch for `engines` (2..4, same problem, resident populations of one size, each
+        having run one ordinary cd_run before).  engines[0] owns the launch."""
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        rc = engines[0].L.qcqpmi_cd_ring_start(arr, len(engines), int(phase2_cus), int(num_iters), float(tol))
+        engines[0]._chk(rc)
+
+    def ring_submit(self, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=0, first_index=0):
+        """Phase 1 + evaluation + gate of the resident population, then hand it to the persistent launch (asynchronous)."""
+        self._chk(self.L.qcqpmi_cd_ring_submit(self.h, int(bool(phase1)), int(num_iters), float(viol_tol), float(tol), int(seed),
+                                               int(first_index)))
+
+    def ring_collect(self):
+        """Wait until the submitted population is complete; the dictionary of cd_run."""
+        R = self.pop_size
+        out = dict(sweeps1=np.zeros(R, dtype=np.int64), sweeps2=np.zeros(R, dtype=np.int64),
+                   visits2=np.zeros(R, dtype=np.int64), accepted2=np.zeros(R, dtype=np.int64),
+                   ran_phase2=np.zeros(R, dtype=np.uint8), f0=np.empty(R), maxviol=np.empty(R))
+        self._chk(self.L.qcqpmi_cd_ring_collect(self.h, _ip(out['sweeps1']), _ip(out['sweeps2']), _ip(out['visits2']),
+                                                _ip(out['accepted2']), _bp(out['ran_phase2']), _dp(out['f0']), _dp(out['maxviol'])))
+        st1 = np.zeros(R, dtype=np.int32)
+        st2 = np.zeros(R, dtype=np.int32)
+        self._chk(self.L.qcqpmi_cd_status(self.h, st1.ctypes.data_as(C.POINTER(C.c_int)), st2.ctypes.data_as(C.POINTER(C.c_int))))
+        out['status1'], out['status2'] = st1, st2
+        return out
+
+    def ring_stop(self):
+        self._chk(self.L.qcqpmi_cd_ring_stop(self.h))
+
     def cd_pulled(self):
         """Restarts of this engine's populations run ahead by the launches of the engine chained to it (running total)."""
         v = np.zeros(1, dtype=np.int64)
