@@ -547,6 +547,7 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / K,
+            'timed_region_s': dt,
             'higher_is_better': True,
             'scaling': args.scaling,
             'vs_baseline': None,

@@ -59,7 +59,11 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *ctx);
 /* QuadraticFunction(P, q, r, relop)  (utilities.py:41-46).  k = 0 is the objective f0,
  * k = 1..m the constraints fs[k-1].  P must be symmetric (get_qcqp_form symmetrises,
  * utilities.py:333,345).  DENSE: vals = n*n row-major, idx = ptr = NULL, nnz ignored.
- * CSR: ptr[n+1], idx[nnz], vals[nnz]. */
+ * CSR: ptr[n+1], idx[nnz], vals[nnz].
+ * Constraints that couple coordinates are kept row-major on the device as long as all of them fit 16 GB (the paths in the
+ * reference's arithmetic and the device-side ADMM setup read them there); beyond that -- BASELINE.json configs[4] is 137 GB --
+ * every coupled function is packed for the matrix cores when this call receives it (streaming upload: no second copy on
+ * the host or the device; up to 200 GB of packed matrices) and the problem runs on the dense path only. */
 int qcqpmi_set_quad(qcqpmi_ctx *ctx, int64_t k, int format, const double *vals,
                     const int64_t *idx, const int64_t *ptr, int64_t nnz, const double *q,
                     double r, int relop);

@@ -39,6 +39,8 @@ struct HostQuad {
     bool gen = false;
     uint64_t gseed = 0;
     double gscale = 0.0, gqscale = 0.0, gdiag = 0.0;
+    // packed on the device at qcqpmi_set_quad time (problems whose constraint matrices exceed the row-major budget)
+    bool streamed = false;
 };
 
 struct Timer {
@@ -142,6 +144,10 @@ struct qcqpmi_ctx {
     hipEvent_t dn_evn[2] = {nullptr, nullptr};   // "live count of sweep t copied" (dense path: the host runs one sweep ahead)
     int *dn_hn = nullptr;                        // pinned: the two live counts in flight
     bool dn_force = false;    // generated functions: the dense path is the only one that holds them
+    // streaming upload (coupled constraints beyond `stream_limit` bytes of row-major storage): every function is packed for the
+    // matrix cores as it arrives; neither the host nor the device ever holds a second copy
+    double stream_limit = 16e9;
+    double *dn_gp_pre = nullptr, *dn_tmp = nullptr;
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -709,6 +715,7 @@ int qcqpmi_ctx_create(qcqpmi_ctx **out, int64_t n, int64_t m, int device) {
     qcqpmi_ctx *c = new qcqpmi_ctx();
     c->device = device; c->n = n; c->m = m; c->n16 = (n + 15) / 16 * 16;
     c->quads.resize((size_t)m + 1);
+    if (const char *sl = getenv("QCQPMI_STREAM_LIMIT")) { const double v = atof(sl); if (v > 0.0) c->stream_limit = v; }   // tests: exercise the streaming upload at small sizes
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 5 && e == hipSuccess; i++) {
@@ -733,6 +740,8 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     if (c->ring_owner && c->ring_owner != c) (void)qcqpmi_cd_ring_stop(c->ring_owner);
     if (c->ring_stream) (void)hipStreamDestroy(c->ring_stream);
     if (c->d_rctl) (void)hipFree(c->d_rctl);
+    if (c->dn_tmp) (void)hipFree(c->dn_tmp);
+    if (c->dn_gp_pre) (void)hipFree(c->dn_gp_pre);      // (handed to prob_allocs by finalize: nullptr by then)
     if (c->stream_p2) { (void)hipStreamSynchronize(c->stream_p2); (void)hipStreamDestroy(c->stream_p2); }
     if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
     if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
@@ -810,6 +819,44 @@ int qcqpmi_set_quad(qcqpmi_ctx *c, int64_t k, int format, const double *vals, co
                 return fail(c, QCQPMI_EINVAL, "set_quad: P of function %lld is not symmetric (entry %lld,%lld); pass (P + P^T)/2",
                             (long long)k, (long long)i, (long long)j);
         }
+    }
+    bool coupled = false;      // does the function touch more than one coordinate?  (separable constraints stay per-coordinate lists)
+    {
+        int64_t coord = -1;
+        for (size_t e = 0; e < h.cv.size() && !coupled; e++) {
+            if (h.ci[e] != h.cj[e] || (coord >= 0 && coord != h.ci[e])) coupled = true;
+            coord = h.ci[e];
+        }
+        for (int64_t j = 0; j < n && !coupled; j++)
+            if (q[j] != 0.0) { if (coord >= 0 && coord != j) coupled = true; coord = j; }
+    }
+    if (k >= 1 && coupled && (double)c->m * (double)n * (double)n * 8.0 > c->stream_limit) {
+        // ---- streaming upload: the row-major copy of all constraint matrices would not fit the budget (16 GB; BASELINE.json
+        // configs[4] is 137 GB).  The function goes to the device now, straight into the block-major fragment layout of the
+        // dense path (cd_dense.h); its entries are not kept on the host.  Such a problem runs on the dense path only.
+        const int64_t n16 = c->n16, m1 = c->m + 1;
+        if ((double)m1 * (double)n16 * (double)n16 * 8.0 > 200e9)
+            return fail(c, QCQPMI_EUNSUPPORTED, "set_quad: %lld matrices of %lld x %lld exceed the 200 GB kept for packed matrices", (long long)m1, (long long)n, (long long)n);
+        HIPCHK(c, hipSetDevice(c->device));
+        int rcs;
+        if (!c->dn_gp_pre && (rcs = dev_alloc(c, &c->dn_gp_pre, (size_t)m1 * n16 * n16, false))) return rcs;
+        if (!c->dn_tmp && (rcs = dev_alloc(c, &c->dn_tmp, (size_t)n * n, false))) return rcs;
+        std::vector<double> dense;
+        const double *src = vals;
+        if (format != QCQPMI_FMT_DENSE) {
+            dense.assign((size_t)n * n, 0.0);
+            for (size_t e = 0; e < h.cv.size(); e++) dense[(size_t)h.ci[e] * n + h.cj[e]] += h.cv[e];
+            src = dense.data();
+        }
+        HIPCHK(c, hipMemcpyAsync(c->dn_tmp, src, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        const int64_t total = n16 * n16;
+        // (dense_pack_kernel addresses function k at gP + (k - 1) n n: hand it a base that puts the staging buffer there)
+        hipLaunchKernelGGL(dense_pack_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, c->stream, (const double *)nullptr,
+                           (const double *)(c->dn_tmp - (k - 1) * n * n), c->dn_gp_pre, n, n16, (int)m1, (int)k);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging buffer and the caller's array are free again
+        std::vector<int>().swap(h.ci); std::vector<int>().swap(h.cj); std::vector<double>().swap(h.cv);
+        h.streamed = true;
     }
     h.q.assign(q, q + n);
     h.r = r; h.relop = relop; h.set = true;
@@ -914,7 +961,7 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
     for (int64_t k = 1; k <= m && sep; k++) {
         const HostQuad &h = c->quads[(size_t)k];
         int coord = -1;
-        if (h.gen) { sep = false; break; }
+        if (h.gen || h.streamed) { sep = false; break; }
         for (size_t e = 0; e < h.cv.size(); e++) {
             if (h.ci[e] != h.cj[e]) { sep = false; break; }
             if (coord >= 0 && coord != h.ci[e]) { sep = false; break; }
@@ -1004,8 +1051,9 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
         bool all_gen = true;
         for (int64_t k = 1; k <= m; k++) all_gen = all_gen && c->quads[(size_t)k].gen;
         c->dn_force = false;
-        for (int64_t k = 0; k <= m; k++) c->dn_force = c->dn_force || c->quads[(size_t)k].gen;
-        if (!all_gen && (double)m * (double)n * (double)n * 8.0 <= 16e9) {
+        bool any_streamed = false;
+        for (int64_t k = 0; k <= m; k++) { c->dn_force = c->dn_force || c->quads[(size_t)k].gen || c->quads[(size_t)k].streamed; any_streamed = any_streamed || c->quads[(size_t)k].streamed; }
+        if (!all_gen && !any_streamed && (double)m * (double)n * (double)n * 8.0 <= 16e9) {
             std::vector<double> gP((size_t)m * n * n, 0.0);
             for (int64_t k = 0; k < m; k++) {
                 const HostQuad &h = c->quads[(size_t)k + 1];
@@ -1023,7 +1071,7 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
         if ((rc = prob_upload(c, &dp.gq, gq))) return rc;
         if ((rc = prob_upload(c, &dp.gr, gr))) return rc;
         if ((rc = prob_upload(c, &dp.grel, grel))) return rc;
-        if ((c->d_gP || all_gen) && (double)(m + 1) * (double)n16 * (double)n16 * 8.0 <= 200e9 && (rc = dense_build(c, gq, gr, grel))) return rc;
+        if ((c->d_gP || all_gen || any_streamed) && (double)(m + 1) * (double)n16 * (double)n16 * 8.0 <= 200e9 && (rc = dense_build(c, gq, gr, grel))) return rc;
         if (c->dn_force && !c->dn_Gpack) return fail(c, QCQPMI_EUNSUPPORTED, "generated functions need the dense path (matrices exceed 200 GB, or generated and uploaded coupled constraints are mixed beyond 16 GB)");
     }
     if ((rc = dev_alloc(c, &c->d_best_idx, 2))) return rc;

@@ -613,3 +613,41 @@ def test_admm_fused_kernel_golden_and_phase2_only(eng_mod, orc):
                 assert rel(res[0][0][:, r], z['xa']) < 1e-4, r
             assert abs(res[0][1]['f0'][0] - z['fva'][0]) <= 1e-4 * (1 + abs(z['fva'][0]))
             assert abs(res[0][1]['maxviol'][0] - z['fva'][1]) <= 1e-4
+
+
+def test_streaming_upload_of_coupled_constraints(eng_mod, orc, monkeypatch):
+    """Coupled constraints beyond the budget for a row-major copy (16 GB; lowered to 100 kB here through QCQPMI_STREAM_LIMIT
+    so that n = 100, m = 11 takes the path): every function is packed for the matrix cores when qcqpmi_set_quad receives it,
+    dense or CSR, and nothing else is kept.  The packed problem must be the one the ordinary upload builds: evaluation of
+    all functions and a coordinate-descent run bit for bit, and the oracle on a few restarts; separable problems are not
+    affected by the limit (they keep their per-coordinate lists)."""
+    import scipy.sparse as sp
+    from qcqp_amd import problems
+    n, m, R = 100, 11, 24
+    funcs, _, _ = problems.dense_indefinite(n, m, seed=5)
+    funcs = [(sp.csr_matrix(P) if k == 3 else P, q, r, rel) for k, (P, q, r, rel) in enumerate(funcs)]     # one function arrives as CSR
+    X0 = 1.5 * np.random.RandomState(2).randn(n, R)
+    e_ref = make(eng_mod, funcs)
+    monkeypatch.setenv('QCQPMI_STREAM_LIMIT', '100000')
+    e_str = make(eng_mod, funcs)
+    bls = make(eng_mod, problems.boolean_least_squares(64, 16, seed=1)[0])
+    monkeypatch.delenv('QCQPMI_STREAM_LIMIT')
+    assert bls.separable
+    res = []
+    for e in (e_ref, e_str):
+        f0, mv, F = e.eval_batch(X0, want_F=True)
+        e.upload(X0)
+        out = e.cd_run(phase1=True, num_iters=4, seed=7, first_index=3)
+        assert e.last_cd_kernel() == 'dense_chain_kernel'
+        res.append((F, e.download(), out))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for key in ('f0', 'maxviol', 'sweeps1', 'visits2', 'accepted2'):
+        assert np.array_equal(res[0][2][key], res[1][2][key]), key
+    prob = orc.Problem([(P.toarray() if sp.issparse(P) else P, q, r, rel) for (P, q, r, rel) in funcs])
+    g0, gv, G = prob.eval_batch(X0, want_F=True)
+    assert rel(res[1][0], G) < 1e-12
+    # the reference-order mode needs the row-major matrices: refused on a streamed problem, with a message
+    e_str.cd_reference_order(True)
+    e_str.upload(X0)
+    with pytest.raises(eng_mod.EngineError, match='reference-order'):
+        e_str.cd_run(phase1=True, num_iters=1, seed=7)
