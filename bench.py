@@ -267,7 +267,9 @@ def secondary_records(device):
             dt = time.perf_counter() - t0
             sw = float(out['sweeps1'].sum()) + float(out['visits2'].sum()) / n
             fl = sw * 2.0 * n * n * (m + 1)
-            pts.append({'restarts': R, 'value': sw / dt, 'achieved': fl / 1e12 / dt, 'frac': fl / 1e12 / dt / FP64_PEAK_TFLOPS})
+            ph = (e.kernel_ms(Engine.KERNEL_CD1) + e.kernel_ms(Engine.KERNEL_CD2)) / 1e3     # HIP events around the two sweep loops
+            pts.append({'restarts': R, 'value': sw / dt, 'achieved': fl / 1e12 / dt, 'frac': fl / 1e12 / dt / FP64_PEAK_TFLOPS,
+                        'sweep_loops_s': ph, 'wall_s': dt, 'value_sweep_loops': sw / ph, 'frac_sweep_loops': fl / 1e12 / ph / FP64_PEAK_TFLOPS})
         recs.append({'config': 'BASELINE.json configs[4] family at n = 1024, m = 256 (full size is 137.6 GB of matrices): dense indefinite '
                                'QCQP generated on the device, COORD_DESCENT, 2 sweeps per phase; 512 restarts (first figures) and 4096',
                      'metric': 'restarts x coord-sweeps / s (phase 1 + phase 2)', 'value': pts[0]['value'], 'unit': 'restart-sweeps/s',
@@ -275,7 +277,11 @@ def secondary_records(device):
                      'roofline': {'bound': 'mfma', 'kernel': 'dense_products_kernel (G_k = P_k X for all k) + dense chain',
                                   'achieved': pts[0]['achieved'], 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': pts[0]['frac'],
                                   'algorithmic_flops_per_restart_sweep': 2.0 * n * n * (m + 1),
-                                  'timing': 'wall clock of the whole cd_run (products, chain, host loop over sweeps)'}})
+                                  'timing': 'value / frac: wall clock of the whole cd_run -- the two sweep loops (products, chain, host loop over '
+                                            'sweeps) AND the two evaluations of all m + 1 functions improve_coord_descent needs (start of '
+                                            'phase 1; gate and slack, qcqp.py:189), each as expensive as the products of one sweep: with only '
+                                            '2 sweeps per phase they are a third of the wall clock; *_sweep_loops: HIP events around the sweep '
+                                            'loops alone'}})
         del e
     except Exception as ex:
         recs.append({'config': 'configs[4]', 'error': repr(ex)})

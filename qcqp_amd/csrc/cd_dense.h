@@ -429,6 +429,23 @@ __global__ void dense_viol_kernel(double *__restrict__ F, int zs, const double *
     maxviol[gr] = v;
 }
 
+// objective and maximum violation of the final points from the function values the chain has tracked through every
+// accepted move (f_k += delta (t2 (xn + xi) + t1)): saves the evaluation pass over all matrices after phase 2 -- as
+// expensive as the products of one whole sweep.  Agrees with a fresh evaluation to ~1e-12 relative (tested at 1e-9).
+__global__ void dense_tracked_out_kernel(const double *__restrict__ Ft, const int *__restrict__ relop, int m1, int m1p, int64_t R,
+                                         double *__restrict__ f0, double *__restrict__ maxviol) {
+    const int64_t gr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gr >= R) return;
+    double v = -QM_INF;
+    for (int k = 1; k < m1; k++) {
+        const double f = Ft[gr * m1p + k];
+        const double w = (relop[k] == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+        v = w > v ? w : v;
+    }
+    f0[gr] = Ft[gr * m1p];
+    maxviol[gr] = v;
+}
+
 // diagonal blocks of every function for block b:  Dg[c][c'][k] = P_k[16 b + c][16 b + c']
 __global__ __launch_bounds__(256) void dense_diag_kernel(DenseProblem D, int b, double *__restrict__ Dg) {
     const int k = blockIdx.x, t = threadIdx.x;
