@@ -288,6 +288,10 @@ int qcqpmi_debug_cd_pulled(qcqpmi_ctx *ctx, int64_t *out);
  * input noise amplified by the phase-1 bisection) is only comparable as a distribution.  Needs uploaded (not generated)
  * functions with m n^2 <= 2e9 entries.  enable = 0 restores the default dispatch. */
 int qcqpmi_cd_reference_order(qcqpmi_ctx *ctx, int enable);
+/* Chain kernel of the dense-constraint path: 0 (default) dense_chain_mw_kernel -- a workgroup of four waves per restart,
+ * the functions dealt to 256 threads -- whenever m + 1 <= 2048; 1: dense_chain_kernel, one wave per restart (round 1-2
+ * kernel, the cross-check: the two produce the same points bit for bit). */
+int qcqpmi_dense_chain_mode(qcqpmi_ctx *ctx, int mode);
 int qcqpmi_sync(qcqpmi_ctx *ctx);
 /* debug: enable in-kernel cycle counters of the phase-2 kernel / read their sums over tiles
  * (slots: 0 mfma, 1 feasible sets, 2 barrier, 3 sequential part, 4 barrier, 5 #blocks) */
@@ -296,6 +300,12 @@ int qcqpmi_debug_profile(qcqpmi_ctx *ctx, int enable, int64_t *sums8);
  * qcqpmi_debug_profile(ctx, 1, NULL) was on: 0 z-update, 1 partial product, 2 exchange 1, 3 sums, 4 secular solves,
  * 5 exchange 2, 6 gather, 7 bookkeeping, 9 iterations */
 int qcqpmi_debug_admm_profile(qcqpmi_ctx *ctx, int64_t *out16);
+/* debug: stage tick sums (s_memtime) of the dense chain kernel's wave of restart 0 over the runs made while
+ * qcqpmi_debug_profile(ctx, 1, NULL) was on (library built with -DDN_PROFILE=1, else zeros): [0..15] phase 1, [16..31]
+ * phase 2 of the serial thread (one-wave kernel: the wave), [32..63] the same for thread 0 of the multi-wave kernel.
+ * Slots: 0 set-up, 1 one-variable coefficients, 2 bounds + reductions, 3 gaps, 4 segment sweep, 5 minimiser / draw,
+ * 6 commit, 7 write-back, 8 coordinates visited, 9 feasible-set evaluations.  Reading resets the sums. */
+int qcqpmi_debug_dense_profile(qcqpmi_ctx *ctx, int64_t *out64);
 /* debug: per-wave event trace (cycle stamps) of tile 0 of the last profiled phase-2 run; count <= 2048 words */
 int qcqpmi_debug_trace(qcqpmi_ctx *ctx, int64_t *out, int count);
 

@@ -16,7 +16,7 @@ HEADER = os.path.join(REPO, 'include', 'qcqp_mi.h')
 # translation unit -> everything it includes (rebuilt when any of these is newer than its object)
 UNITS = {
     'capi.hip': ['capi.hip', 'capi_admm.inc', 'capi_units.inc', 'capi_dense.inc', 'kernels.hip', 'kernels.h', 'onevar.h', 'philox.h',
-                 'cd_phase2.h', 'cd_phase2_rs.h', 'cd_phase2_q.h', 'admm.h', 'admm_fused.h', 'cd_queue.h', 'gemm_pk.h', 'cd_general.h', 'cd_dense.h',
+                 'cd_phase2.h', 'cd_phase2_rs.h', 'cd_phase2_q.h', 'admm.h', 'admm_fused.h', 'cd_queue.h', 'gemm_pk.h', 'cd_general.h', 'cd_dense.h', 'cd_dense_mw.h',
                  'sdr_solve.h'],
     'admm_fused.hip': ['admm_fused.hip', 'admm_fused.h', 'onevar.h', 'philox.h'],
     'cd_queue.hip': ['cd_queue.hip', 'cd_queue.h', 'cd_phase2_q.h', 'cd_phase2_rs.h', 'cd_phase2.h', 'kernels.h', 'onevar.h', 'philox.h'],
@@ -51,6 +51,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(OBJ, exist_ok=True)
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-I' + os.path.join(REPO, 'include')]
+    if os.environ.get('QCQPMI_DN_PROFILE') == '1':     # stage timers of the dense chain kernels (tools/dense_stage_profile.py)
+        flags.append('-DDN_PROFILE=1')
 
     def compile_unit(unit):
         cmd = [hipcc] + flags + ['-c', os.path.join(SRC, unit), '-o', _obj(unit)]

@@ -73,6 +73,8 @@ PROTOTYPES = [
     ('qcqpmi_sync', C.c_int, [C.c_void_p]),
     ('qcqpmi_debug_profile', C.c_int, [C.c_void_p, C.c_int, c_ip]),
     ('qcqpmi_debug_admm_profile', C.c_int, [C.c_void_p, c_ip]),
+    ('qcqpmi_debug_dense_profile', C.c_int, [C.c_void_p, c_ip]),
+    ('qcqpmi_dense_chain_mode', C.c_int, [C.c_void_p, C.c_int]),
     ('qcqpmi_debug_trace', C.c_int, [C.c_void_p, c_ip, C.c_int]),
     ('qcqpmi_comm_unique_id', C.c_int, [c_bp]),
     ('qcqpmi_comm_init', C.c_int, [C.c_void_p, C.c_int, C.c_int, c_bp]),
@@ -92,7 +94,7 @@ def lib():
             raise ImportError(
                 'libqcqp_mi.so is not built (%s missing). Run `python -m qcqp_amd._build` or '
                 '__graft_entry__.build(); the engine has no CPU fallback.' % LIBPATH)
-        L = C.CDLL(LIBPATH)
+        L = C.CDLL(os.environ.get('QCQPMI_LIB') or LIBPATH)     # QCQPMI_LIB: an alternative build (e.g. with stage timers)
         for name, res, args in PROTOTYPES:
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res

@@ -137,6 +137,8 @@ struct qcqpmi_ctx {
     const double *dn_Gpack = nullptr, *dn_q = nullptr, *dn_qT = nullptr, *dn_r = nullptr;
     const int *dn_relop = nullptr;
     double *dn_G = nullptr, *dn_Dg = nullptr, *dn_Ft = nullptr;
+    int dense_chain_mode = 0;             // 0: four waves per restart where it applies, 1: one wave per restart (cross-check)
+    long long *dn_prof = nullptr;         // 32 tick sums of the dense chain kernel (debug profile)
     int64_t dn_G_cap = 0, dn_state_cap = 0;
     void *dn_state = nullptr;
     hipStream_t stream2 = nullptr;   // second stream of the dense path: products of block b+1 while the chain walks b
@@ -634,6 +636,10 @@ int check_ready(qcqpmi_ctx *c, bool need_pop) {
 
 }  // namespace
 
+#include "cd_dense_mw.h"
+// which chain kernel the dense path dispatches to (four waves per restart unless a thread would hold more than 8 slots)
+static bool dense_chain_mw(const qcqpmi_ctx *c) { return c->dense_chain_mode != 1 && mw_geometry((int)c->m + 1).SL <= 8; }
+static const char *dense_chain_name(const qcqpmi_ctx *c) { return dense_chain_mw(c) ? "dense_chain_mw_kernel" : "dense_chain_kernel"; }
 #include "capi_dense.inc"
 
 // coordinate descent for constraints that couple coordinates (cd_general.h)
@@ -751,7 +757,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext};
     if (c->h_out) (void)hipHostFree(c->h_out);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
@@ -1391,7 +1397,7 @@ int qcqpmi_cd_run_stage(qcqpmi_ctx *c, int stage, int phase1, int64_t num_iters,
     if (whole) {
         if (stage == 1 || stage == 2) { c->cd_stage = stage; return 0; }
         c->cd_stage = 0;
-        c->last_cd2_kernel = (dense_on(c) && !c->cd_ref_order) ? "dense_chain_kernel" : "cd_general_kernel";
+        c->last_cd2_kernel = (dense_on(c) && !c->cd_ref_order) ? dense_chain_name(c) : "cd_general_kernel";
         if (c->cd_ref_order && !c->d_gP)
             return fail(c, QCQPMI_EUNSUPPORTED, "reference-order coordinate descent needs the row-major constraint matrices "
                         "(uploaded functions, m n^2 <= 2e9 entries); device-generated functions only exist packed");
@@ -1703,6 +1709,12 @@ int qcqpmi_last_kernel_ms(qcqpmi_ctx *c, int which, double *ms) {
     float f = 0.f;
     HIPCHK(c, hipEventElapsedTime(&f, c->timers[which].beg, c->timers[which].end));
     *ms = (double)f;
+    return 0;
+}
+
+int qcqpmi_dense_chain_mode(qcqpmi_ctx *c, int mode) {
+    if (!c || mode < 0 || mode > 1) return QCQPMI_EINVAL;
+    c->dense_chain_mode = mode;
     return 0;
 }
 

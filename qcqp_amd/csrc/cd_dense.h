@@ -45,8 +45,10 @@ namespace qcqpmi {
 constexpr int DN_GC = 64;    // gaps kept per restart
 constexpr int DN_SC = 32;    // segments kept per restart
 constexpr int DN_WPB = 4;    // at most this many restarts (= waves) per workgroup of the chain kernel
-// LDS doubles per wave of the chain kernel besides the 4 per-function arrays (t2, t1, t0, f_k)
+// LDS doubles per wave of the chain kernel besides the DN_FARR per-function arrays (t2, t1, t0, f_k, gap start, gap end)
 constexpr int DN_LDS_WAVE = 2 * DN_GC + 2 * DN_SC + 32 + 8;
+constexpr int DN_FARR = 6;
+constexpr int DN_PF = 8;     // function slots per lane whose per-coordinate operands are requested in one batch
 
 typedef double dn_v4d __attribute__((ext_vector_type(4)));
 
@@ -562,10 +564,32 @@ struct DenseChainArgs {
     int64_t t;             // sweep number
     double tol, viol_tol;
     uint64_t seed, first_index;
+    long long *prof;       // optional: 16 tick sums of the wave of restart 0 (qcqpmi_debug_dense_profile), or nullptr
+    int mw_Tc, mw_ts;      // dense_chain_mw_kernel: threads that hold constraints, index of the serial thread (mw_geometry)
+};
+
+// stage timer of one wave (s_memtime ticks): 0 set-up, 1 coefficients, 2 bounds + reductions, 3 gaps, 4 segment sweep
+// (lane 0), 5 minimiser / draw (lane 0), 6 commit, 7 write-back, 8 coordinates visited, 9 feasible-set evaluations
+#ifndef DN_PROFILE
+#define DN_PROFILE 0       // build with -DDN_PROFILE=1 to compile the stage timers in (s_memtime drains the wave's loads)
+#endif
+struct DnProf {
+    long long t[10];
+    long long last;
+    bool on;
+    __device__ inline void start(bool enable) {
+        on = DN_PROFILE && enable;
+        for (int i = 0; i < 10; i++) t[i] = 0;
+        last = on ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    }
+    __device__ inline void tick(int slot) {
+        if (DN_PROFILE && on) { const long long now = (long long)__builtin_amdgcn_s_memtime(); t[slot] += now - last; last = now; }
+    }
 };
 
 struct DnWave {            // the wave's LDS region
     double *t2, *t1, *t0, *F;    // [m1p]
+    double *fga, *fgb;           // [m1p] the gap of a function that allows two intervals (pass 1 -> pass 2)
     double *gapa, *gapb;         // [DN_GC]
     double *seglo, *seghi;       // [DN_SC]
     double *xb, *dlt;            // [16]
@@ -611,7 +635,8 @@ __device__ inline int dn_sweep_segments(double *ga, double *gb, int ng, double *
 
 // Feasible set of the current coordinate at slack s from the coefficient arrays in LDS.
 // Returns the number of segments (wave-uniform); the list is in W.seglo / W.seghi.
-__device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, int lane, double s, int *overflow) {
+__device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, int lane, double s, int *overflow, DnProf &pf,
+                                      unsigned long long relbits) {
     // pass 1: bounds of this lane's constraints
     double L = -QM_INF, H = QM_INF;
     int mH = 0;
@@ -622,10 +647,10 @@ __device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, in
         if (k == 0) continue;
         const double t2 = W.t2[k], t1 = W.t1[k];
         if (t2 == 0.0 && t1 == 0.0) continue;   // qcqp.py:116,166
-        const Seg2 iv = feasible_intervals(t2, t1, W.t0[k], D.relop[k], s);
+        const Seg2 iv = feasible_intervals(t2, t1, W.t0[k], (int)((relbits >> (2 * j)) & 3ull), s);
         if (iv.n == 0) { empty = true; continue; }
         const double lo = iv.lo0, hi = (iv.n == 2) ? iv.hi1 : iv.hi0;
-        if (iv.n == 2) n2 |= 1u << j;
+        if (iv.n == 2) { n2 |= 1u << j; W.fga[k] = iv.hi0; W.fgb[k] = iv.lo1; }   // same lane reads them back in pass 2
         L = lo > L ? lo : L;
         if (hi < H) { H = hi; mH = 1; } else if (hi == H) mH++;
     }
@@ -641,7 +666,8 @@ __device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, in
             mHg += __builtin_amdgcn_readlane(mH, l);
         }
     }
-    // pass 2: gaps that cut into [Lg, Hg]  (two-interval constraints only, recomputed)
+    pf.tick(2);
+    // pass 2: gaps that cut into [Lg, Hg]  (two-interval constraints only)
     int ng = 0;
     const int kpt = (D.m1 + 63) >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -651,8 +677,7 @@ __device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, in
             bool has = false;
             double ga = 0.0, gb = 0.0;
             if ((n2 >> jj) & 1u) {
-                const Seg2 iv = feasible_intervals(W.t2[k], W.t1[k], W.t0[k], D.relop[k], s);
-                ga = iv.hi0; gb = iv.lo1;
+                ga = W.fga[k]; gb = W.fgb[k];
                 has = gb > Lg && ga <= Hg;
             }
             const unsigned long long mk = __builtin_amdgcn_ballot_w64(has);
@@ -665,14 +690,21 @@ __device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, in
     }
     if (ng > DN_GC) { *overflow = 1; ng = DN_GC; }
     dn_wave_sync();
+    pf.tick(3);
     if (lane == 0) {
         int ns = 0;
         if (!anyempty && Lg <= Hg) ns = dn_sweep_segments(W.gapa, W.gapb, ng, W.seglo, W.seghi, Lg, Hg, mHg, overflow);
         W.misc[0] = ns;
     }
     dn_wave_sync();
-    return __builtin_amdgcn_readfirstlane(W.misc[0]);
+    const int nsu = __builtin_amdgcn_readfirstlane(W.misc[0]);
+    if (pf.on) pf.t[9]++;
+    pf.tick(4);
+    return nsu;
 }
+
+// entry (c2, c) of the diagonal blocks: Dg[16 c2 + c][k]
+__device__ inline double Dc2(const double *Dg, int c2, int c, int m1p, int k) { return Dg[((int64_t)c2 * 16 + c) * m1p + k]; }
 
 // GLDS: the restart's 16 rows of G (K-split partials summed) are staged in LDS in one burst of
 // coalesced loads at kernel start instead of being fetched coordinate by coordinate.
@@ -687,10 +719,13 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
     if (gr >= a.R) return;            // no workgroup barrier anywhere below: waves are independent
     if (!a.S.on[gr]) return;
     const int m1 = D.m1, m1p = D.m1p;
+    DnProf pf;
+    pf.start(a.prof != nullptr && gr == 0);
     DnWave W;
     {
-        double *sp = smem + (size_t)wave * ((GLDS ? 20 : 4) * (size_t)m1p + DN_LDS_WAVE);
+        double *sp = smem + (size_t)wave * ((GLDS ? 16 + DN_FARR : DN_FARR) * (size_t)m1p + DN_LDS_WAVE);
         W.t2 = sp; sp += m1p; W.t1 = sp; sp += m1p; W.t0 = sp; sp += m1p; W.F = sp; sp += m1p;
+        W.fga = sp; sp += m1p; W.fgb = sp; sp += m1p;
         W.gapa = sp; sp += DN_GC; W.gapb = sp; sp += DN_GC;
         W.seglo = sp; sp += DN_SC; W.seghi = sp; sp += DN_SC;
         W.xb = sp; sp += 16; W.dlt = sp; sp += 16;
@@ -703,20 +738,26 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
     double *Xt = a.X + tile * D.n16 * 16;
     double *Ftr = a.Ft + gr * m1p;
     for (int k = lane; k < m1; k += 64) W.F[k] = Ftr[k];
+    // relop of the lane's functions, 2 bits per slot (m1p <= 2048)
+    unsigned long long relbits = 0ull;
+    {
+        int j = 0;
+        for (int k = lane; k < m1; k += 64, j++) relbits |= (unsigned long long)(D.relop[k] & 3) << (2 * j);
+    }
     if (GLDS) {
         const double *Gr = a.G + (tile * 256 + r) * m1p;   // row c of this restart: + c * 16 * m1p
-        const int tot = 16 * m1p;
+        const int tot2 = 8 * m1p;                          // pairs of doubles (m1p is a multiple of 64: rows stay 16-byte aligned)
 #pragma unroll 4
-        for (int idx = lane; idx < tot; idx += 64) {
-            const int c = idx / m1p, k = idx - c * m1p;
-            const double *g0 = Gr + (int64_t)c * 16 * m1p + k;
-            double gz[8];
+        for (int idx = lane; idx < tot2; idx += 64) {
+            const int c = (2 * idx) / m1p, k = 2 * idx - c * m1p;
+            const dn_v2d *g0 = reinterpret_cast<const dn_v2d *>(Gr + (int64_t)c * 16 * m1p + k);
+            dn_v2d gz[8];
 #pragma unroll
-            for (int z = 0; z < 8; z++) gz[z] = (z < a.zs) ? g0[(int64_t)z * a.gz_stride] : 0.0;
-            double g = gz[0];
+            for (int z = 0; z < 8; z++) gz[z] = (z < a.zs) ? g0[(int64_t)z * (a.gz_stride / 2)] : dn_v2d{0.0, 0.0};
+            dn_v2d g = gz[0];
 #pragma unroll
             for (int z = 1; z < 8; z++) g += gz[z];   // K-split partials, fixed order (absent planes add 0)
-            W.G[idx] = g;
+            *reinterpret_cast<dn_v2d *>(W.G + 2 * idx) = g;
         }
     }
     if (lane < 16) { W.xb[lane] = Xt[(16 * (int64_t)b + lane) * 16 + r]; W.dlt[lane] = 0.0; }
@@ -729,46 +770,68 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
     dn_wave_sync();
     const int cmax = (D.n - 16 * (int64_t)b) < 16 ? (int)(D.n - 16 * (int64_t)b) : 16;
     const SegList SL{W.seglo, W.seghi, nullptr, 0};
+    pf.tick(0);
 
     for (int c = 0; c < cmax && on; c++) {
         const int64_t i = 16 * (int64_t)b + c;
         const double xi = W.xb[c];
+        if (pf.on) pf.t[8]++;
         // ---- A. one-variable coefficients of the lane's functions (utilities.py:99-105)
         const double *Gc = a.G + ((tile * 16 + c) * 16 + r) * m1p;
         const double *Dc = a.Dg + (int64_t)(c * 16) * m1p;
         const double *qi = D.qT + i * m1p;
         double vloc = -QM_INF;
         bool inv = false;
-        for (int k = lane; k < m1; k += 64) {
-            double g;
-            if (GLDS) g = W.G[c * m1p + k];
-            else {
-                g = Gc[k];
-                for (int z = 1; z < a.zs; z++) g += Gc[(int64_t)z * a.gz_stride + k];   // K-split partials, fixed order
-            }
-            unsigned mm = mvmask;
-            while (mm) {   // Gauss-Seidel inside the block: moves made so far, in coordinate order
-                const int c2 = __builtin_ctz(mm);
-                mm &= mm - 1;
-                g = __builtin_fma(Dc[(int64_t)c2 * m1p + k], W.dlt[c2], g);
-            }
-            const double t2 = Dc[(int64_t)c * m1p + k];
-            const double t1 = 2.0 * (g - t2 * xi) + qi[k];
-            const double t0 = W.F[k] - xi * (t2 * xi + t1);
-            W.t2[k] = t2; W.t1[k] = t1; W.t0[k] = t0;
-            if (PHASE == 1 && k > 0 && !(t2 == 0.0 && t1 == 0.0)) {
-                const double f = xi * (t2 * xi + t1) + t0;
-                const double v = (D.relop[k] == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
-                vloc = v > vloc ? v : vloc;
-                inv = true;
+        // the diagonal entry and the linear coefficient of the first DN_PF slots are requested in one batch (one round
+        // trip instead of one per slot)
+        double pt2[DN_PF], pq[DN_PF];
+#pragma unroll
+        for (int j = 0; j < DN_PF; j++) {
+            const int k = lane + 64 * j;
+            const bool in = k < m1;
+            pt2[j] = in ? Dc[(int64_t)c * m1p + k] : 0.0;
+            pq[j] = in ? qi[k] : 0.0;
+        }
+        {
+            int j = 0;
+            for (int k = lane; k < m1; k += 64, j++) {
+                double g;
+                if (GLDS) g = W.G[c * m1p + k];            // kept current by the commits of this block (below)
+                else {
+                    g = Gc[k];
+                    for (int z = 1; z < a.zs; z++) g += Gc[(int64_t)z * a.gz_stride + k];   // K-split partials, fixed order
+                    unsigned mm = mvmask;
+                    while (mm) {   // Gauss-Seidel inside the block: moves made so far, in coordinate order
+                        const int c2 = __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        g = __builtin_fma(Dc[(int64_t)c2 * m1p + k], W.dlt[c2], g);
+                    }
+                }
+                double t2, ql;
+                if (j < DN_PF) {
+                    // static indexing of the register batch (j is wave-uniform)
+                    t2 = pt2[0]; ql = pq[0];
+#pragma unroll
+                    for (int u = 1; u < DN_PF; u++) if (j == u) { t2 = pt2[u]; ql = pq[u]; }
+                } else { t2 = Dc[(int64_t)c * m1p + k]; ql = qi[k]; }
+                const double t1 = 2.0 * (g - t2 * xi) + ql;
+                const double t0 = W.F[k] - xi * (t2 * xi + t1);
+                W.t2[k] = t2; W.t1[k] = t1; W.t0[k] = t0;
+                if (PHASE == 1 && k > 0 && !(t2 == 0.0 && t1 == 0.0)) {
+                    const double f = xi * (t2 * xi + t1) + t0;
+                    const double v = ((int)((relbits >> (2 * j)) & 3ull) == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+                    vloc = v > vloc ? v : vloc;
+                    inv = true;
+                }
             }
         }
         bool moved = false;
         double xn = xi;
         visits++;
+        pf.tick(1);
         if (PHASE == 2) {
             // ---- B. feasible set at the fixed slack, minimiser of the scalar objective
-            const int ns = dn_feasible_set(W, D, lane, slack, &overflow);
+            const int ns = dn_feasible_set(W, D, lane, slack, &overflow, pf, relbits);
             int got = 0;
             if (lane == 0) {
                 SegList C = SL;
@@ -800,7 +863,7 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
                 bool pending = false;
                 while (es - ss > a.tol) {
                     const double sm = (ss + es) / 2.0;
-                    const int ns = dn_feasible_set(W, D, lane, sm, &overflow);
+                    const int ns = dn_feasible_set(W, D, lane, sm, &overflow, pf, relbits);
                     const uint32_t itc = it++;
                     if (ns == 0) { ss = sm; continue; }
                     bool unb = false;
@@ -843,14 +906,26 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
                 }
             }
         }
+        pf.tick(5);
         // ---- C. commit: x_i, the block-local move list, f_k(x) += delta (t2 (xn + xi) + t1)
         if (moved) {
             const double d = xn - xi;
             if (lane == 0) { W.xb[c] = xn; W.dlt[c] = d; }
             mvmask |= 1u << c;
             for (int k = lane; k < m1; k += 64) W.F[k] += d * (W.t2[k] * (xn + xi) + W.t1[k]);
+            if (GLDS) {
+                // Gauss-Seidel inside the block: the rows of the coordinates still to come take the move at once --
+                // the same fused multiply-adds in the same order as adding the moves made so far at every visit, but
+                // the loads are independent of each other and go out together
+                for (int k = lane; k < m1; k += 64) {
+#pragma unroll 5
+                    for (int c2 = c + 1; c2 < cmax; c2++)
+                        W.G[c2 * m1p + k] = __builtin_fma(Dc2(a.Dg, c2, c, m1p, k), d, W.G[c2 * m1p + k]);
+                }
+            }
             dn_wave_sync();
         }
+        pf.tick(6);
     }
     dn_wave_sync();
     if (lane < 16) Xt[(16 * (int64_t)b + lane) * 16 + r] = W.xb[lane];
@@ -859,6 +934,10 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
         a.S.live[gr] = live ? 1 : 0; a.S.on[gr] = on ? 1 : 0;
         a.S.upd[gr] = upd; a.S.visits[gr] = visits; a.S.accepted[gr] = accepted;
         a.S.status[gr] = overflow ? -4 : status;
+    }
+    if (pf.on) {
+        pf.tick(7);
+        if (lane == 0) for (int i = 0; i < 10; i++) a.prof[i + (PHASE == 1 ? 0 : 16)] += pf.t[i];
     }
 }
 

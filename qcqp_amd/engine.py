@@ -387,6 +387,11 @@ class Engine(object):
         the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""
         self._chk(self.L.qcqpmi_cd_reference_order(self.h, 1 if enable else 0))
 
+    def dense_chain_mode(self, mode=0):
+        """Chain kernel of the dense-constraint path: 0 four waves per restart (default), 1 one wave per restart (the
+        round-2 kernel, kept as the cross-check; same points bit for bit)."""
+        self._chk(self.L.qcqpmi_dense_chain_mode(self.h, int(mode)))
+
     def sync(self):
         self._chk(self.L.qcqpmi_sync(self.h))
 

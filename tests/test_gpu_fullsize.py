@@ -58,7 +58,7 @@ def test_config5_dense_full_size(eng_mod, orc):
     t0 = time.time()
     out = e.cd_run(phase1=True, num_iters=1, seed=seed, first_index=0)
     t_run = time.time() - t0
-    assert e.last_cd_kernel() == 'dense_chain_kernel'
+    assert e.last_cd_kernel() == 'dense_chain_mw_kernel'
     X1 = e.download()
     g0, gv, G = e.eval(want_F=True)
     assert rel(out['f0'], g0) < 1e-9 and np.max(np.abs(out['maxviol'] - gv)) < 1e-9 * (1 + np.max(gv))

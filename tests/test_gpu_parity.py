@@ -441,7 +441,7 @@ def test_cd_more_than_four_constraints_per_coordinate(eng_mod, orc, per_coord, n
     X0 = 1.3 * np.random.RandomState(6).randn(n, R)
     e.upload(X0)
     out = e.cd_run(phase1=True, num_iters=iters, seed=seed, first_index=first)
-    assert e.last_cd_kernel() == ('cd_general_kernel' if n <= 64 else 'dense_chain_kernel')
+    assert e.last_cd_kernel() == ('cd_general_kernel' if n <= 64 else 'dense_chain_mw_kernel')
     X = e.download()
     same = 0
     for r in range(R):
@@ -501,7 +501,7 @@ def test_dense_path_phase2_matches_reference_golden(eng_mod, name):
     e.L.qcqpmi_debug_profile(e.h, DENSE_PATH, None)
     e.upload(z['X0'])
     out = e.cd_run(phase1=False)
-    assert e.last_cd_kernel() == 'dense_chain_kernel'
+    assert e.last_cd_kernel() == 'dense_chain_mw_kernel'
     X = e.download()
     assert rel(X, z['p2_x']) < 1e-6
     assert rel(out['f0'], z['p2_fv'][:, 0]) < 1e-6
@@ -558,7 +558,7 @@ def test_dense_path_default_dispatch_vs_oracle(eng_mod, orc):
     X0 = 1.5 * np.random.RandomState(2).randn(n, R)
     e.upload(X0)
     out = e.cd_run(phase1=True, num_iters=iters, seed=seed, first_index=first)
-    assert e.last_cd_kernel() == 'dense_chain_kernel'
+    assert e.last_cd_kernel() == 'dense_chain_mw_kernel'
     X = e.download()
     exact = 0
     for r in range(R):

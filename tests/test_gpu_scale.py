@@ -638,7 +638,7 @@ def test_streaming_upload_of_coupled_constraints(eng_mod, orc, monkeypatch):
         f0, mv, F = e.eval_batch(X0, want_F=True)
         e.upload(X0)
         out = e.cd_run(phase1=True, num_iters=4, seed=7, first_index=3)
-        assert e.last_cd_kernel() == 'dense_chain_kernel'
+        assert e.last_cd_kernel() == 'dense_chain_mw_kernel'
         res.append((F, e.download(), out))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     for key in ('f0', 'maxviol', 'sweeps1', 'visits2', 'accepted2'):

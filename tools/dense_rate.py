@@ -8,11 +8,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qcqp_amd import problems
 from qcqp_amd.engine import Engine
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-m = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-Rs = [int(a) for a in sys.argv[3:]] or [512, 4096]
+ARGS = [a for a in sys.argv[1:] if not a.startswith('--')]
+n = int(ARGS[0]) if len(ARGS) > 0 else 1024
+m = int(ARGS[1]) if len(ARGS) > 1 else 256
+Rs = [int(a) for a in ARGS[2:]] or [512, 4096]
 form = problems.dense_indefinite_generated(n, m, seed=7)
 e = Engine(form)
+e.dense_chain_mode(1 if '--one-wave' in sys.argv else 0)
 for R in Rs:
     e.randn(R, seed=5)
     e.cd_run(phase1=True, num_iters=1, seed=5)
