@@ -292,6 +292,10 @@ int qcqpmi_cd_reference_order(qcqpmi_ctx *ctx, int enable);
  * the functions dealt to 256 threads -- whenever m + 1 <= 2048; 1: dense_chain_kernel, one wave per restart (round 1-2
  * kernel, the cross-check: the two produce the same points bit for bit). */
 int qcqpmi_dense_chain_mode(qcqpmi_ctx *ctx, int mode);
+/* Geometry of dense_chain_mw_kernel for m constraints (host-only, no device call): out4 = {slots per thread, threads that
+ * hold constraints Tc, index of the serial thread (holds the objective), threads per restart}.  Constraint k = 1..m is
+ * slot (k - 1) / Tc of thread (k - 1) % Tc.  More than 8 slots: the one-wave kernel is used instead. */
+int qcqpmi_dense_chain_geometry(int64_t m, int *out4);
 int qcqpmi_sync(qcqpmi_ctx *ctx);
 /* debug: enable in-kernel cycle counters of the phase-2 kernel / read their sums over tiles
  * (slots: 0 mfma, 1 feasible sets, 2 barrier, 3 sequential part, 4 barrier, 5 #blocks) */

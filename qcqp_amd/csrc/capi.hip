@@ -1712,6 +1712,13 @@ int qcqpmi_last_kernel_ms(qcqpmi_ctx *c, int which, double *ms) {
     return 0;
 }
 
+int qcqpmi_dense_chain_geometry(int64_t m, int *out4) {
+    if (m < 0 || m > (1 << 24) || !out4) return QCQPMI_EINVAL;
+    const MwGeom g = mw_geometry((int)m + 1);
+    out4[0] = g.SL; out4[1] = g.Tc; out4[2] = g.ts; out4[3] = g.T;
+    return 0;
+}
+
 int qcqpmi_dense_chain_mode(qcqpmi_ctx *c, int mode) {
     if (!c || mode < 0 || mode > 1) return QCQPMI_EINVAL;
     c->dense_chain_mode = mode;

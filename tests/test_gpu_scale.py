@@ -651,3 +651,34 @@ def test_streaming_upload_of_coupled_constraints(eng_mod, orc, monkeypatch):
     e_str.upload(X0)
     with pytest.raises(eng_mod.EngineError, match='reference-order'):
         e_str.cd_run(phase1=True, num_iters=1, seed=7)
+
+
+# ------------------------------------------------------------------ the chain kernels of the dense path (round 3)
+@pytest.mark.parametrize('n,m,R,geom', [(250, 33, 100, (1, 64, 33, 64)),      # a free lane of the only wave is the serial thread
+                                        (256, 64, 512, (1, 64, 64, 128)),     # full waves of constraints: an extra wave
+                                        (1024, 256, 96, (1, 256, 256, 320)),  # BASELINE.json configs[4] family at the bench size
+                                        (128, 600, 48, (2, 320, 320, 384)),   # two slots per thread (rows of G still in registers)
+                                        (128, 1100, 32, (3, 384, 384, 448))]) # three slots: rows fetched visit by visit
+def test_dense_chain_kernels_agree_bit_for_bit(eng_mod, n, m, R, geom):
+    """dense_chain_mw_kernel (up to eight waves per restart, csrc/cd_dense_mw.h) against dense_chain_kernel (one wave per
+    restart, the round-1/2 kernel): same expressions in the same order of operations per function, reductions over exact
+    maxima / minima, a sorted gap list -- the points, values and counters must be IDENTICAL, phase 1 (bisection on the slack,
+    qcqp.py:101-149) and phase 2 (qcqp.py:152-178).  `geom` = (slots per thread, constraint threads, serial thread, threads)
+    documents the geometry each case exercises (mw_geometry)."""
+    from qcqp_amd import problems
+    form = problems.dense_indefinite_generated(n, m, seed=11)
+    res = []
+    for mode, name in ((0, 'dense_chain_mw_kernel'), (1, 'dense_chain_kernel')):
+        e = eng_mod.Engine(form)
+        e.dense_chain_mode(mode)
+        e.randn(R, seed=3)
+        out = e.cd_run(phase1=True, num_iters=3, seed=9)
+        assert e.last_cd_kernel() == name
+        res.append((e.download(), out))
+    (X0, o0), (X1, o1) = res
+    assert np.array_equal(X0, X1)
+    for key in ('f0', 'maxviol', 'sweeps1', 'sweeps2', 'visits2', 'accepted2'):
+        assert np.array_equal(o0[key], o1[key]), key
+    assert o0['sweeps1'].sum() > 0
+    if m < n:        # feasible families reach phase 2 (more constraints than variables: phase 1 only)
+        assert o0['accepted2'].sum() > 0

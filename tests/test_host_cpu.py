@@ -371,3 +371,29 @@ def test_cvxpy_adapter_keeps_bilinear_only_terms():
     lin = Expr(lambda: (calls.__setitem__(0, calls[0] + 1), float(x.value[0]))[1], ())
     problem_from_cvxpy(Prob(Objective('minimize', lin), sep, [x]))
     assert calls[0] == 1 + 2 * n + 2 * (n + 1)
+
+
+def test_dense_chain_geometry_tiles_the_constraints():
+    """dense_chain_mw_kernel deals the constraints to (thread, slot) pairs and gives the objective to the serial thread
+    (csrc/cd_dense_mw.h, mw_geometry): every constraint exactly once, the serial thread holds no constraint in slot 0, whole
+    waves, at most 512 threads.  Host-only entry point (no device call)."""
+    import ctypes
+    from qcqp_amd import _ffi
+    L = _ffi.lib()
+    out = (ctypes.c_int * 4)()
+    for m in list(range(0, 70)) + [127, 128, 129, 255, 256, 257, 447, 448, 449, 511, 512, 513, 1024, 2047, 3583, 3584, 3585, 5000]:
+        assert L.qcqpmi_dense_chain_geometry(m, out) == 0
+        SL, Tc, ts, T = out[0], out[1], out[2], out[3]
+        assert T % 64 == 0 and Tc % 64 == 0 and 64 <= T <= 512 and Tc <= T and ts < T, (m, SL, Tc, ts, T)
+        seen = set()
+        for tid in range(Tc):
+            for j in range(SL):
+                k = 1 + tid + Tc * j
+                if k <= m:
+                    assert k not in seen
+                    seen.add(k)
+        assert seen == set(range(1, m + 1)), m
+        # slot 0 of the serial thread is free for the objective
+        assert ts >= Tc or 1 + ts > m, (m, ts, Tc)
+        if SL == 1:
+            assert ts == (m if m < Tc else Tc)
