@@ -126,6 +126,8 @@ struct qcqpmi_ctx {
     std::vector<double> p0_diag_host;
     // outputs of a run packed into one device buffer, copied with ONE transfer into pinned host memory
     char *d_out = nullptr, *h_out = nullptr;
+    char *h_pin = nullptr;                // pinned bounce buffer of the relaxation solver's downloads (pin_reserve)
+    size_t h_pin_cap = 0;
     int64_t out_cap = 0;
     int eval_zs = 1;   // planes of the last dense evaluation
     double *d_wS = nullptr, *d_wY = nullptr, *d_ww = nullptr, *d_wz = nullptr;   // qcqpmi_pop_weighted_product work buffers
@@ -301,6 +303,18 @@ __global__ void pack_cd_outputs_kernel(char *out, int64_t R, const int64_t *s1, 
     int *oi = (int *)(out + 48 * R);
     oi[r] = st[r]; oi[R + r] = st1[r];
     ((uint8_t *)(out + 56 * R))[r] = flag[r];
+}
+
+// pinned host memory for downloads that are repeated thousands of times (a 2-D copy into pageable memory is staged row by
+// row by the runtime: 1025 rows of 47 doubles cost 15 ms)
+int pin_reserve(qcqpmi_ctx *c, size_t bytes) {
+    if (bytes <= c->h_pin_cap) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    c->h_pin = nullptr; c->h_pin_cap = 0;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_pin, bytes, hipHostMallocDefault));
+    c->h_pin_cap = bytes;
+    return 0;
 }
 
 int fetch_cd_outputs(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
@@ -759,6 +773,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
                     c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext};
     if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &t : c->timers) { if (t.beg) (void)hipEventDestroy(t.beg); if (t.end) (void)hipEventDestroy(t.end); }
     for (auto &e : c->dn_ev) if (e) (void)hipEventDestroy(e);
@@ -1287,9 +1302,12 @@ int qcqpmi_pop_weighted_product(qcqpmi_ctx *c, const double *w, double *Y) {
         c->wY_cap = c->Rpad * n16;
     }
     double *dw = c->d_ww, *dS = c->d_wS, *dY = c->d_wY, *dz = c->d_wz;
+    if ((rc = pin_reserve(c, (size_t)(c->R * c->n) * sizeof(double) + (size_t)D.m1 * sizeof(double)))) return rc;
+    char *hw = c->h_pin + (size_t)(c->R * c->n) * sizeof(double);       // the weights go up through pinned memory too
+    memcpy(hw, w, (size_t)D.m1 * sizeof(double));
     hipError_t e = hipSuccess;
     if (!rc) {
-        e = hipMemcpyAsync(dw, w, (size_t)D.m1 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        e = hipMemcpyAsync(dw, hw, (size_t)D.m1 * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(dense_wsum_pack_kernel, dim3((unsigned)((n16 * n16 + 255) / 256)), dim3(256), 0, c->stream, D, (const double *)dw, dS);
             DenseProdArgs pa;
@@ -1305,10 +1323,11 @@ int qcqpmi_pop_weighted_product(qcqpmi_ctx *c, const double *w, double *Y) {
                 hipLaunchKernelGGL(from_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                                    (const double *)dY, c->d_stage, c->n, c->n16, c->R);
                 e = hipGetLastError();
-                if (e == hipSuccess) e = hipMemcpyAsync(Y, c->d_stage, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(c->h_pin, c->d_stage, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
             }
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) memcpy(Y, c->h_pin, (size_t)(c->R * c->n) * sizeof(double));
     }
     if (rc) return rc;
     if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "pop_weighted_product: %s", hipGetErrorString(e));
@@ -1364,11 +1383,17 @@ int qcqpmi_pop_eval_parts(qcqpmi_ctx *c, double *quad, double *lin) {
     if ((rc = eval_parts_dense(c))) return rc;
     const int64_t m1 = c->m + 1;
     const double *dlin = c->d_F + (int64_t)c->eval_zs * m1 * c->Rpad;
-    HIPCHK(c, hipMemcpy2DAsync(quad, (size_t)c->R * sizeof(double), c->d_F, (size_t)c->Rpad * sizeof(double),
-                               (size_t)c->R * sizeof(double), (size_t)m1, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(lin, (size_t)c->R * sizeof(double), dlin, (size_t)c->Rpad * sizeof(double),
-                               (size_t)c->R * sizeof(double), (size_t)m1, hipMemcpyDeviceToHost, c->stream));
+    // the two planes ([m1][Rpad], contiguous) through pinned memory in one copy each, the padding columns dropped on the host
+    const size_t plane = (size_t)m1 * c->Rpad * sizeof(double);
+    if ((rc = pin_reserve(c, 2 * plane))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_F, plane, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + plane, dlin, plane, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double *hq = (const double *)c->h_pin, *hl = (const double *)(c->h_pin + plane);
+    for (int64_t k = 0; k < m1; k++) {
+        memcpy(quad + k * c->R, hq + k * c->Rpad, (size_t)c->R * sizeof(double));
+        memcpy(lin + k * c->R, hl + k * c->Rpad, (size_t)c->R * sizeof(double));
+    }
     c->evaluated = false;    // plane 0 no longer holds the full function values
     return 0;
 }

@@ -157,8 +157,15 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
     const DenseProblem &D = a.D;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
     const int f0 = DP_FG * blockIdx.x, tg0 = DP_TG * blockIdx.y, z = blockIdx.z;
+    // narrow tile group (at most 4 tiles of candidates: few restarts, the 47-column factor of the relaxation solver): the
+    // four waves split the 8 FUNCTIONS (2 each) and all walk the same 4 tile slots -- with the 2 x 2 arrangement the two
+    // waves of the upper tile slots would have nothing to multiply and half of the SIMDs would idle.  (MODE 2 keeps the
+    // 2 x 2 arrangement: its partial planes are indexed by the wave row.)
+    const bool narrow = MODE != 2 && a.ntiles - tg0 <= 4;
+    const int nu = narrow ? 2 : 4;                                   // functions per wave
+    const int wm = narrow ? 0 : (wave >> 1), wn = narrow ? 0 : (wave & 1);
+    const int fw = narrow ? 2 * wave : 4 * wm;                       // first function of this wave inside the group
     if (MODE == 0 && a.tile_on) {   // uniform for the workgroup
         bool any = false;
         for (int t = 0; t < DP_TG; t++) any = any || (tg0 + t < a.ntiles && a.tile_on[tg0 + t]);
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
         fs[p] = (MODE >= 2) ? (f < D.NB ? f : D.NB - 1) : (f < D.m1 ? f : D.m1 - 1);   // clamped: loaded, multiplied, never stored
         ts[p] = t < a.ntiles ? t : a.ntiles - 1;
     }
-    const int kf0 = f0 + 4 * wm, tl0 = tg0 + 4 * wn;   // this wave's functions / tiles
+    const int kf0 = f0 + fw, tl0 = tg0 + 4 * wn;   // this wave's functions / tiles
     const int vt = (a.ntiles - tl0) < 4 ? ((a.ntiles - tl0) > 0 ? a.ntiles - tl0 : 0) : 4;   // valid tile slots of this wave
     double fa[4][4];
 #pragma unroll
@@ -208,16 +215,16 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
         }
         dn_v2d pf[8];
 #pragma unroll
-        for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)stage_of(ch_lo) * 256);
+        for (int p = 0; p < 8; p++) { pf[p] = dn_v2d{0.0, 0.0}; if (!(narrow && p >= 6)) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)stage_of(ch_lo) * 256); }   // narrow: tile slots 4-7 are never multiplied
         int buf = 0;
         __syncthreads();   // the previous row block's readers are done with both buffers
 #pragma unroll
         for (int p = 0; p < 8; p++)
-            *reinterpret_cast<dn_v2d *>(smem + ((buf * 16 + 2 * p + half) * 256 + off)) = pf[p];
+            if (!(narrow && p >= 6)) *reinterpret_cast<dn_v2d *>(smem + ((buf * 16 + 2 * p + half) * 256 + off)) = pf[p];
         {
             const int c1 = (ch_lo + 1 < ch_hi) ? ch_lo + 1 : ch_lo;
 #pragma unroll
-            for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)stage_of(c1) * 256);
+            for (int p = 0; p < 8; p++) if (!(narrow && p >= 6)) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)stage_of(c1) * 256);
         }
         __syncthreads();
         // Stage ch multiplies out of `buf`.  The registers hold stage ch+1, fetched a whole stage ago:
@@ -226,11 +233,11 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
         for (int ch = ch_lo; ch < ch_hi; ch++) {
 #pragma unroll
             for (int p = 0; p < 8; p++)
-                *reinterpret_cast<dn_v2d *>(smem + (((buf ^ 1) * 16 + 2 * p + half) * 256 + off)) = pf[p];
+                if (!(narrow && p >= 6)) *reinterpret_cast<dn_v2d *>(smem + (((buf ^ 1) * 16 + 2 * p + half) * 256 + off)) = pf[p];
             const int chn = (ch + 2 < ch_hi) ? ch + 2 : ch_hi - 1;
 #pragma unroll
-            for (int p = 0; p < 8; p++) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)stage_of(chn) * 256);
-            const double *As = smem + (buf * 16 + 4 * wm) * 256 + lane;
+            for (int p = 0; p < 8; p++) if (!(narrow && p >= 6)) pf[p] = *reinterpret_cast<const dn_v2d *>(src[p] + (int64_t)stage_of(chn) * 256);
+            const double *As = smem + (buf * 16 + fw) * 256 + lane;
             const double *Bs = smem + (buf * 16 + 8 + 4 * wn) * 256 + lane;
             if (MODE == 0) {
                 double av[DP_KC][4], bv[DP_KC][4];
@@ -244,8 +251,10 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
                     for (int t = 0; t < 4; t++) {
                         if (t >= vt) continue;   // wave-uniform: tile slot beyond the population (small populations)
 #pragma unroll
-                        for (int u = 0; u < 4; u++)
+                        for (int u = 0; u < 4; u++) {
+                            if (u >= nu) continue;   // wave-uniform (narrow tile group)
                             acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][u], bv[ks][t], acc[u][t], 0, 0, 0);
+                        }
                     }
             } else {
                 // the quadratic-form accumulators need 32 more registers: operands two k-steps at a time
@@ -262,8 +271,10 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
                         for (int t = 0; t < 4; t++) {
                             if (t >= vt) continue;   // wave-uniform
 #pragma unroll
-                            for (int u = 0; u < 4; u++)
+                            for (int u = 0; u < 4; u++) {
+                                if (u >= nu) continue;   // wave-uniform (narrow tile group)
                                 acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][u], bv[ks][t], acc[u][t], 0, 0, 0);
+                            }
                         }
                 }
             }
@@ -282,13 +293,13 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
                     double *g = Gz + (((int64_t)(tl0 + t) * 16 + c) * 16 + r) * D.m1p + kf0;
 #pragma unroll
                     for (int u = 0; u < 4; u++)
-                        if (kf0 + u < D.m1) g[u] = acc[u][t][v];
+                        if (u < nu && kf0 + u < D.m1) g[u] = acc[u][t][v];
                 }
             }
         } else if (MODE == 3) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (kf0 + u >= D.NB) continue;   // wave-uniform
+                if (u >= nu || kf0 + u >= D.NB) continue;   // wave-uniform
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     if (tl0 + t >= a.ntiles) continue;
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
         } else if (MODE == 2) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (kf0 + u >= D.NB) continue;   // wave-uniform
+                if (u >= nu || kf0 + u >= D.NB) continue;   // wave-uniform
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     const int64_t i = 16 * (int64_t)(kf0 + u) + (lane >> 4) + 4 * v;
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void dense_products_kernel(DenseProdArgs a)
                 double s = fa[u][t];
                 s += __shfl_xor(s, 16);
                 s += __shfl_xor(s, 32);
-                if (lane < 16 && kf0 + u < D.m1 && tl0 + t < a.ntiles)
+                if (lane < 16 && u < nu && kf0 + u < D.m1 && tl0 + t < a.ntiles)
                     Fz[(int64_t)(kf0 + u) * a.Rpad + (int64_t)(tl0 + t) * 16 + lane] = s + (z == 0 ? D.r[kf0 + u] : 0.0);
             }
     }

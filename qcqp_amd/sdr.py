@@ -110,7 +110,92 @@ def _functions(form, engine=None):
     return Q, r, eq
 
 
-def _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inner, feas_tol, seed, verbose):
+class _LbfgsResult(object):
+    def __init__(self, x, f, nit, nfev):
+        self.x, self.fun, self.nit, self.nfev = x, f, nit, nfev
+
+
+def _lbfgs(fun_grad, x0, maxiter, maxfun, gtol, ftol, memory=20):
+    """Unconstrained L-BFGS (two-loop recursion, Armijo backtracking with a cubic / quadratic step model, curvature-guarded
+    updates) for the inner problems of the augmented Lagrangian.  Same stopping rules as SciPy's L-BFGS-B -- relative decrease
+    <= ftol, max |g| <= gtol, iteration / evaluation limits -- at a fraction of its host cost: on the 262 193 unknowns of the
+    full-size factor one call of L-BFGS-B's Fortran driver takes 33 ms (bound handling, Cauchy point, subspace step), this
+    loop 5 ms; the function / gradient evaluation it feeds is 70 ms of device work."""
+    x = np.array(x0, dtype=np.float64)
+    f, g = fun_grad(x)
+    g = np.array(g, dtype=np.float64)
+    nfev = 1
+    S, Y, RHO = [], [], []
+    nit = 0
+    while nit < maxiter and nfev < maxfun:
+        if np.max(np.abs(g)) <= gtol:
+            break
+        # two-loop recursion: d = -H g
+        q = g.copy()
+        al = [0.0] * len(S)
+        for i in range(len(S) - 1, -1, -1):
+            al[i] = RHO[i] * S[i].dot(q)
+            q -= al[i] * Y[i]
+        if S:
+            q *= S[-1].dot(Y[-1]) / Y[-1].dot(Y[-1])
+        for i in range(len(S)):
+            be = RHO[i] * Y[i].dot(q)
+            q += (al[i] - be) * S[i]
+        d = -q
+        gd = g.dot(d)
+        if not gd < 0.0:                     # not a descent direction: restart from steepest descent
+            S, Y, RHO = [], [], []
+            d = -g
+            gd = -g.dot(g)
+        t = 1.0 if S else min(1.0, 1.0 / max(np.sqrt(-gd), 1e-300))
+        f_new = g_new = None
+        t_prev = f_prev = None
+        ok = False
+        for _ in range(30):
+            if nfev >= maxfun:
+                break
+            x_new = x + t * d
+            f_new, g_new = fun_grad(x_new)
+            nfev += 1
+            if np.isfinite(f_new) and f_new <= f + 1e-4 * t * gd:
+                ok = True
+                break
+            # minimiser of the quadratic through f, gd, f(t) (cubic with the previous trial when there is one), safeguarded
+            if not np.isfinite(f_new):
+                t_next = 0.1 * t
+            elif t_prev is None:
+                t_next = -gd * t * t / (2.0 * (f_new - f - gd * t))
+            else:
+                r1 = f_new - f - gd * t
+                r2 = f_prev - f - gd * t_prev
+                den = t * t * t_prev * t_prev * (t - t_prev)
+                a_ = (t_prev * t_prev * r1 - t * t * r2) / den
+                b_ = (-t_prev ** 3 * r1 + t ** 3 * r2) / den
+                disc = b_ * b_ - 3.0 * a_ * gd
+                t_next = (-b_ + np.sqrt(disc)) / (3.0 * a_) if (a_ != 0.0 and disc >= 0.0) else -gd / (2.0 * b_)
+            t_prev, f_prev = t, f_new
+            t = float(min(max(t_next, 0.1 * t), 0.5 * t)) if np.isfinite(t_next) else 0.1 * t
+        if not ok:
+            break
+        g_new = np.array(g_new, dtype=np.float64)
+        s = x_new - x
+        y = g_new - g
+        sy = s.dot(y)
+        if sy > 1e-10 * np.sqrt(s.dot(s) * y.dot(y)):
+            S.append(s); Y.append(y); RHO.append(1.0 / sy)
+            if len(S) > memory:
+                S.pop(0); Y.pop(0); RHO.pop(0)
+        decrease = f - f_new
+        x, g = x_new, g_new
+        f_old, f = f, f_new
+        nit += 1
+        if decrease <= ftol * max(abs(f_old), abs(f), 1.0):
+            break
+    return _LbfgsResult(x, f, nit, nfev)
+
+
+def _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inner, feas_tol, seed, verbose, optimizer='own',
+                       inner0=None, growth=1.5):
     """Augmented-Lagrangian loop on the Burer-Monteiro factor V ((n+1) x rank) of the lifted matrix, shared by the
     dense and the separable operator sets.  values(V) -> h (m+1,): <M_k, V V'> for the objective (k = 0) and every
     constraint; gradient(V, ws, wN) -> d/dV of sum_k ws_k <M_k, V V'> + wN |t|^2 (V is the matrix `values` saw last)."""
@@ -149,8 +234,15 @@ def _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inne
         # inexact inner solves: no point in polishing the Lagrangian far below the current infeasibility
         rough = prev_infeas is not None and prev_infeas > 1e-4
         ftol = 1e-9 if (prev_infeas is None or rough) else 1e-15
-        res = minimize(fun_grad, V.ravel(), jac=True, method='L-BFGS-B',
-                       options=dict(maxiter=inner, maxfun=2 * inner, gtol=1e-9, ftol=ftol, maxcor=20))
+        # inexact inner solves, second part: while the multipliers are far from their limit a few dozen L-BFGS iterations per
+        # outer iteration move them as well as three hundred do (inner0 iterations at first, growing by `growth` per outer
+        # iteration up to `inner`)
+        cap = inner if inner0 is None else int(min(inner, inner0 * growth ** it))
+        if optimizer == 'scipy':
+            res = minimize(fun_grad, V.ravel(), jac=True, method='L-BFGS-B',
+                           options=dict(maxiter=cap, maxfun=2 * cap, gtol=1e-9, ftol=ftol, maxcor=20))
+        else:
+            res = _lbfgs(fun_grad, V.ravel(), cap, 2 * cap, 1e-9, ftol, memory=20)
         V = res.x.reshape(n + 1, rank)
         h = values(V) * sc
         tt = V[n, :].dot(V[n, :]) - 1.0
@@ -179,7 +271,8 @@ def _default_rank(m, rank):
     return int(min(max(rank, 2), 64))
 
 
-def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400, feas_tol=1e-6, seed=0, verbose=False):
+def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400, feas_tol=1e-6, seed=0, verbose=False, optimizer='own',
+                      inner0=20, growth=1.3):
     """SDP relaxation of ANY QCQP the dense path holds (constraints that couple coordinates), in the
     Burer-Monteiro form X = V V' (V: (n+1) x r, r(r+1)/2 > m+1) with an augmented Lagrangian on the
     constraints  <M_k, X> (<=, ==) 0,  X_nn = 1   (solve_sdr, qcqp.py:72-97).  The heavy linear algebra runs
@@ -196,25 +289,57 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
     sc = np.ones(m + 1)
     sc[1:] = 1.0 / (1.0 + np.abs(rr[1:]) + np.linalg.norm(Q[1:], axis=1) / np.sqrt(n))
     evals = [0]
+    import time as _time
+    tm = dict(upload=0.0, eval_parts=0.0, weighted_product=0.0, host_values=0.0, host_gradient=0.0)
 
     def values(Vm):
         Vx, t = Vm[:n, :], Vm[n, :]
+        t0 = _time.perf_counter()
         engine.upload(Vx)
+        t1 = _time.perf_counter()
         quad, lin = engine.eval_parts()          # x'P_k x + r_k and q_k'x per column, one pass on the device
+        t2 = _time.perf_counter()
         evals[0] += 1
-        return (quad - rr[:, None]).sum(axis=1) + lin.dot(t) + rr * t.dot(t)
+        h = (quad - rr[:, None]).sum(axis=1) + lin.dot(t) + rr * t.dot(t)
+        tm['upload'] += t1 - t0; tm['eval_parts'] += t2 - t1; tm['host_values'] += _time.perf_counter() - t2
+        return h
 
     def gradient(Vm, ws, wN):
         Vx, t = Vm[:n, :], Vm[n, :]
+        t0 = _time.perf_counter()
         SVx = engine.weighted_product(ws)                       # population = Vx (uploaded by values()): (sum_k ws_k P_k) Vx
+        t1 = _time.perf_counter()
+        tm['weighted_product'] += t1 - t0
+        try:
+            return _gradient_host(Vx, t, SVx, ws, wN)
+        finally:
+            tm['host_gradient'] += _time.perf_counter() - t1
+
+    def _gradient_host(Vx, t, SVx, ws, wN):
         qh = 0.5 * ws.dot(Q)                                    # sum_k ws_k q_k / 2
-        G = np.empty_like(Vm)
+        G = np.empty((n + 1, Vx.shape[1]))
         G[:n, :] = 2.0 * (SVx + np.outer(qh, t))
         G[n, :] = 2.0 * (qh.dot(Vx) + (ws.dot(rr) + wN) * t)
         return G
 
-    X, bound, info = _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inner, feas_tol, seed, verbose)
+    t_all = _time.perf_counter()
+    # OpenBLAS starts one spinning thread per core (64 on the GPU box) for the small products of the optimizer: they starve
+    # the HIP runtime's own threads -- 25 ms per device call at full size -- and make the level-1 products slower, not faster
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=4, user_api='blas')
+    except Exception:       # noqa: BLE001 -- optional dependency
+        limiter = None
+    try:
+        X, bound, info = _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inner, feas_tol, seed, verbose, optimizer,
+                                            inner0, growth)
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
     info['evals'] = evals[0]
+    tm['total'] = _time.perf_counter() - t_all
+    tm['optimizer_and_rest'] = tm['total'] - sum(v for k, v in tm.items() if k != 'total')
+    info['timing'] = tm          # seconds: where the wall time of the solve went
     return X, bound, info
 
 

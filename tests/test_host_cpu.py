@@ -397,3 +397,30 @@ def test_dense_chain_geometry_tiles_the_constraints():
         assert ts >= Tc or 1 + ts > m, (m, ts, Tc)
         if SL == 1:
             assert ts == (m if m < Tc else Tc)
+
+
+def test_own_lbfgs_matches_scipy_on_standard_problems():
+    """The L-BFGS loop of the relaxation solver (qcqp_amd/sdr.py::_lbfgs) reaches the same minimisers as SciPy's L-BFGS-B with
+    the same stopping rules: a convex quadratic (solution of A x = b) and the 20-dimensional Rosenbrock function."""
+    from scipy.optimize import minimize
+    from qcqp_amd.sdr import _lbfgs
+    rs = np.random.RandomState(0)
+    A = rs.randn(60, 60)
+    A = A.dot(A.T) + np.eye(60)
+    b = rs.randn(60)
+    r = _lbfgs(lambda x: (0.5 * x.dot(A.dot(x)) - b.dot(x), A.dot(x) - b), np.zeros(60), 500, 1000, 1e-9, 1e-15)
+    assert np.linalg.norm(A.dot(r.x) - b) < 1e-5 and r.nfev <= 1000
+
+    def ros(x):
+        f = np.sum(100 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2)
+        g = np.zeros_like(x)
+        g[:-1] = -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+        return f, g
+    r = _lbfgs(ros, np.zeros(20), 2000, 4000, 1e-9, 1e-15)
+    r2 = minimize(ros, np.zeros(20), jac=True, method='L-BFGS-B', options=dict(maxiter=2000, maxfun=4000, gtol=1e-9, ftol=1e-15, maxcor=20))
+    assert r.fun < 1e-12 and np.allclose(r.x, 1.0, atol=1e-6) and np.allclose(r.x, r2.x, atol=1e-5)
+    assert r.nfev < 2 * r2.nfev
+    # limits are honoured
+    r = _lbfgs(ros, np.zeros(20), 5, 4000, 1e-9, 1e-15)
+    assert r.nit == 5

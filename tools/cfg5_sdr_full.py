@@ -18,6 +18,7 @@ print('n=%d m=%d: %.1f GB of matrices on the device in %.1f s' % (n, m, (m + 1) 
 t0 = time.time(); X, bound, info = sdr.solve_sdr_general(e, form, outer=outer, inner=inner, verbose=True); t1 = time.time()
 print('SDP relaxation: %.1f s, %d evaluations (%.0f ms each), rank %d, %d outer iterations; value %.6g, dual value %.6g'
       % (t1 - t0, info['evals'], 1e3 * (t1 - t0) / info['evals'], info['rank'], len(info['hist']), bound, info['dual_value']), flush=True)
+print('   per evaluation (ms): ' + ', '.join('%s %.1f' % (k, 1e3 * v / info['evals']) for k, v in info['timing'].items()), flush=True)
 t0 = time.time(); lmin, S = sdr.dual_certificate_device(e, info['y'], info['yN']); t1 = time.time()
 print('dual certificate (dual matrix assembled on the device, eigvalsh on the host %.1f s): lambda_min %.3e (|S|max %.2e)' % (t1 - t0, lmin, np.abs(S).max()), flush=True)
 # samples from N(mu, Sigma) of the relaxation, then coordinate descent
