@@ -54,7 +54,7 @@ def profiled_counters():
 
 
 # ------------------------------------------------------------------------------------- secondary records
-def secondary_records(device):
+def secondary_records(device, sdr_full=False):
     """Bounded measurements of the other BASELINE.json configurations on ONE GPU (not part of `value`): the share of
     one rank, inputs resident, a few seconds in total.  Each record names its workload, kernel time and roofline."""
     import numpy as np
@@ -273,8 +273,8 @@ def secondary_records(device):
         recs.append({'config': 'BASELINE.json configs[4] family at n = 1024, m = 256 (full size is 137.6 GB of matrices): dense indefinite '
                                'QCQP generated on the device, COORD_DESCENT, 2 sweeps per phase; 512 restarts (first figures) and 4096',
                      'metric': 'restarts x coord-sweeps / s (phase 1 + phase 2)', 'value': pts[0]['value'], 'unit': 'restart-sweeps/s',
-                     'by_restarts': pts,
-                     'roofline': {'bound': 'mfma', 'kernel': 'dense_products_kernel (G_k = P_k X for all k) + dense chain',
+                     'by_restarts': pts, 'kernel': e.last_cd_kernel(),
+                     'roofline': {'bound': 'mfma', 'kernel': 'dense_products_kernel (G_k = P_k X for all k) + ' + e.last_cd_kernel(),
                                   'achieved': pts[0]['achieved'], 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': pts[0]['frac'],
                                   'algorithmic_flops_per_restart_sweep': 2.0 * n * n * (m + 1),
                                   'timing': 'value / frac: wall clock of the whole cd_run -- the two sweep loops (products, chain, host loop over '
@@ -282,10 +282,49 @@ def secondary_records(device):
                                             'phase 1; gate and slack, qcqp.py:189), each as expensive as the products of one sweep: with only '
                                             '2 sweeps per phase they are a third of the wall clock; *_sweep_loops: HIP events around the sweep '
                                             'loops alone'}})
+        # the SDP relaxation in front of it (suggest(SDR), qcqp.py:72-97): the engine's own Burer-Monteiro / augmented-Lagrangian
+        # solver on the same problem; --sdr-full adds the full-size solve (137.6 GB, about 130 s)
+        recs.append(sdr_record(e, form, n, m))
         del e
     except Exception as ex:
         recs.append({'config': 'configs[4]', 'error': repr(ex)})
+    if sdr_full:
+        try:
+            n, m = 4096, 1024
+            form = problems.dense_indefinite_generated(n, m, seed=7)
+            e = Engine(form, device=device)
+            recs.append(sdr_record(e, form, n, m))
+            del e
+        except Exception as ex:
+            recs.append({'config': 'configs[4] SDP relaxation at full size', 'error': repr(ex)})
     return recs
+
+
+def sdr_record(e, form, n, m):
+    """One record of the SDP relaxation (suggest(SDR), qcqp.py:72-97) of a dense problem held by engine `e`."""
+    try:
+        from qcqp_amd import sdr
+        t0 = time.perf_counter()
+        X, bound, info = sdr.solve_sdr_general(e, form, outer=40, inner=300)
+        dt = time.perf_counter() - t0
+        lmin, S = sdr.dual_certificate_device(e, info['y'], info['yN'])
+        fl_eval = 2.0 * (m + 1) * n * n * info['rank']
+        return {'config': 'SDP relaxation of the configs[4] family at n = %d, m = %d (%.1f GB of matrices): Burer-Monteiro factor of rank %d, '
+                          'augmented Lagrangian, function values and gradient on the device, L-BFGS on the host'
+                          % (n, m, (m + 1) * n * n * 8 / 1e9, info['rank']),
+                'metric': 'seconds to a certified relaxation', 'value': dt, 'unit': 's', 'higher_is_better': False,
+                'evaluations': info['evals'], 'ms_per_evaluation': 1e3 * dt / info['evals'], 'outer_iterations': len(info['hist']),
+                'bound': bound, 'dual_value': info['dual_value'], 'infeasibility': info['infeas'],
+                'lambda_min_of_dual_matrix': lmin, 'dual_matrix_scale': float(np.abs(S).max()),
+                'ms_per_evaluation_by_part': {k: 1e3 * v / info['evals'] for k, v in info['timing'].items()},
+                'roofline': {'bound': 'mfma', 'kernel': "dense_products_kernel<1> (all quadratic forms of the factor's columns)",
+                             'achieved': fl_eval * info['evals'] / info['timing']['eval_parts'] / 1e12, 'peak': FP64_PEAK_TFLOPS,
+                             'unit': 'TFLOP/s', 'frac': fl_eval * info['evals'] / info['timing']['eval_parts'] / 1e12 / FP64_PEAK_TFLOPS,
+                             'timing': 'wall clock of the evaluation calls (upload excluded)'},
+                'full_size': 'n = 4096, m = 1024 (137.6 GB): 125 s, 1582 evaluations of 79 ms (round 1: 700 s, 3481 of 201 ms), '
+                             'profiles/r03_cfg5_sdr.md'}
+    except Exception as ex:      # a secondary record must never take the headline down
+        return {'config': 'configs[4] SDP relaxation (n = %d, m = %d)' % (n, m), 'error': repr(ex)}
 
 
 # ------------------------------------------------------------------------------------- CPU baselines
@@ -389,6 +428,7 @@ def main():
     ap.add_argument('--p2-cus', type=int, default=0, help='chained mode: CUs the phase-2 launches are confined to (0 = no partition)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the bounded records of the other BASELINE.json configs')
+    ap.add_argument('--sdr-full', action='store_true', help='add the SDP relaxation of configs[4] at FULL size (137.6 GB, about 130 s) to the secondary records')
     args = ap.parse_args()
 
     from qcqp_amd import dist, problems
@@ -598,7 +638,7 @@ def main():
             res['roofline']['kernel_ms_per_launch_max_over_ranks'] = p2_ms_max / K
             res['roofline']['achieved_all_gpus'] = (flops_all / 1e12) / (p2_ms_max / 1e3) if p2_ms_max > 0 else 0.0
         if world == 1 and not args.no_secondary:
-            res['secondary'] = secondary_records(local_rank)
+            res['secondary'] = secondary_records(local_rank, sdr_full=args.sdr_full)
         if world == 1 and not args.no_cpu_baseline:      # a reported baseline of rank 0 at N = 1 only
             cores = args.cpu_cores or min(effective_cores(), 32)
             # the winning restart of the winning step again on the CPU: the cross-check of `best`
