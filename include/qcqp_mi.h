@@ -146,6 +146,12 @@ int qcqpmi_cd_status(qcqpmi_ctx *ctx, int *status1, int *status2);
  *        zero-objective draw (utilities.py:266-267, 288) use the keyed Philox stream (seed; case index).
  *        C_out (optional) = count x 5 x (lo, hi): the feasible set after the end-point sweep, nC_out its size. */
 int qcqpmi_feasible_intervals_batch(int device, int64_t count, const double *pqrs, const int *relop, double *out);
+/*   QuadraticFunction.get_onevar_func(x, k)  utilities.py:99-105: for every function j = 0..m of the problem (objective
+ *        first) and every restart r of the resident population, the coefficients of f_j as a function of the coordinate
+ *        coord[r] alone: out[(r (m + 1) + j) 3 + (0, 1, 2)] = (t2, t1, t0) = (P[k,k], 2 P[k,:] z + q[k], f_j(z)) with z = x_r,
+ *        z[k] = 0, summed in the reference's order by the device functions the coupled-constraint kernel inlines
+ *        (csrc/cd_general.h).  Needs the row-major matrices (not device-generated / streamed problems). */
+int qcqpmi_onevar_coeffs(qcqpmi_ctx *ctx, const int64_t *coord, double *out);
 int qcqpmi_onevar_qcqp_batch(int device, int64_t count, const double *f0, const double *fs, const int *nf,
                              const double *s, uint64_t seed, double *x, int *status, double *C_out, int *nC_out);
 

@@ -44,6 +44,7 @@ PROTOTYPES = [
                                       C.c_uint64, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp]),
     ('qcqpmi_cd_status', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ('qcqpmi_feasible_intervals_batch', C.c_int, [C.c_int, C.c_int64, c_dp, C.POINTER(C.c_int), c_dp]),
+    ('qcqpmi_onevar_coeffs', C.c_int, [C.c_void_p, c_ip, c_dp]),
     ('qcqpmi_onevar_qcqp_batch', C.c_int, [C.c_int, C.c_int64, c_dp, c_dp, C.POINTER(C.c_int), c_dp, C.c_uint64, c_dp,
                                            C.POINTER(C.c_int), c_dp, C.POINTER(C.c_int)]),
     ('qcqpmi_admm_set_eig', C.c_int, [C.c_void_p, c_dp, c_dp]),

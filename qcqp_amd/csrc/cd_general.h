@@ -33,6 +33,37 @@ struct CdGenArgs {
                           // 0: t0 from the incrementally tracked f_k(x) (rounding-level different)
 };
 
+// get_onevar_func (utilities.py:99-105) of function k (0: the objective) in coordinate i for the restart in column r of the
+// tile X ([n16][16]); gP: dense constraint matrices [m][n][n].  t2 = P[i, i], t1 = 2 P[i, :] z + q[i] with z = x, z[i] = 0.
+__device__ inline void gen_onevar_t2t1(const DevProblem &P, const double *gP, const double *X, int r, int64_t i, int k,
+                                       double *t2, double *t1) {
+    const int64_t n = P.n;
+    const double *row = (k == 0) ? (P.P0 + i * P.n16) : (gP + ((int64_t)(k - 1) * n + i) * n);
+    double d = 0.0;
+    for (int64_t j = 0; j < n; j++)
+        if (j != i) d += row[j] * X[j * 16 + r];
+    const double qk = (k == 0) ? P.q0[i] : P.gq[(int64_t)(k - 1) * P.n16 + i];
+    *t2 = row[i];
+    *t1 = 2.0 * d + qk;
+}
+
+// t0 = (P.dot(z) + q).dot(z) + r with z = x, z[i] = 0, rows and columns in index order (utilities.py:104)
+__device__ inline double gen_onevar_t0(const DevProblem &P, const double *gP, const double *X, int r, int64_t i, int k) {
+    const int64_t n = P.n;
+    const double *Pk = (k == 0) ? P.P0 : (gP + (int64_t)(k - 1) * n * n);
+    const int64_t ld = (k == 0) ? P.n16 : n;
+    const double *qv = (k == 0) ? P.q0 : (P.gq + (int64_t)(k - 1) * P.n16);
+    double acc = 0.0;
+    for (int64_t i2 = 0; i2 < n; i2++) {
+        double rw = 0.0;
+        for (int64_t j = 0; j < n; j++)
+            if (j != i) rw += Pk[i2 * ld + j] * X[j * 16 + r];
+        const double z2 = (i2 == i) ? 0.0 : X[i2 * 16 + r];
+        acc += (rw + qv[i2]) * z2;
+    }
+    return acc + ((k == 0) ? P.r0 : P.gr[k - 1]);
+}
+
 struct SegList {
     double *lo, *hi;
     int *cnt;
@@ -193,32 +224,11 @@ __global__ __launch_bounds__(256) void cd_general_kernel(CdGenArgs ga) {
             // ---- A. one-variable coefficients of every function in x_i (utilities.py:99-105)
             const double xi = X[i * 16 + r];
             for (int k = slot; k <= m; k += 16) {
-                const double *row = (k == 0) ? (P.P0 + i * n16) : (ga.gP + ((int64_t)(k - 1) * n + i) * n);
-                double d = 0.0;
-                for (int64_t j = 0; j < n; j++)
-                    if (j != i) d += row[j] * X[j * 16 + r];
-                const double t2 = row[i];
-                const double qk = (k == 0) ? P.q0[i] : P.gq[(int64_t)(k - 1) * n16 + i];
-                const double t1 = 2.0 * d + qk;
-                double t0;
-                if (ga.exact_t0) {
-                    // (P.dot(z) + q).dot(z) + r with z = x, z[i] = 0, rows and columns in index order
-                    // (utilities.py:104): bit-identical to the reference/oracle, O(n^2) per function
-                    const double *Pk = (k == 0) ? P.P0 : (ga.gP + (int64_t)(k - 1) * n * n);
-                    const int64_t ld = (k == 0) ? n16 : n;
-                    const double *qv = (k == 0) ? P.q0 : (P.gq + (int64_t)(k - 1) * n16);
-                    double acc = 0.0;
-                    for (int64_t i2 = 0; i2 < n; i2++) {
-                        double rw = 0.0;
-                        for (int64_t j = 0; j < n; j++)
-                            if (j != i) rw += Pk[i2 * ld + j] * X[j * 16 + r];
-                        const double z2 = (i2 == i) ? 0.0 : X[i2 * 16 + r];
-                        acc += (rw + qv[i2]) * z2;
-                    }
-                    t0 = acc + ((k == 0) ? P.r0 : P.gr[k - 1]);
-                } else {
-                    t0 = Fk[k * 16 + r] - xi * (t2 * xi + t1);
-                }
+                double t2, t1;
+                gen_onevar_t2t1(P, ga.gP, X, r, i, k, &t2, &t1);
+                // t0: f_k(z) afresh in the reference's summation order (utilities.py:104; bit-identical to the reference /
+                // oracle, O(n^2) per function) or from the tracked f_k(x)
+                const double t0 = ga.exact_t0 ? gen_onevar_t0(P, ga.gP, X, r, i, k) : Fk[k * 16 + r] - xi * (t2 * xi + t1);
                 coef[(k * 16 + r) * 3] = t2; coef[(k * 16 + r) * 3 + 1] = t1; coef[(k * 16 + r) * 3 + 2] = t0;
             }
             __syncthreads();

@@ -387,6 +387,15 @@ class Engine(object):
         the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""
         self._chk(self.L.qcqpmi_cd_reference_order(self.h, 1 if enable else 0))
 
+    def onevar_coeffs(self, coord):
+        """QuadraticFunction.get_onevar_func (utilities.py:99-105) on the device: (t2, t1, t0) of every function in the
+        coordinate coord[r] of restart r of the resident population.  Returns (R, m + 1, 3)."""
+        coord = np.ascontiguousarray(coord, dtype=np.int64)
+        assert coord.size == self.pop_size
+        out = np.empty((self.pop_size, self.m + 1, 3))
+        self._chk(self.L.qcqpmi_onevar_coeffs(self.h, coord.ctypes.data_as(C.POINTER(C.c_int64)), _dp(out)))
+        return out
+
     def dense_chain_mode(self, mode=0):
         """Chain kernel of the dense-constraint path: 0 four waves per restart (default), 1 one wave per restart (the
         round-2 kernel, kept as the cross-check; same points bit for bit)."""

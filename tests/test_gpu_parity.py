@@ -36,6 +36,27 @@ def test_eval_matches_golden(eng_mod, orc, name):
     assert rel(f0, z['F'][0]) < 1e-12
 
 
+@pytest.mark.parametrize('name', ['bls10', 'bls32', 'maxcut12', 'dense16', 'beam10'])
+def test_onevar_coefficients_match_reference_golden(eng_mod, orc, name):
+    """QuadraticFunction.get_onevar_func (utilities.py:99-105) on the device (qcqpmi_onevar_coeffs: the device functions the
+    coupled-constraint kernel inlines, csrc/cd_general.h) against the reference's own outputs stored in the G1 fixtures
+    (6 points x every function of the problem, tools/gen_golden.py) and, bit for bit, against the oracle's restatement."""
+    z = load_golden('g1_' + name)
+    e = make(eng_mod, funcs_from_npz(z))
+    e.upload(np.ascontiguousarray(z['ov_x'].T))
+    T = e.onevar_coeffs(z['ov_k'])
+    assert T.shape == z['ov_T'].shape
+    assert np.array_equal(T[:, :, 0], z['ov_T'][:, :, 0])                  # t2 = P[k, k]
+    # tolerance: the reference's sparse products visit the same terms in another association (measured: <= 3e-15, 85-100 %
+    # of the entries bit-identical)
+    assert rel(T, z['ov_T']) < 1e-14
+    assert (T == z['ov_T']).mean() > 0.8
+    # the oracle's restatement at the same points: bit for bit
+    prob = orc.Problem(funcs_from_npz(z))
+    O = np.array([[prob.onevar_coeffs(j, z['ov_x'][t], int(z['ov_k'][t])) for j in range(T.shape[1])] for t in range(T.shape[0])])
+    assert np.array_equal(T, O)
+
+
 def test_eval_large_vs_oracle(eng_mod, orc):
     from qcqp_amd import problems
     funcs, _, _ = problems.boolean_least_squares(200, 64, seed=5)
