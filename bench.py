@@ -166,8 +166,12 @@ def secondary_records(device, sdr_full=False):
                      'sampler_kernel_ms': t_s / reps, 'eval_kernel_ms': t_e / reps,
                      'roofline': {'bound': 'mfma', 'kernel': 'dense_products_kernel (sampler x = mu + F xi; evaluation X^T P X)',
                                   'achieved': fl / 1e12 / (t_s / reps / 1e3), 'achieved_eval': fl / 1e12 / (t_e / reps / 1e3),
-                                  'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / 1e12 / (t_s / reps / 1e3) / FP64_PEAK_TFLOPS,
-                                  'algorithmic_flops_per_launch': fl}})
+                                  'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / 1e12 / (t_e / reps / 1e3) / FP64_PEAK_TFLOPS,
+                                  'frac_sampler': fl / 1e12 / (t_s / reps / 1e3) / FP64_PEAK_TFLOPS,
+                                  'algorithmic_flops_per_launch': fl,
+                                  'note': 'frac = the EVALUATION product (2 n^2 S flops whatever the factor); frac_sampler counts the 2 n^2 S '
+                                          'flops of the general n x n factor the API takes and the sampler multiplies (the eigen-factor of the '
+                                          'relaxation; SURVEY 8d counts n^2 S for a triangular Cholesky factor: half of it)'}})
         del e
     except Exception as ex:      # a secondary record must never take the headline down
         recs.append({'config': 'configs[2]', 'error': repr(ex)})
