@@ -682,3 +682,35 @@ def test_dense_chain_kernels_agree_bit_for_bit(eng_mod, n, m, R, geom):
     assert o0['sweeps1'].sum() > 0
     if m < n:        # feasible families reach phase 2 (more constraints than variables: phase 1 only)
         assert o0['accepted2'].sum() > 0
+
+
+def test_dense_chain_kernels_agree_with_equality_constraints(eng_mod, orc):
+    """The same comparison on an UPLOADED problem with '==' constraints among the coupled ones (|f| <= s takes the general
+    interval rule, utilities.py:209-231, in both kernels) -- and the points follow the oracle as far as the dense path can
+    (same feasibility class; objective within the population's spread)."""
+    from qcqp_amd import problems
+    n, R = 96, 64
+    funcs, _, _ = problems.dense_indefinite(n, 6, seed=5)
+    rs = np.random.RandomState(2)
+    # two equality constraints through the origin's neighbourhood: x' P x + q' x + r == 0 with an indefinite P
+    for k in (2, 4):
+        P, q, r, _ = funcs[k]
+        funcs[k] = (P, q, 0.05 * rs.randn(), '==')
+    res = []
+    for mode, name in ((0, 'dense_chain_mw_kernel'), (1, 'dense_chain_kernel')):
+        e = make(eng_mod, funcs)
+        e.dense_chain_mode(mode)
+        e.randn(R, seed=4)
+        out = e.cd_run(phase1=True, num_iters=4, seed=8)
+        assert e.last_cd_kernel() == name
+        res.append((e.download(), out))
+    (X0, o0), (X1, o1) = res
+    assert np.array_equal(X0, X1)
+    for key in ('f0', 'maxviol', 'sweeps1', 'sweeps2', 'visits2', 'accepted2'):
+        assert np.array_equal(o0[key], o1[key]), key
+    # reported values are those of the reported points (oracle evaluation)
+    prob = orc.Problem(funcs)
+    g0, gv = prob.eval_batch(X0)
+    assert np.max(np.abs(g0 - o0['f0']) / (1.0 + np.abs(g0))) < 1e-9
+    assert np.max(np.abs(gv - o0['maxviol']) / (1.0 + np.abs(gv))) < 1e-9
+    assert o0['sweeps1'].sum() > 0
