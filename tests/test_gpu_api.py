@@ -261,6 +261,27 @@ def test_sdr_general_solver_certified_and_consistent_with_mixing():
     assert np.max(np.abs(np.diag(X2)[:n] - 1.0)) < 1e-5
 
 
+def test_sdr_general_solver_optimizers_agree():
+    """The relaxation solver's own L-BFGS loop with inexact inner solves (the default since round 3: 5.5x faster at full
+    size, profiles/r03_cfg5_sdr.md) against SciPy's L-BFGS-B with full inner solves on the dense family at n = 128, m = 24:
+    the same certified bound from both, the timing breakdown of the solve is reported."""
+    from qcqp_amd import problems, sdr
+    from qcqp_amd.engine import Engine
+    form = problems.dense_indefinite_generated(128, 24, seed=3)
+    e = Engine(form)
+    res = {}
+    for opt, kw in (('own', {}), ('scipy', dict(inner0=None))):
+        X, bound, info = sdr.solve_sdr_general(e, form, optimizer=opt, **kw)
+        lmin, S = sdr.dual_certificate_device(e, info['y'], info['yN'])
+        assert lmin > -1e-6 * (1 + np.abs(S).max()), (opt, lmin)
+        assert abs(bound - info['dual_value']) <= 2e-5 * (1 + abs(bound)), (opt, bound, info['dual_value'])
+        assert info['infeas'] < 1e-6
+        assert set(info['timing']) >= {'upload', 'eval_parts', 'weighted_product', 'total', 'optimizer_and_rest'}
+        res[opt] = (bound, info['evals'])
+    assert abs(res['own'][0] - res['scipy'][0]) <= 2e-5 * (1 + abs(res['scipy'][0])), res
+    print('\nSDP relaxation n=128 m=24: own L-BFGS + inexact inner solves %d evaluations, L-BFGS-B %d; bound %.8g' % (res['own'][1], res['scipy'][1], res['own'][0]))
+
+
 def test_suggest_spectral_relaxation():
     """suggest(SPECTRAL) (qcqp.py:41-70, 383-388): for the Boolean family the relaxation is the sphere-constrained
     problem  min x'P0x + q0'x + r0  s.t.  ||x||^2 = n  (all equalities summed) -- a trust-region subproblem with a
