@@ -95,12 +95,31 @@ __device__ inline int64_t admm_hat_index(const AdmmArgs &a, int64_t r, int64_t h
     return ((r >> 4) * a.Mh16 + h) * 16 + (r & 15);
 }
 
-// one wave per (constraint k, restart r); EPL = elements per lane (rows_k <= 64 EPL)
-template <int EPL>
+// NW = 1: one wave per (constraint k, restart r), four pairs per workgroup; EPL = elements per lane (rows_k <= 64 EPL).
+// NW = 4 (rows_k > 4096, round 3): the whole workgroup of four waves shares one pair -- element j of thread t is t + 256 e,
+// the sums of the secular function go through LDS (two buffers in turn: one barrier per sum), every thread sees the same
+// totals in the same order, so the bisection takes the same branches in all four waves.
+template <int EPL, int NW = 1>
 __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ double sec_red[2][2][4];
+    int sec_buf = 0;
+    const int lane = (NW == 1) ? (threadIdx.x & 63) : (int)threadIdx.x;      // element slot of this thread
+    constexpr int STRIDE = 64 * NW;
+    const int64_t widx = (NW == 1) ? (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) : (int64_t)blockIdx.x;
     if (widx >= a.m * ((a.R + 15) / 16) * 16) return;
+    // sum over the pair's threads of (x, y): one wave (DPP) or the workgroup (DPP per wave, then LDS in wave order)
+    auto pair_sum = [&](double x, double y, double *sx, double *sy) {
+        const double wx = wave_sum(x), wy = wave_sum(y);
+        if (NW == 1) { *sx = wx; *sy = wy; return; }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sec_red[sec_buf][0][w] = wx; sec_red[sec_buf][1][w] = wy; }
+        __syncthreads();
+        double tx = sec_red[sec_buf][0][0], ty = sec_red[sec_buf][1][0];
+#pragma unroll
+        for (int q = 1; q < 4; q++) { tx += sec_red[sec_buf][0][q]; ty += sec_red[sec_buf][1][q]; }
+        sec_buf ^= 1;
+        *sx = tx; *sy = ty;
+    };
     // consecutive waves: the 16 restarts of a tile for one constraint (they share every cache line they touch)
     const int64_t tile = widx / (16 * a.m), rem = widx % (16 * a.m);
     const int64_t k = rem / 16, r = tile * 16 + (rem % 16);
@@ -117,7 +136,7 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
     double fz_a = 0.0, fz_b = 0.0, fv_a = 0.0, fv_b = 0.0;
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
-        const int64_t j = lane + 64 * e;
+        const int64_t j = lane + STRIDE * e;
         const bool ok = j < n;
         L[e] = ok ? lm[j] : 0.0;
         Qh[e] = ok ? qh[j] : 0.0;
@@ -134,14 +153,17 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
     for (int e = 0; e < EPL; e++)
         if (__builtin_amdgcn_ballot_w64(L[e] != 0.0) != 0ull) nzmask |= 1u << e;
     // violation of z itself (QuadraticFunction.violation, utilities.py:56-62) in eigen form
-    const double fz = wave_sum(fz_a) + wave_sum(fz_b) + rk;
+    double sa_, sb_;
+    pair_sum(fz_a, fz_b, &sa_, &sb_);
+    const double fz = sa_ + sb_ + rk;
     if (lane == 0 && a.mvbits) {
         const double viol = (relop == RELOP_EQ) ? fabs(fz) : (fz > 0.0 ? fz : 0.0);
         atomicMax(&a.mvbits[r], (unsigned long long)__double_as_longlong(viol));   // viol >= 0: bit order = value order
     }
     if (a.viol_only) return;
     // onecons_qcqp(z + u, f): feasible inequality -> the point itself (utilities.py:157-158)
-    const double fv = wave_sum(fv_a) + wave_sum(fv_b) + rk;
+    pair_sum(fv_a, fv_b, &sa_, &sb_);
+    const double fv = sa_ + sb_ + rk;
     double X[EPL];
     if (relop == RELOP_LE && fv <= 0.0) {
 #pragma unroll
@@ -157,7 +179,9 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
                 pa += L[e] * (xh * xh);
                 pb += Qh[e] * xh;
             }
-            return wave_sum(pa) + wave_sum(pb) + rk;
+            double ta, tb;
+            pair_sum(pa, pb, &ta, &tb);
+            return ta + tb + rk;
         };
         double s = a.slo[k], e_ = a.ehi[k];
         int guard = 0;
@@ -176,7 +200,7 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
     // dual update in the basis and the operand of the consensus product
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
-        const int64_t j = lane + 64 * e;
+        const int64_t j = lane + STRIDE * e;
         if (j < n) {
             if (a.project_only) { zq[j * 16] = X[e]; continue; }
             const double u_old = a.first_iter ? 0.0 : uh[j * 16];

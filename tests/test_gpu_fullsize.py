@@ -191,3 +191,35 @@ def test_config4_admm_full_size_converges(eng_mod):
     assert feas.sum() > R // 2
     assert vb < 1e-2 and fb == f0[idx]
     assert out['iters1'].max() <= 1000 and out['iters2'].max() <= 1000
+
+
+def test_admm_full_eigenbasis_beyond_4096_vs_oracle(eng_mod, orc):
+    """improve(ADMM) (qcqp.py:254-285) in the FULL eigenbasis at n = 4160 > 4096 -- refused until round 3 (one wave held a
+    constraint's 4096 hat coordinates in registers; beyond that a workgroup of four waves shares a (constraint, restart) pair,
+    admm_secular_kernel<EPL, 4>, the sums of the secular function go through LDS).  Beamforming with 2080 antennas, 2 + 2
+    constraints; the oracle and the engine are fed the same eigenpairs; two restarts, 8 + 8 iterations, points to 1e-6
+    relative (the reference's bisection stops at 1e-6 on every multiplier), reported values equal to the oracle's evaluation."""
+    from qcqp_amd import problems
+    from qcqp_amd.form import QCQPForm
+    funcs, _, _ = problems.beamforming(2080, 2, 2, seed=3)
+    form = QCQPForm.from_arrays(funcs)
+    n, m = form.n, form.m
+    assert (n, m) == (4160, 4)
+    rho, iters, R = 1.0, 8, 2
+    lm, Q = _eig_lowrank(form)
+    X0 = np.random.RandomState(7).randn(n, R)
+    e = eng_mod.Engine(form)
+    e.admm_set_eig(lm, Q)
+    e.upload(X0)
+    out = e.admm_run(rho, None, phase1=True, num_iters=iters)
+    assert e.last_admm_kernel()[0] == 'admm_multi_launch'
+    Xf = e.download()
+    prob = orc.Problem(funcs)
+    prob._eig = (np.ascontiguousarray(lm), np.ascontiguousarray(Q))
+    for r in range(R):
+        xa = prob.improve_admm(X0[:, r], num_iters=iters, rho=rho)
+        d = rel(Xf[:, r], xa)
+        assert d < 1e-6, (r, d)
+        fo, vo = prob.eval(0, xa), prob.max_violation(xa)
+        assert abs(out['f0'][r] - fo) <= 1e-6 * (1 + abs(fo)), (r, out['f0'][r], fo)
+        assert abs(out['maxviol'][r] - vo) <= 1e-6 * (1 + abs(vo)), (r, out['maxviol'][r], vo)
