@@ -266,7 +266,8 @@ __global__ __launch_bounds__(MW_TMAX) void dense_chain_mw_kernel(DenseChainArgs 
     // moves made so far at every visit (dense_chain_kernel), with independent loads that go out together and no per-visit
     // loop over the move list.  Beyond two slots the rows are fetched visit by visit.
     constexpr bool GREG = SL <= 2;
-    double g[GREG ? SL : 1][16];
+    typedef double mw_v16d __attribute__((ext_vector_type(16)));
+    mw_v16d g[GREG ? SL : 1];        // a vector per slot: g[j][c] with the loop's c is ONE indexed register move, not a 15-way select
     if (GREG) {
 #pragma unroll
         for (int j = 0; j < SL; j++) {
@@ -334,9 +335,7 @@ __global__ __launch_bounds__(MW_TMAX) void dense_chain_mw_kernel(DenseChainArgs 
                 const int k = slot_k(j);
                 t2[j] = 0.0; t1[j] = 0.0; t0[j] = 0.0;
                 if (k >= m1) continue;
-                double gs = g[j][0];
-#pragma unroll
-                for (int cc = 1; cc < 16; cc++) gs = (c == cc) ? g[j][cc] : gs;     // c is identical in every thread
+                const double gs = g[j][c];                                         // c is identical in every thread
                 const double u1 = 2.0 * (gs - d2[j] * xi) + ql[j];
                 const double u0 = W.F[k] - xi * (d2[j] * xi + u1);
                 t2[j] = d2[j]; t1[j] = u1; t0[j] = u0;
