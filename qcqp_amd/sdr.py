@@ -195,7 +195,7 @@ def _lbfgs(fun_grad, x0, maxiter, maxfun, gtol, ftol, memory=20):
 
 
 def _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inner, feas_tol, seed, verbose, optimizer='own',
-                       inner0=None, growth=1.5):
+                       inner0=None, growth=1.5, ftol_final=1e-15):
     """Augmented-Lagrangian loop on the Burer-Monteiro factor V ((n+1) x rank) of the lifted matrix, shared by the
     dense and the separable operator sets.  values(V) -> h (m+1,): <M_k, V V'> for the objective (k = 0) and every
     constraint; gradient(V, ws, wN) -> d/dV of sum_k ws_k <M_k, V V'> + wN |t|^2 (V is the matrix `values` saw last)."""
@@ -233,7 +233,7 @@ def _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inne
     for it in range(outer):
         # inexact inner solves: no point in polishing the Lagrangian far below the current infeasibility
         rough = prev_infeas is not None and prev_infeas > 1e-4
-        ftol = 1e-9 if (prev_infeas is None or rough) else 1e-15
+        ftol = 1e-9 if (prev_infeas is None or rough) else ftol_final
         # inexact inner solves, second part: while the multipliers are far from their limit a few dozen L-BFGS iterations per
         # outer iteration move them as well as three hundred do (inner0 iterations at first, growing by `growth` per outer
         # iteration up to `inner`)
@@ -272,7 +272,7 @@ def _default_rank(m, rank):
 
 
 def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400, feas_tol=1e-6, seed=0, verbose=False, optimizer='own',
-                      inner0=20, growth=1.3):
+                      inner0=20, growth=1.3, ftol_final=1e-15):
     """SDP relaxation of ANY QCQP the dense path holds (constraints that couple coordinates), in the
     Burer-Monteiro form X = V V' (V: (n+1) x r, r(r+1)/2 > m+1) with an augmented Lagrangian on the
     constraints  <M_k, X> (<=, ==) 0,  X_nn = 1   (solve_sdr, qcqp.py:72-97).  The heavy linear algebra runs
@@ -332,7 +332,7 @@ def solve_sdr_general(engine, form, rank=None, sigma0=10.0, outer=25, inner=400,
         limiter = None
     try:
         X, bound, info = _burer_monteiro_al(n, m, eq, sc, rank, values, gradient, sigma0, outer, inner, feas_tol, seed, verbose, optimizer,
-                                            inner0, growth)
+                                            inner0, growth, ftol_final)
     finally:
         if limiter is not None:
             limiter.restore_original_limits()

@@ -21,6 +21,8 @@ for opt in opts:
     kw = dict(inner0=int(parts[1]), growth=float(parts[2])) if len(parts) > 2 else {}
     if len(parts) > 3:
         kw['sigma0'] = float(parts[3])
+    if len(parts) > 4:
+        kw['ftol_final'] = float(parts[4])
     X, bound, info = sdr.solve_sdr_general(e, form, outer=40, inner=300, optimizer=parts[0], **kw)
     dt = time.time() - t0
     lmin, S = sdr.dual_certificate_device(e, info['y'], info['yN'])
