@@ -287,7 +287,7 @@ def secondary_records(device, sdr_full=False):
                                             '2 sweeps per phase they are a third of the wall clock; *_sweep_loops: HIP events around the sweep '
                                             'loops alone'}})
         # the SDP relaxation in front of it (suggest(SDR), qcqp.py:72-97): the engine's own Burer-Monteiro / augmented-Lagrangian
-        # solver on the same problem; --sdr-full adds the full-size solve (137.6 GB, about 130 s)
+        # solver on the same problem; --sdr-full adds the full-size solve (137.6 GB, about 100 s)
         recs.append(sdr_record(e, form, n, m))
         del e
     except Exception as ex:
@@ -325,7 +325,7 @@ def sdr_record(e, form, n, m):
                              'achieved': fl_eval * info['evals'] / info['timing']['eval_parts'] / 1e12, 'peak': FP64_PEAK_TFLOPS,
                              'unit': 'TFLOP/s', 'frac': fl_eval * info['evals'] / info['timing']['eval_parts'] / 1e12 / FP64_PEAK_TFLOPS,
                              'timing': 'wall clock of the evaluation calls (upload excluded)'},
-                'full_size': 'n = 4096, m = 1024 (137.6 GB): 125 s, 1582 evaluations of 79 ms (round 1: 700 s, 3481 of 201 ms), '
+                'full_size': 'n = 4096, m = 1024 (137.6 GB): 95 s, 1582 evaluations of 60 ms (round 1: 700 s, 3481 of 201 ms), '
                              'profiles/r03_cfg5_sdr.md'}
     except Exception as ex:      # a secondary record must never take the headline down
         return {'config': 'configs[4] SDP relaxation (n = %d, m = %d)' % (n, m), 'error': repr(ex)}
@@ -432,7 +432,7 @@ def main():
     ap.add_argument('--p2-cus', type=int, default=0, help='chained mode: CUs the phase-2 launches are confined to (0 = no partition)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the bounded records of the other BASELINE.json configs')
-    ap.add_argument('--sdr-full', action='store_true', help='add the SDP relaxation of configs[4] at FULL size (137.6 GB, about 130 s) to the secondary records')
+    ap.add_argument('--sdr-full', action='store_true', help='add the SDP relaxation of configs[4] at FULL size (137.6 GB, about 100 s) to the secondary records')
     args = ap.parse_args()
 
     from qcqp_amd import dist, problems
