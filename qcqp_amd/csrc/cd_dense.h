@@ -45,9 +45,11 @@ namespace qcqpmi {
 constexpr int DN_GC = 64;    // gaps kept per restart
 constexpr int DN_SC = 32;    // segments kept per restart
 constexpr int DN_WPB = 4;    // at most this many restarts (= waves) per workgroup of the chain kernel
-// LDS doubles per wave of the chain kernel besides the DN_FARR per-function arrays (t2, t1, t0, f_k, gap start, gap end)
+// LDS doubles per wave of the chain kernel besides the per-function arrays: t2, t1, t0, f_k (DN_FARR_MIN) and, when G is
+// staged in LDS (few restarts: there is room), the gap of every two-interval function kept from pass 1 (DN_FARR)
 constexpr int DN_LDS_WAVE = 2 * DN_GC + 2 * DN_SC + 32 + 8;
 constexpr int DN_FARR = 6;
+constexpr int DN_FARR_MIN = 4;
 constexpr int DN_PF = 8;     // function slots per lane whose per-coordinate operands are requested in one batch
 
 typedef double dn_v4d __attribute__((ext_vector_type(4)));
@@ -651,6 +653,7 @@ __device__ inline int dn_sweep_segments(double *ga, double *gb, int ng, double *
 
 // Feasible set of the current coordinate at slack s from the coefficient arrays in LDS.
 // Returns the number of segments (wave-uniform); the list is in W.seglo / W.seghi.
+template <bool SG>      // SG: the gaps found in pass 1 are kept in W.fga / W.fgb; else pass 2 recomputes them
 __device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, int lane, double s, int *overflow, DnProf &pf,
                                       unsigned long long relbits) {
     // pass 1: bounds of this lane's constraints
@@ -666,7 +669,7 @@ __device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, in
         const Seg2 iv = feasible_intervals(t2, t1, W.t0[k], (int)((relbits >> (2 * j)) & 3ull), s);
         if (iv.n == 0) { empty = true; continue; }
         const double lo = iv.lo0, hi = (iv.n == 2) ? iv.hi1 : iv.hi0;
-        if (iv.n == 2) { n2 |= 1u << j; W.fga[k] = iv.hi0; W.fgb[k] = iv.lo1; }   // same lane reads them back in pass 2
+        if (iv.n == 2) { n2 |= 1u << j; if (SG) { W.fga[k] = iv.hi0; W.fgb[k] = iv.lo1; } }   // same lane reads them back in pass 2
         L = lo > L ? lo : L;
         if (hi < H) { H = hi; mH = 1; } else if (hi == H) mH++;
     }
@@ -693,7 +696,11 @@ __device__ inline int dn_feasible_set(const DnWave &W, const DenseProblem &D, in
             bool has = false;
             double ga = 0.0, gb = 0.0;
             if ((n2 >> jj) & 1u) {
-                ga = W.fga[k]; gb = W.fgb[k];
+                if (SG) { ga = W.fga[k]; gb = W.fgb[k]; }
+                else {
+                    const Seg2 iv = feasible_intervals(W.t2[k], W.t1[k], W.t0[k], (int)((relbits >> (2 * jj)) & 3ull), s);
+                    ga = iv.hi0; gb = iv.lo1;
+                }
                 has = gb > Lg && ga <= Hg;
             }
             const unsigned long long mk = __builtin_amdgcn_ballot_w64(has);
@@ -739,9 +746,10 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
     pf.start(a.prof != nullptr && gr == 0);
     DnWave W;
     {
-        double *sp = smem + (size_t)wave * ((GLDS ? 16 + DN_FARR : DN_FARR) * (size_t)m1p + DN_LDS_WAVE);
+        double *sp = smem + (size_t)wave * ((GLDS ? 16 + DN_FARR : DN_FARR_MIN) * (size_t)m1p + DN_LDS_WAVE);
         W.t2 = sp; sp += m1p; W.t1 = sp; sp += m1p; W.t0 = sp; sp += m1p; W.F = sp; sp += m1p;
-        W.fga = sp; sp += m1p; W.fgb = sp; sp += m1p;
+        W.fga = nullptr; W.fgb = nullptr;
+        if (GLDS) { W.fga = sp; sp += m1p; W.fgb = sp; sp += m1p; }
         W.gapa = sp; sp += DN_GC; W.gapb = sp; sp += DN_GC;
         W.seglo = sp; sp += DN_SC; W.seghi = sp; sp += DN_SC;
         W.xb = sp; sp += 16; W.dlt = sp; sp += 16;
@@ -847,7 +855,7 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
         pf.tick(1);
         if (PHASE == 2) {
             // ---- B. feasible set at the fixed slack, minimiser of the scalar objective
-            const int ns = dn_feasible_set(W, D, lane, slack, &overflow, pf, relbits);
+            const int ns = dn_feasible_set<GLDS>(W, D, lane, slack, &overflow, pf, relbits);
             int got = 0;
             if (lane == 0) {
                 SegList C = SL;
@@ -879,7 +887,7 @@ __global__ __launch_bounds__(64 * DN_WPB) void dense_chain_kernel(DenseChainArgs
                 bool pending = false;
                 while (es - ss > a.tol) {
                     const double sm = (ss + es) / 2.0;
-                    const int ns = dn_feasible_set(W, D, lane, sm, &overflow, pf, relbits);
+                    const int ns = dn_feasible_set<GLDS>(W, D, lane, sm, &overflow, pf, relbits);
                     const uint32_t itc = it++;
                     if (ns == 0) { ss = sm; continue; }
                     bool unb = false;

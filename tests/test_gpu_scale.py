@@ -714,3 +714,23 @@ def test_dense_chain_kernels_agree_with_equality_constraints(eng_mod, orc):
     assert np.max(np.abs(g0 - o0['f0']) / (1.0 + np.abs(g0))) < 1e-9
     assert np.max(np.abs(gv - o0['maxviol']) / (1.0 + np.abs(gv))) < 1e-9
     assert o0['sweeps1'].sum() > 0
+
+
+def test_dense_chain_falls_back_to_one_wave_beyond_eight_slots(eng_mod):
+    """More than 8 constraints per thread of the multi-wave chain kernel (m > 3584) take dense_chain_kernel -- one wave per
+    restart, four per-function arrays in LDS (120 KB at m = 3700) -- without being asked to: the run completes, the reported
+    (objective, max violation) are those of the returned points, phase 1 reduces the violation."""
+    from qcqp_amd import problems
+    n, m, R = 128, 3700, 16
+    form = problems.dense_indefinite_generated(n, m, seed=5)
+    e = eng_mod.Engine(form)
+    out4 = (C.c_int * 4)()
+    assert e.L.qcqpmi_dense_chain_geometry(m, out4) == 0 and out4[0] > 8
+    e.randn(R, seed=2)
+    f_start, v_start = e.eval()
+    out = e.cd_run(phase1=True, num_iters=2, seed=3)
+    assert e.last_cd_kernel() == 'dense_chain_kernel'
+    f0, mv = e.eval()
+    assert np.max(np.abs(out['f0'] - f0) / (1.0 + np.abs(f0))) < 1e-9
+    assert np.max(np.abs(out['maxviol'] - mv) / (1.0 + np.abs(mv))) < 1e-9
+    assert out['sweeps1'].sum() > 0 and np.median(mv) < np.median(v_start)
