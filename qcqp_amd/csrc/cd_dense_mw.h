@@ -57,27 +57,30 @@ struct MwLds {
     int *bi;                       // [8] 0 segments, 1 got, 2 unbounded, 3 gap count (atomic), 4 overflow, 5 moved
 };
 
-// p x^2 + q x + rs <= 0: intervals_le (onevar.h) with its two quadratic branches merged -- the same expressions, but a
-// wave whose lanes hold convex and concave functions walks the square root and the two divisions once, not twice
+// p x^2 + q x + rs <= 0: intervals_le (onevar.h) without its branches
 __device__ inline Seg2 mw_intervals_le(double p, double q, double rs, double smr) {
+    // Straight-line form: ONE square root and TWO divisions whatever mix of convex, concave and linear functions the lanes of
+    // a wave hold; every case selects the operands of the reference's expression for it (same operations on the same values,
+    // bit for bit), results that a case does not use are discarded.
     const double tol = 1e-4;
+    const bool pos = p > tol, neg = p < -tol, quad = pos || neg;
+    const double D = q * q - 4.0 * p * rs;
+    const bool real = D >= 0.0;
+    const double rD = sqrt(real ? D : 0.0);
+    const double den = quad ? 2.0 * p : q;
+    const double a = (quad ? (-q - rD) : smr) / den;        // (-q - rD) / (2 p)   or   (s - r) / q
+    const double b = (-q + rD) / den;                       // (-q + rD) / (2 p)
+    const bool qp = q > tol, qn = q < -tol;
     Seg2 o;
-    o.n = 0; o.lo0 = o.hi0 = o.lo1 = o.hi1 = 0.0;
-    const bool pos = p > tol, neg = p < -tol;
-    if (pos || neg) {
-        const double D = q * q - 4.0 * p * rs;
-        if (D >= 0.0) {
-            const double rD = sqrt(D);
-            const double a = (-q - rD) / (2.0 * p), b = (-q + rD) / (2.0 * p);
-            if (pos) { o.n = 1; o.lo0 = a; o.hi0 = b; }
-            else { o.n = 2; o.lo0 = -QM_INF; o.hi0 = b; o.lo1 = a; o.hi1 = QM_INF; }
-        } else if (neg) { o.n = 1; o.lo0 = -QM_INF; o.hi0 = QM_INF; }
-    } else {
-        o.n = 1;
-        if (q > tol) { o.lo0 = -QM_INF; o.hi0 = smr / q; }
-        else if (q < -tol) { o.lo0 = smr / q; o.hi0 = QM_INF; }
-        else { o.lo0 = -QM_INF; o.hi0 = QM_INF; }
-    }
+    // number of intervals: convex 1 (0 without real roots); concave 2 (1 = the whole line without real roots); linear 1
+    o.n = quad ? (real ? (pos ? 1 : 2) : (pos ? 0 : 1)) : 1;
+    // first interval
+    o.lo0 = (pos && real) ? a : ((!quad && qn) ? a : -QM_INF);
+    o.hi0 = (pos && real) ? b : ((neg && real) ? b : ((!quad && qp) ? a : QM_INF));
+    if (pos && !real) { o.lo0 = 0.0; o.hi0 = 0.0; }
+    // second interval (concave with real roots)
+    o.lo1 = (neg && real) ? a : 0.0;
+    o.hi1 = (neg && real) ? QM_INF : 0.0;
     return o;
 }
 
