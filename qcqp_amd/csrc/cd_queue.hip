@@ -35,9 +35,50 @@ namespace {
 __device__ inline int qs_load_int(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline double qs_load_d(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// A pointer that was read from the descriptor table in LDS is GLOBAL memory, but the compiler cannot know: it emits FLAT
+// loads / stores / atomics for everything reached through it (31 of them; they count against the LDS counter as well, and
+// the roles of this kernel synchronise through LDS words) -- the chained variant was 30 % slower than the single-population
+// one for that alone (12.9 against 9.8 ms at 16384 restarts).  Hence descriptors with pointers typed as global memory.
+#define QG __attribute__((address_space(1)))
+struct CdBatchG {
+    QG double *X;
+    QG const double *f0cur, *slack;
+    QG const uint8_t *flag;
+    QG int64_t *visits, *accepted, *sweeps;
+    QG int *status;
+    QG double *f0out, *mvout;
+    int64_t R;
+    uint64_t seed, first_index;
+    QG int *next;
+    QG const int *ready;
+    int ready_gen;
+};
+template <class T>
+__device__ __attribute__((always_inline)) inline QG T *qs_g(T *p) { return (QG T *)p; }
+__device__ __attribute__((always_inline)) inline CdBatchG qs_batch(const CdBatch &t) {
+    CdBatchG b;
+    b.X = qs_g(t.X); b.f0cur = qs_g(t.f0cur); b.slack = qs_g(t.slack); b.flag = qs_g(t.flag);
+    b.visits = qs_g(t.visits); b.accepted = qs_g(t.accepted); b.sweeps = qs_g(t.sweeps); b.status = qs_g(t.status);
+    b.f0out = qs_g(t.f0out); b.mvout = qs_g(t.mvout); b.next = qs_g(t.next); b.ready = qs_g(t.ready);
+    b.R = t.R; b.seed = t.seed; b.first_index = t.first_index; b.ready_gen = t.ready_gen;
+    return b;
+}
+__device__ inline int qs_load_int(QG const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double qs_load_d(QG const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int qs_add(QG int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // CS: blocks of the contraction the chain wave multiplies itself (0..RQ_CSMAX)
-template <int CS>
-__global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
+// MULTI = false: ONE population and no ring -- the descriptor is the kernel argument itself, the chain / ring branches are
+// compiled out.  (With the four descriptors in LDS and the ring branches in place the single-population launch was 30 %
+// slower: 12.9 instead of 9.8 ms at 16384 restarts; measured late in round 3, tools/queue_rate.py.)
+template <int CS, int QM>      // QM: 0 one population, 1 chained populations (descriptor table), 2 ring
+__global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
+    constexpr bool MULTI = QM != 0;
+    // the compiler sees constants where the other modes read the arguments
+    CdQueueArgs a = a0;
+    a.ring = (QM == 2) ? 1 : 0;
+    if (!MULTI) a.nb = 1;
+#define QB(i) (MULTI ? Bt[i] : a0.b[0])
     constexpr int MAXC = 1;
     constexpr int CSU = CS > 0 ? CS : 1;
     extern __shared__ double smem[];
@@ -88,7 +129,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
         for (int f = 0; f < 8; f++) cst[f * 64 + tid0] = (f == 4) ? 1 : 0;
     }
     if (tid0 < 16) { sid[tid0] = -1; sbt[tid0] = 0; sfin[tid0] = 0; }
-    if (tid0 == 0) { Bt[0] = a.b[0]; Bt[1] = a.b[1]; Bt[2] = a.b[2]; Bt[3] = a.b[3]; ctl[1] = 0; ctl[2] = 0; }
+    if (tid0 == 0) { if (MULTI) { Bt[0] = a0.b[0]; Bt[1] = a0.b[1]; Bt[2] = a0.b[2]; Bt[3] = a0.b[3]; } ctl[1] = 0; ctl[2] = 0; }
     const long long ring_t0 = a.ring ? (long long)wall_clock64() : 0;
     __syncthreads();
     const int64_t gmax = (int64_t)1 << 40;         // the roles end through RQ_STOP
@@ -114,32 +155,32 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                 int j = ctl[1];
                 for (;;) {
                     const int e = j % a.nb;
-                    int *qe = Bt[e].next;
+                    QG int *qe = qs_g(QB(e).next);
                     const int want = j / a.nb + 1, gen = qs_load_int(qe + 1);
                     if (gen < want) break;
                     if (gen > want) { j++; continue; }              // that population was complete long ago (entry reused)
-                    const int idx = atomicAdd(qe, 1);
+                    const int idx = qs_add(qe, 1);
                     if (idx >= qs_load_int(qe + 4)) { j++; continue; }
-                    if (__hip_atomic_load(Bt[e].flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (__hip_atomic_load(qs_g(QB(e).flag) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                         id = idx; bt = e; nw = 1;
                         sseed[tid] = (unsigned long long)(unsigned)qs_load_int(qe + 5) | ((unsigned long long)(unsigned)qs_load_int(qe + 6) << 32);
                         sfirst[tid] = (unsigned long long)(unsigned)qs_load_int(qe + 7) | ((unsigned long long)(unsigned)qs_load_int(qe + 8) << 32);
                         break;
                     }
-                    atomicAdd(qe + 3, 1);                            // did not pass the gate (qcqp.py:189): nothing to run, done
+                    qs_add(qe + 3, 1);                            // did not pass the gate (qcqp.py:189): nothing to run, done
                 }
                 atomicMax(&ctl[2], j);
             } else if (id < 0) {
                 for (int q = 0; q < a.nb && id < 0; q++) {
-                    const CdBatch &B = Bt[q];
+                    const CdBatchG B = qs_batch(QB(q));
                     if (B.ready && qs_load_int(B.ready) != B.ready_gen) break;     // not published yet (nor are the ones after it)
                     for (;;) {
-                        const int idx = atomicAdd(B.next, 1);      // (runs past R by at most 16 per workgroup and episode: harmless)
+                        const int idx = qs_add(B.next, 1);      // (runs past R by at most 16 per workgroup and episode: harmless)
                         if (idx >= (int)B.R) break;
                         if (__hip_atomic_load(B.flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                             id = idx; bt = q; nw = 1;
                             sseed[tid] = B.seed; sfirst[tid] = B.first_index;
-                            if (q >= 1) atomicAdd(B.next + 2, 1);      // statistics: restarts of the next population run ahead by this launch
+                            if (q >= 1) qs_add(B.next + 2, 1);      // statistics: restarts of the next population run ahead by this launch
                             break;
                         }
                     }
@@ -147,7 +188,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             }
             sid[tid] = id; sbt[tid] = bt; snew[tid] = nw;
             if (nw) {
-                const CdBatch &B = Bt[bt];
+                const CdBatchG B = qs_batch(QB(bt));
                 slk[tid] = qs_load_d(B.slack + id);
                 f0new[tid] = qs_load_d(B.f0cur + id);
                 FeasSet<MAXC> C;
@@ -183,7 +224,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                 // eight loads in flight per thread; the own population was complete before this launch (plain loads), the
                 // next one was written by kernels of another stream while this one was running (sc1 loads)
                 const bool nxt = a.ring || sbt[col] != 0;
-                const double *src = Bt[sbt[col]].X + ((int64_t)(id >> 4) * n16) * 16 + (id & 15);
+                QG const double *src = qs_g(QB(sbt[col]).X) + ((int64_t)(id >> 4) * n16) * 16 + (id & 15);
                 for (int64_t j0 = tid >> 4; j0 < n16; j0 += 32 * 8) {
                     double pv[8];
 #pragma unroll
@@ -578,16 +619,20 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
                         bool more = false;
                         if (a.ring) {
                             for (int j = ctl[1], tries = 0; tries < 2 && !more; j++, tries++) {
-                                int *qe = Bt[j % a.nb].next;
+                                QG int *qe = qs_g(QB(j % a.nb).next);
                                 const int want = j / a.nb + 1, gen = qs_load_int(qe + 1);
                                 if (gen < want) break;
                                 more = gen == want && qs_load_int(qe) < qs_load_int(qe + 4);
                             }
                         }
-                        for (int q = 0; q < a.nb && !more && !a.ring; q++) {
-                            const CdBatch &B = Bt[q];
-                            if (B.ready && qs_load_int(B.ready) != B.ready_gen) break;
-                            more = qs_load_int(B.next) < (int)B.R;
+                        if (!a.ring) {
+                            // own population from the kernel arguments (scalar registers), the others from the table
+                            more = (!a0.b[0].ready || qs_load_int(a0.b[0].ready) == a0.b[0].ready_gen) && qs_load_int(a0.b[0].next) < (int)a0.b[0].R;
+                            for (int q = 1; q < a.nb && !more; q++) {
+                                const CdBatchG B = qs_batch(QB(q));
+                                if (B.ready && qs_load_int(B.ready) != B.ready_gen) break;
+                                more = qs_load_int(B.next) < (int)B.R;
+                            }
                         }
                         if (more) break;
                     }
@@ -642,7 +687,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             const int col = tid & 15, slot = tid >> 4;
             double v = -QM_INF;
             if (sfin[col]) {
-                double *dst = Bt[sbt[col]].X + ((int64_t)(sid[col] >> 4) * n16) * 16 + (sid[col] & 15);
+                QG double *dst = qs_g(QB(sbt[col]).X) + ((int64_t)(sid[col] >> 4) * n16) * 16 + (sid[col] & 15);
                 for (int64_t i = slot; i < n16; i += 32) {
                     const double x = Xs[i * 16 + col];
                     if (a.ring) __hip_atomic_store(dst + i * 16, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // read by other kernels while this one runs
@@ -661,17 +706,17 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
             if (tid < 16 && sfin[tid]) {
                 double m = -QM_INF;
                 for (int s2 = 0; s2 < 32; s2++) { const double w = red[s2 * 16 + tid]; m = w > m ? w : m; }
-                const CdBatch &B = Bt[sbt[tid]];
+                const CdBatchG B = qs_batch(QB(sbt[tid]));
                 const int id = sid[tid];
                 if (a.ring) {
-                    __hip_atomic_store((long long *)B.visits + id, ovis[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store((long long *)B.accepted + id, oacc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store((long long *)B.sweeps + id, oswp[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((QG long long *)B.visits + id, ovis[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((QG long long *)B.accepted + id, oacc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((QG long long *)B.sweeps + id, oswp[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(B.status + id, ost[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (B.f0out) __hip_atomic_store(B.f0out + id, of0[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (B.mvout) __hip_atomic_store(B.mvout + id, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    atomicAdd(B.next + 3, 1);                              // one more restart of that population is complete
+                    qs_add(B.next + 3, 1);                              // one more restart of that population is complete
                 } else {
                     B.visits[id] = ovis[tid]; B.accepted[id] = oacc[tid]; B.sweeps[id] = oswp[tid]; B.status[id] = ost[tid];
                     if (B.f0out) B.f0out[id] = of0[tid];
@@ -685,6 +730,8 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a) {
 }
 
 }  // namespace
+
+#undef QB
 
 size_t cd_queue_lds_bytes(const DevProblem &P) {
     const int NB = (int)P.NB;
@@ -702,7 +749,11 @@ int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st) {
     if (cs >= NB) cs = 0;
     cs &= ~1;
     if (NB - cs > RQ_NSIMD * RQ_MAXU) return (int)hipErrorInvalidValue;
-    auto k = cs == 0 ? cd_phase2_qs_kernel<0> : cs == 2 ? cd_phase2_qs_kernel<2> : cs == 4 ? cd_phase2_qs_kernel<4> : cd_phase2_qs_kernel<6>;
+    int qm = a.ring ? 2 : (a.nb > 1 ? 1 : 0);
+    if (const char *e = getenv("QCQPMI_QS_MODE")) { const int v = atoi(e); if (!a.ring && v >= qm && v <= 1) qm = v; }     // experiments: the chained variant on one population
+    auto k = qm == 2 ? (cs == 0 ? cd_phase2_qs_kernel<0, 2> : cs == 2 ? cd_phase2_qs_kernel<2, 2> : cs == 4 ? cd_phase2_qs_kernel<4, 2> : cd_phase2_qs_kernel<6, 2>)
+           : qm == 1 ? (cs == 0 ? cd_phase2_qs_kernel<0, 1> : cs == 2 ? cd_phase2_qs_kernel<2, 1> : cs == 4 ? cd_phase2_qs_kernel<4, 1> : cd_phase2_qs_kernel<6, 1>)
+                     : (cs == 0 ? cd_phase2_qs_kernel<0, 0> : cs == 2 ? cd_phase2_qs_kernel<2, 0> : cs == 4 ? cd_phase2_qs_kernel<4, 0> : cd_phase2_qs_kernel<6, 0>);
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int64_t wgs = (a.b[0].R + 15) / 16;
