@@ -175,6 +175,34 @@ def secondary_records(device, sdr_full=False):
         del e
     except Exception as ex:      # a secondary record must never take the headline down
         recs.append({'config': 'configs[2]', 'error': repr(ex)})
+    # the headline step with phase 2 in ONE persistent slot-queue launch that serves the populations of four contexts in turn
+    # (ring mode): no launch per step, no exposed tail.  Run in a subprocess with a time limit: the
+    # scheme needs more hardware queues than the runtime's default (GPU_MAX_HW_QUEUES, read when the runtime starts) and is
+    # experimental -- a stall must not take the headline down.
+    try:
+        import subprocess
+        env = dict(os.environ)
+        env['GPU_MAX_HW_QUEUES'] = '16'
+        tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'ring_bench.py')
+        pr = subprocess.run([sys.executable, tool, '4096', '200', '24', '192', '4'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            timeout=90)
+        line = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
+        if pr.returncode != 0 or not line:
+            raise RuntimeError('ring_bench.py failed: ' + pr.stderr.decode()[-300:])
+        rb = json.loads(line[-1])
+        recs.append({'config': 'headline workload (4096 restarts per step) with phase 2 in one persistent slot-queue launch on 192 CUs that '
+                               'serves the populations of 4 contexts in turn (ring mode; suggest, phase 1, evaluation and gate of the next '
+                               'populations on the other 64 CUs); 24 warm-up + 200 timed steps, wall clock',
+                     'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': rb['value'], 'unit': 'restart-sweeps/s',
+                     'ms_per_step': rb['ms_per_step'], 'kernel': 'cd_phase2_qs_kernel', 'ring': rb,
+                     'roofline': {'bound': 'mfma', 'kernel': 'cd_phase2_qs_kernel (persistent)', 'achieved': rb['achieved_tflops'],
+                                  'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': rb['frac'],
+                                  'timing': 'flops of the timed steps / wall time of the timed region (the launch is busy throughout)'},
+                     'note': 'not the headline: the pipeline of four contexts needs about ten steps to fill (20 steps after 3 warm-up steps '
+                             'average 3.97 ms), the scheme needs GPU_MAX_HW_QUEUES > 4 and a 192-CU partition (other partitions stall or '
+                             'run slower: profiles/r03_queue_chain_ring.md)'})
+    except Exception as ex:
+        recs.append({'config': 'headline workload through the persistent ring', 'error': repr(ex)[:400]})
     # configs[3]: secondary-user beamforming, 512 antennas (n = 1024 real), 16 + 64 constraints, improve(ADMM, rho = 1)
     try:
         funcs, _, _ = problems.beamforming(512, 16, 64, seed=1)

@@ -1,0 +1,86 @@
+"""The headline step (suggest(RANDOM) for R restarts + improve(COORD_DESCENT) + selection of the best point) with phase 2 in ONE
+persistent slot-queue launch that serves the populations of N contexts in turn (qcqpmi_cd_ring_*): prints one JSON line.
+W warm-up steps, then K timed steps (wall clock); the first steps of the run are also made serially with the tile-bound kernel
+and compared.  Needs GPU_MAX_HW_QUEUES >= 8 in the environment (set before the HIP runtime starts): with the default of 4 a
+member's stream shares a hardware queue with the persistent launch and its preparation kernels never run.
+usage: ring_bench.py [R=4096] [steps=200] [warmup=24] [p2_cus=192] [N=4] [n=1024]"""
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from qcqp_amd import problems
+from qcqp_amd.engine import Engine
+from qcqp_amd.form import QCQPForm
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+p2 = int(sys.argv[4]) if len(sys.argv) > 4 else 192
+N = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+n = int(sys.argv[6]) if len(sys.argv) > 6 else 1024
+seed = 1000
+funcs, _, _ = problems.boolean_least_squares(n, n // 4, seed=1)
+form = QCQPForm.from_arrays(funcs)
+engs = [Engine(form) for _ in range(N)]
+ref = Engine(form)
+ref.cd_queue(0)
+NCHK = 4
+refs = []
+for k in range(NCHK):
+    ref.randn(R, seed=seed + k)
+    o = ref.cd_run(seed=seed + k)
+    refs.append((ref.download(), o, ref.select_best(1e-4)[:3]))
+del ref
+for e in engs:                      # every buffer exists before the persistent launch starts
+    e.randn(R, seed=1)
+    e.cd_run(seed=1)
+Engine.ring_start(engs, phase2_cus=p2)
+total = W + K
+
+
+def submit(k):
+    e = engs[k % N]
+    e.randn(R, seed=seed + k)
+    e.ring_submit(seed=seed + k)
+
+
+for k in range(min(N - 1, total)):
+    submit(k)
+sw = 0.0
+ok = True
+t0 = None
+best = None
+for k in range(total):
+    if k == W:
+        for e in engs:
+            e.sync()
+        t0 = time.perf_counter()
+    e = engs[k % N]
+    o = e.ring_collect()
+    b = e.select_best(1e-4)
+    if k >= W:
+        sw += o['visits2'].sum() / float(n)
+        if best is None or (b[2], b[1]) < (best[2], best[1]):
+            best = b[:3]
+    if k < NCHK:
+        X = e.download()
+        rX, ro, rb = refs[k]
+        # same restarts, same arithmetic per restart: points to 1e-12 (restarts that need the reference's arithmetic walk the generic
+        # loop alone here and with their tile there: ulps), counters identical, the same best restart
+        ok = ok and np.max(np.abs(X - rX)) < 1e-12 and all(np.array_equal(o[key], ro[key]) for key in ('sweeps2', 'visits2', 'accepted2', 'ran_phase2')) \
+            and b[0] == rb[0] and abs(b[1] - rb[1]) <= 1e-11 * (1.0 + abs(rb[1]))
+    if k + N - 1 < total:
+        submit(k + N - 1)
+for e in engs:
+    e.sync()
+dt = time.perf_counter() - t0
+engs[0].ring_stop()
+fl = sw * 2.0 * n * n
+print(json.dumps({'ms_per_step': 1e3 * dt / K, 'value': sw / dt, 'unit': 'restart-sweeps/s', 'steps': K, 'warmup': W, 'restarts_per_step': R,
+                  'contexts': N, 'phase2_cus': p2, 'achieved_tflops': fl / dt / 1e12, 'frac': fl / dt / 78.6e12,
+                  'first_steps_equal_serial_tile_bound_kernel': bool(ok), 'steps_compared': NCHK,
+                  'best': {'index': best[0], 'f0': best[1], 'maxviol': best[2]}}))
