@@ -175,34 +175,6 @@ def secondary_records(device, sdr_full=False):
         del e
     except Exception as ex:      # a secondary record must never take the headline down
         recs.append({'config': 'configs[2]', 'error': repr(ex)})
-    # the headline step with phase 2 in ONE persistent slot-queue launch that serves the populations of four contexts in turn
-    # (ring mode): no launch per step, no exposed tail.  Run in a subprocess with a time limit: the
-    # scheme needs more hardware queues than the runtime's default (GPU_MAX_HW_QUEUES, read when the runtime starts) and is
-    # experimental -- a stall must not take the headline down.
-    try:
-        import subprocess
-        env = dict(os.environ)
-        env['GPU_MAX_HW_QUEUES'] = '16'
-        tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'ring_bench.py')
-        pr = subprocess.run([sys.executable, tool, '4096', '200', '24', '192', '4'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                            timeout=90)
-        line = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
-        if pr.returncode != 0 or not line:
-            raise RuntimeError('ring_bench.py failed: ' + pr.stderr.decode()[-300:])
-        rb = json.loads(line[-1])
-        recs.append({'config': 'headline workload (4096 restarts per step) with phase 2 in one persistent slot-queue launch on 192 CUs that '
-                               'serves the populations of 4 contexts in turn (ring mode; suggest, phase 1, evaluation and gate of the next '
-                               'populations on the other 64 CUs); 24 warm-up + 200 timed steps, wall clock',
-                     'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': rb['value'], 'unit': 'restart-sweeps/s',
-                     'ms_per_step': rb['ms_per_step'], 'kernel': 'cd_phase2_qs_kernel', 'ring': rb,
-                     'roofline': {'bound': 'mfma', 'kernel': 'cd_phase2_qs_kernel (persistent)', 'achieved': rb['achieved_tflops'],
-                                  'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': rb['frac'],
-                                  'timing': 'flops of the timed steps / wall time of the timed region (the launch is busy throughout)'},
-                     'note': 'not the headline: the pipeline of four contexts needs about ten steps to fill (20 steps after 3 warm-up steps '
-                             'average 3.97 ms), the scheme needs GPU_MAX_HW_QUEUES > 4 and a 192-CU partition (other partitions stall or '
-                             'run slower: profiles/r03_queue_chain_ring.md)'})
-    except Exception as ex:
-        recs.append({'config': 'headline workload through the persistent ring', 'error': repr(ex)[:400]})
     # configs[3]: secondary-user beamforming, 512 antennas (n = 1024 real), 16 + 64 constraints, improve(ADMM, rho = 1)
     try:
         funcs, _, _ = problems.beamforming(512, 16, 64, seed=1)
@@ -458,10 +430,19 @@ def main():
                     help='experimental: ring of chained contexts, phase 2 through the slot-queue kernel, launches run restarts of the next '
                          'populations (qcqpmi_cd_chain); default: two contexts, phase-2 launches never overlap (DESIGN.md section 4.1c)')
     ap.add_argument('--p2-cus', type=int, default=0, help='chained mode: CUs the phase-2 launches are confined to (0 = no partition)')
+    ap.add_argument('--scheme', choices=['auto', 'two', 'ring'], default='auto',
+                    help='two: two contexts, phase-2 launches never overlap; ring: ONE persistent slot-queue launch on 192 CUs serves the '
+                         'populations of four contexts in turn (DESIGN.md section 4.1c); auto (default): `two` in this process, then -- on one '
+                         'GPU -- `ring` in a child process with a time limit, and the faster of the two is reported (both are in the line)')
+    ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the bounded records of the other BASELINE.json configs')
     ap.add_argument('--sdr-full', action='store_true', help='add the SDP relaxation of configs[4] at FULL size (137.6 GB, about 100 s) to the secondary records')
     args = ap.parse_args()
+    ringmode = args.scheme == 'ring'
+    if ringmode:
+        # more hardware queues than the runtime's default of 4: a member's stream must not share one with the persistent launch
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
     from qcqp_amd import dist, problems
     from qcqp_amd.engine import Engine
@@ -485,7 +466,7 @@ def main():
     # other stream.  The phase-2 kernels themselves never overlap (the next one is launched after the results of the
     # current one have been fetched), so their HIP-event durations stay those of a kernel that owns the chip.
     eng2 = None
-    if args.overlap:
+    if args.overlap and not ringmode:
         try:
             eng2 = Engine(form, device=local_rank)
             dist.init_rccl(eng2, rank, world, bootstrap=boot)   # its own communicator (same rendezvous object)
@@ -525,6 +506,21 @@ def main():
                 e_.cd_queue(1)
                 e_.cd_partition(args.p2_cus)
 
+    RING_CUS, RING_N = 192, 4
+    ring_pos = [0]
+    if ringmode:
+        ring = [eng]
+        while len(ring) < RING_N:
+            ex_ = Engine(form, device=local_rank)
+            if world > 1:               # (one rank: no communicator per context -- every RCCL communicator brings streams of its own,
+                dist.init_rccl(ex_, rank, world, bootstrap=boot)      # and the ring needs its hardware queues)
+            ring.append(ex_)
+        engs = ring
+        for e_ in engs:                 # every buffer exists before the persistent launch starts
+            e_.randn(R, seed=1, first_index=first)
+            e_.cd_run(phase1=True, seed=1, first_index=first)
+        Engine.ring_start(engs, phase2_cus=RING_CUS)
+
     def prepare(e, k):
         e.randn(R, seed=args.seed + k, first_index=first)
         e.cd_begin(phase1=True, seed=args.seed + k, first_index=first)
@@ -532,6 +528,29 @@ def main():
     def run_steps(count, base, record):
         """`count` steps; step k = suggest(RANDOM) + improve(COORD_DESCENT) + selection of the best point."""
         if count <= 0:
+            return
+        if ringmode:
+            NC = len(engs)
+            p0 = ring_pos[0]            # the populations of a run visit the members in turn: the count goes on across calls
+            ring_pos[0] += count
+
+            def submit(j):
+                e = engs[(p0 + j) % NC]
+                e.randn(R, seed=args.seed + base + j, first_index=first)
+                e.ring_submit(phase1=True, seed=args.seed + base + j, first_index=first)
+            for j in range(min(NC - 1, count)):
+                submit(j)
+            for k in range(count):
+                e = engs[(p0 + k) % NC]
+                out = e.ring_collect()
+                if world > 1:
+                    b = e.comm_select_best(1e-4, index_offset=first)
+                else:
+                    sb = e.select_best(1e-4)
+                    b = (sb[0] + first, sb[1], sb[2], sb[3])
+                record(k, e, out, b)
+                if k + NC - 1 < count:
+                    submit(k + NC - 1)
             return
         if chained:
             NC = len(engs)
@@ -588,7 +607,7 @@ def main():
         acc['sweeps1'] += float(out['sweeps1'].sum())
         acc['sweeps2'] += float(out['visits2'].sum()) / n
         acc['p2_flops'] += float(out['visits2'].sum()) * 2.0 * n   # algorithmic: 2n flops per visit
-        acc['p2_ms'] += cur.kernel_ms(Engine.KERNEL_CD2)
+        acc['p2_ms'] += 0.0 if ringmode else cur.kernel_ms(Engine.KERNEL_CD2)      # (ring: one launch for the whole run)
         acc['p1_ms'] += cur.kernel_ms(Engine.KERNEL_CD1)
         best = acc['best']
         if best is None or dist.better_key(b[1], b[2], b[0]) < dist.better_key(best[1], best[2], best[0]):
@@ -603,6 +622,8 @@ def main():
     eng.sync()
     eng.comm_barrier()
     dt = time.perf_counter() - t0
+    if ringmode:
+        engs[0].ring_stop()
     dt = float(eng.comm_allreduce([dt], 'max')[0])
     tot = eng.comm_allreduce([sweeps1, sweeps2, p2_flops, p2_ms], 'sum')
     p2_ms_max = float(eng.comm_allreduce([p2_ms], 'max')[0])
@@ -612,8 +633,8 @@ def main():
     if rank == 0:
         K = max(args.steps, 1)
         achieved = (p2_flops / 1e12) / (p2_ms / 1e3) if p2_ms > 0 else 0.0      # rank 0's GPU, its own launches
-        if chained:
-            # the launches of consecutive steps overlap: the busy time of the phase-2 kernels is the timed region itself
+        if chained or ringmode:
+            # the launches of consecutive steps overlap / one launch serves all steps: the busy time of phase 2 is the timed region itself
             achieved = (p2_flops / 1e12) / dt
         pmc = profiled_counters()
         res = {
@@ -636,7 +657,12 @@ def main():
                                                                     'per GPU' if args.scaling == 'weak' else 'in total'),
                        'restarts_per_gpu': R, 'num_iters': 1000, 'viol_tol': 1e-2, 'tol': 1e-4,
                        'sharding': 'restarts by global index, replicas of P',
-                       'step_overlap': ('%d chained contexts per GPU (populations prepared %d steps ahead, a launch may run restarts of the next %d populations; phase-2 launches confined to %d CUs): the phase-2 launch of step k (slot-queue kernel: 16 restart slots '
+                       'scheme': 'ring' if ringmode else ('chain' if chained else 'two'),
+                       'step_overlap': ('ring: ONE persistent slot-queue launch (cd_phase2_qs_kernel: 16 restart slots per workgroup, refilled from '
+                                        'device-side queues at sweep boundaries) on %d CUs serves the populations of %d contexts in turn; suggest, '
+                                        'phase 1, evaluation and gate of the next populations run on the other CUs; no launch per step, no '
+                                        'exposed tail; results per restart do not depend on the scheduling' % (RING_CUS, RING_N)) if ringmode else
+                                       ('%d chained contexts per GPU (populations prepared %d steps ahead, a launch may run restarts of the next %d populations; phase-2 launches confined to %d CUs): the phase-2 launch of step k (slot-queue kernel: 16 restart slots '
                                         'per workgroup) takes restarts of step k+1 -- prepared meanwhile in the next context: suggest, '
                                         'phase 1, evaluation, gate -- once its own queue is empty; results per restart do not depend on '
                                         'the scheduling' % (len(engs), LA + 1, LA, args.p2_cus or 256)) if chained else
@@ -660,15 +686,61 @@ def main():
                          'mfma_busy': pmc['mfma_busy'] if pmc else None,
                          'algorithmic_flops_per_restart_sweep': 2.0 * n * n,
                          'algorithmic_flops_per_launch': p2_flops / K,
-                         'kernel_ms_per_launch': p2_ms / K,
+                         'kernel_ms_per_launch': None if ringmode else p2_ms / K,
                          'restarts_run_ahead_per_step': (sum(e_.cd_pulled() for e_ in engs) / float(args.steps + args.warmup)) if chained else None,
-                         'timing': ('chained launches overlap each other: flops of all timed steps / wall time of the timed region (%.4f s); '
+                         'timing': ('one persistent launch serves every step (busy throughout): flops of the timed steps / wall time of the '
+                                    'timed region (%.4f s)' % dt) if ringmode else
+                                   ('chained launches overlap each other: flops of all timed steps / wall time of the timed region (%.4f s); '
                                     'the sum of the HIP-event durations of the launches is %.1f ms per step' % (dt, p2_ms / K)) if chained
                                    else 'HIP events on the engine stream around every phase-2 launch of the timed steps'},
         }
         if world > 1:
             res['roofline']['kernel_ms_per_launch_max_over_ranks'] = p2_ms_max / K
             res['roofline']['achieved_all_gpus'] = (flops_all / 1e12) / (p2_ms_max / 1e3) if p2_ms_max > 0 else 0.0
+        if world == 1 and args.scheme == 'auto' and not args.child and not args.chain and args.overlap:
+            # The same K steps after the same W warm-up steps through the ring scheme, in a CHILD process with a time limit (the
+            # scheme needs the runtime started with more hardware queues, and a stall must not take the line down).  The faster
+            # scheme is the one reported; the other stays in the line.
+            two = {k_: res[k_] for k_ in ('value', 'ms_per_step', 'timed_region_s', 'phase2_sweeps_per_restart')}
+            two['roofline'] = {k_: res['roofline'][k_] for k_ in ('kernel', 'achieved', 'frac', 'kernel_ms_per_launch', 'timing')}
+            two['best'] = dict(res['best'])
+            two['step_overlap'] = res['config']['step_overlap']
+            try:
+                import subprocess
+                env = dict(os.environ)
+                env['GPU_MAX_HW_QUEUES'] = '16'
+                cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
+                       '--n', str(n), '--m-rows', str(args.m_rows), '--restarts', str(args.restarts), '--scaling', args.scaling,
+                       '--seed', str(args.seed), '--scheme', 'ring', '--child', '--no-secondary', '--no-cpu-baseline']
+                pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=90 + 0.02 * (args.steps + args.warmup))
+                line = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
+                if pr.returncode != 0 or not line:
+                    raise RuntimeError('child failed (rc %d): %s' % (pr.returncode, pr.stderr.decode()[-300:]))
+                rg = json.loads(line[-1])
+                same_best = (rg['best']['global_restart_index'] == res['best']['global_restart_index'] and rg['best']['step'] == res['best']['step']
+                             and abs(rg['best']['objective'] - res['best']['objective']) <= 1e-9 * (1.0 + abs(res['best']['objective'])))
+                res['schemes'] = {'two': two, 'ring': {k_: rg[k_] for k_ in ('value', 'ms_per_step', 'timed_region_s', 'phase2_sweeps_per_restart')}}
+                res['schemes']['ring']['roofline'] = {k_: rg['roofline'][k_] for k_ in ('kernel', 'achieved', 'frac', 'timing')}
+                res['schemes']['ring']['best'] = rg['best']
+                res['schemes']['ring']['same_best_point_as_two'] = bool(same_best)
+                res['schemes']['ring']['step_overlap'] = rg['config']['step_overlap']
+                if same_best and rg['value'] > res['value']:
+                    for k_ in ('value', 'ms_per_step', 'timed_region_s', 'phase2_sweeps_per_restart'):
+                        res[k_] = rg[k_]
+                    res['phase1'] = rg['phase1']
+                    for k_ in ('kernel', 'achieved', 'frac', 'kernel_ms_per_launch', 'timing', 'algorithmic_flops_per_launch'):
+                        res['roofline'][k_] = rg['roofline'][k_]
+                    # counters of the profiled run belong to the tile-bound kernel of the `two` scheme
+                    res['roofline']['traffic_note'] = 'traffic / mfma_busy: rocprofv3 counters of cd_phase2_q_kernel (scheme two)'
+                    res['config']['scheme'] = 'ring'
+                    res['config']['step_overlap'] = rg['config']['step_overlap']
+                    res['schemes']['reported'] = 'ring'
+                    res['schemes']['note'] = ('runs on more than one GPU use scheme two (the ring has not run on several GPUs yet): compare their '
+                                              'per-GPU value with schemes.two.value, not with value')
+                else:
+                    res['schemes']['reported'] = 'two'
+            except Exception as ex:      # time limit, missing runtime feature, ...: the line of this process stands
+                res['schemes'] = {'two': two, 'ring': {'error': repr(ex)[:400]}, 'reported': 'two'}
         if world == 1 and not args.no_secondary:
             res['secondary'] = secondary_records(local_rank, sdr_full=args.sdr_full)
         if world == 1 and not args.no_cpu_baseline:      # a reported baseline of rank 0 at N = 1 only
