@@ -597,7 +597,8 @@ def main():
                     cur.cd_phase2()
             record(k, cur, out, b)
 
-    run_steps(args.warmup, -1000, lambda *_: None)
+    warm_flops = [0.0]
+    run_steps(args.warmup, -1000, lambda k_, c_, out_, b_: warm_flops.__setitem__(0, warm_flops[0] + float(out_['visits2'].sum()) * 2.0 * n))
     for e_ in engs:
         e_.sync()
     eng.comm_barrier()
@@ -622,8 +623,10 @@ def main():
     eng.sync()
     eng.comm_barrier()
     dt = time.perf_counter() - t0
+    launch_ms = None
     if ringmode:
         engs[0].ring_stop()
+        launch_ms = engs[0].kernel_ms(Engine.KERNEL_CD2)      # HIP events on the ring's stream around the ONE persistent launch
     dt = float(eng.comm_allreduce([dt], 'max')[0])
     tot = eng.comm_allreduce([sweeps1, sweeps2, p2_flops, p2_ms], 'sum')
     p2_ms_max = float(eng.comm_allreduce([p2_ms], 'max')[0])
@@ -687,6 +690,12 @@ def main():
                          'algorithmic_flops_per_restart_sweep': 2.0 * n * n,
                          'algorithmic_flops_per_launch': p2_flops / K,
                          'kernel_ms_per_launch': None if ringmode else p2_ms / K,
+                         'persistent_launch': ({'ms': launch_ms, 'flops_served': warm_flops[0] + p2_flops,
+                                                'achieved': (warm_flops[0] + p2_flops) / 1e12 / (launch_ms / 1e3) if launch_ms else None,
+                                                'note': 'HIP events on the ring stream around the ONE launch that served the %d warm-up and the %d '
+                                                        'timed steps: it also spans the waits before, between and after them (the duration '
+                                                        'rocprofv3 reports for cd_phase2_qs_kernel)' % (args.warmup, args.steps)}
+                                               if ringmode else None),
                          'restarts_run_ahead_per_step': (sum(e_.cd_pulled() for e_ in engs) / float(args.steps + args.warmup)) if chained else None,
                          'timing': ('one persistent launch serves every step (busy throughout): flops of the timed steps / wall time of the '
                                     'timed region (%.4f s)' % dt) if ringmode else
@@ -728,7 +737,7 @@ def main():
                     for k_ in ('value', 'ms_per_step', 'timed_region_s', 'phase2_sweeps_per_restart'):
                         res[k_] = rg[k_]
                     res['phase1'] = rg['phase1']
-                    for k_ in ('kernel', 'achieved', 'frac', 'kernel_ms_per_launch', 'timing', 'algorithmic_flops_per_launch'):
+                    for k_ in ('kernel', 'achieved', 'frac', 'kernel_ms_per_launch', 'timing', 'algorithmic_flops_per_launch', 'persistent_launch'):
                         res['roofline'][k_] = rg['roofline'][k_]
                     # counters of the profiled run belong to the tile-bound kernel of the `two` scheme
                     res['roofline']['traffic_note'] = 'traffic / mfma_busy: rocprofv3 counters of cd_phase2_q_kernel (scheme two)'
