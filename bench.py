@@ -17,6 +17,14 @@ selection (RCCL all-gather + broadcast inside libqcqp_mi.so).
 
 `value` counts PHASE-2 restart-sweeps only (the unit SURVEY.md section 8d defines: 2 n^2 flops each);
 phase-1 sweeps (element-wise for this family) are reported separately.
+
+How the steps are scheduled (--scheme, DESIGN.md sections 4.1c / 6).  `two`: two contexts per GPU, the preparation of step
+k + 1 runs in the tail of the phase-2 kernel of step k, phase-2 launches never overlap.  `ring`: ONE persistent phase-2 launch
+on 192 CUs serves the populations of four contexts in turn, the other 64 CUs prepare the next populations.  `auto` (default):
+the K steps after W warm-up steps are measured with `two` in this process and then -- on one GPU -- with `ring` in a child
+process with a time limit (the ring needs the HIP runtime started with more hardware queues, and a stall must not cost the
+line); the faster scheme is reported, both are in the line (`schemes`), the best point must be the same.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
