@@ -785,3 +785,25 @@ def test_cd_chained_contexts_match_serial_runs(eng_mod, NC, LA, DL):
             assert np.array_equal(o[key], ro[key]), (k, key)
         assert rel(o['f0'], ro['f0']) < 1e-12 and np.array_equal(o['maxviol'], ro['maxviol']), k
         assert b[0] == rb[0] and abs(b[1] - rb[1]) <= 1e-12 * (1 + abs(rb[1])), k
+
+
+def test_cd_ring_scheme_equals_serial_runs():
+    """The scheme `python bench.py` reports on one GPU: ONE persistent cd_phase2_qs_kernel launch on 192 CUs serves the populations of
+    four contexts in turn (qcqpmi_cd_ring_start / submit / collect / stop).  Run in a child process -- the HIP
+    runtime must be started with GPU_MAX_HW_QUEUES > 4, which cannot be changed in this process any more -- with a time limit:
+    the first steps must equal the same steps made one after the other with the tile-bound kernel (points to 1e-12, counters
+    identical, the same best restart: coord_descent_phase2, qcqp.py:152-178, does not depend on the scheduling), and the run must
+    end (the launch leaves on the host's request)."""
+    import json
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'ring_bench.py')
+    env = dict(os.environ)
+    env['GPU_MAX_HW_QUEUES'] = '16'
+    pr = subprocess.run([sys.executable, tool, '4096', '16', '4', '192', '4'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    lines = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
+    assert pr.returncode == 0 and lines, pr.stderr.decode()[-500:]
+    rb = json.loads(lines[-1])
+    assert rb['steps_compared'] == 4 and rb['first_steps_equal_serial_tile_bound_kernel'] is True, rb
+    assert rb['best']['maxviol'] < 1e-2 and rb['value'] > 0
+    print('\nring scheme: %.2f ms per step (16 steps after 4 warm-up steps), %.3f of the fp64 peak' % (rb['ms_per_step'], rb['frac']))
