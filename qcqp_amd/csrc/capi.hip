@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <set>
 
 #include "../../include/qcqp_mi.h"
 #include "kernels.hip"
@@ -1554,6 +1555,72 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
 
 // ---- ring mode: one persistent launch for the populations of up to four contexts --------------------------------------
+// ---- CU masks (hipExtStreamCreateWithCUMask).  Measured (tools/ubench/cumask2.hip): the bits of the mask do NOT map evenly
+// to the 8 XCDs -- "the first k bits" gives every XCD k / 8 CUs only when k is a multiple of 32 (192: 24 each, 224: 28 each;
+// 208: 25 24 25 26 24 24 25 24), and a persistent launch of k workgroups that need a CU each is dealt k / 8 workgroups per
+// XCD: with an uneven mask some of them never become resident.  Other partition sizes are therefore built bit by bit under
+// the eyes of a probe kernel that reports which CUs a masked stream really reaches.
+__global__ void cu_probe_kernel(unsigned *out, long long ticks) {
+    extern __shared__ double probe_lds[];
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (threadIdx.x == 0) {
+        probe_lds[0] = 1.0;
+        out[2 * blockIdx.x] = xcc & 0xf; out[2 * blockIdx.x + 1] = (hw >> 8) & 0xfff;      // CU id [11:8], SH [12], SE [15:13]
+        const long long t0 = (long long)wall_clock64();
+        while ((long long)wall_clock64() - t0 < ticks) {}                                  // hold the CU: the other workgroups must go elsewhere
+    }
+}
+
+// CUs per XCD a stream with this mask reaches (256 probe workgroups of 150 KB LDS: one per CU at a time)
+static int cu_mask_probe(qcqpmi_ctx *c, const std::vector<uint32_t> &mask, unsigned *d_out, int per_xcc[8]) {
+    hipStream_t s = nullptr;
+    HIPCHK(c, hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    const int wgs = 256;
+    hipError_t e = hipFuncSetAttribute((const void *)cu_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cu_probe_kernel, dim3(wgs), dim3(64), 150 * 1024, s, d_out, (long long)khz / 2);      // 0.5 ms each
+        e = hipStreamSynchronize(s);
+    }
+    std::vector<unsigned> h((size_t)wgs * 2);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d_out, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+    (void)hipStreamDestroy(s);
+    if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "CU mask probe: %s", hipGetErrorString(e));
+    std::set<unsigned> seen[8];
+    for (int i = 0; i < wgs; i++) seen[h[2 * i] & 7].insert(h[2 * i + 1]);
+    for (int x = 0; x < 8; x++) per_xcc[x] = (int)seen[x].size();
+    return 0;
+}
+
+// a mask that reaches exactly cus / 8 CUs of every XCD (cus a multiple of 8)
+static int cu_mask_balanced(qcqpmi_ctx *c, int cus_total, int cus, std::vector<uint32_t> &mask) {
+    const int words = (cus_total + 31) / 32, target = cus / 8;
+    mask.assign((size_t)words, 0u);
+    if (cus % 8 != 0 || target < 1) return fail(c, QCQPMI_EINVAL, "CU partition of %d CUs: not a multiple of 8", cus);
+    const int base = cus / 32 * 32;
+    for (int i = 0; i < base; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+    if (cus == base) return 0;                      // whole words are even (measured)
+    unsigned *d_out = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_out, 512 * sizeof(unsigned)));
+    int per[8], rc = 0;
+    bool done = false;
+    for (int bit = base; bit < cus_total && !done && !rc; bit++) {
+        mask[(size_t)bit / 32] |= 1u << (bit % 32);
+        if ((rc = cu_mask_probe(c, mask, d_out, per))) break;
+        bool over = false, all = true;
+        for (int x = 0; x < 8; x++) { over = over || per[x] > target; all = all && per[x] == target; }
+        if (over) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+        done = all && !over;
+    }
+    (void)hipFree(d_out);
+    if (rc) return rc;
+    if (!done) return fail(c, QCQPMI_EUNSUPPORTED, "no CU mask with %d CUs on every XCD found", target);
+    return 0;
+}
+
 int qcqpmi_cd_ring_start(qcqpmi_ctx **ctxs, int count, int phase2_cus, int64_t num_iters, double tol) {
     if (!ctxs || count < 2 || count > CDQ_MAXB || !ctxs[0]) return QCQPMI_EINVAL;
     qcqpmi_ctx *o = ctxs[0];
@@ -1593,8 +1660,14 @@ int qcqpmi_cd_ring_start(qcqpmi_ctx **ctxs, int count, int phase2_cus, int64_t n
     HIPCHK(o, hipStreamSynchronize(o->stream));
     if (o->ring_stream) { (void)hipStreamDestroy(o->ring_stream); o->ring_stream = nullptr; }
     if (phase2_cus < cus) {
-        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);      // bits are dealt round-robin to the XCDs (tools/ubench/cumask.hip)
-        for (int i = 0; i < phase2_cus; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+        // Partitions of whole mask words (192, 224 CUs) are the ones that work: with others -- also with a mask built bit by bit to
+        // reach the same number of CUs on every XCD (cu_mask_balanced, verified by the probe) -- the run stalls after a few
+        // populations or crawls (profiles/r03_queue_chain_ring.md); not understood yet, hence refused unless asked for.
+        if (phase2_cus % 32 != 0 && !getenv("QCQPMI_RING_ANY_PARTITION"))
+            return fail(o, QCQPMI_EUNSUPPORTED, "cd_ring_start: a partition of %d CUs is not a multiple of 32 (only whole words of the CU mask behave: "
+                        "192 or 224 of 256)", phase2_cus);
+        std::vector<uint32_t> mask;
+        if ((rc = cu_mask_balanced(o, cus, phase2_cus, mask))) return rc;      // the same number of CUs on every XCD
         HIPCHK(o, hipExtStreamCreateWithCUMask(&o->ring_stream, (uint32_t)mask.size(), mask.data()));
     } else {
         HIPCHK(o, hipStreamCreateWithFlags(&o->ring_stream, hipStreamNonBlocking));
