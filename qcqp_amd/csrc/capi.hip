@@ -1602,10 +1602,20 @@ static int cu_mask_balanced(qcqpmi_ctx *c, int cus_total, int cus, std::vector<u
     if (cus % 8 != 0 || target < 1) return fail(c, QCQPMI_EINVAL, "CU partition of %d CUs: not a multiple of 8", cus);
     const int base = cus / 32 * 32;
     for (int i = 0; i < base; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
-    if (cus == base) return 0;                      // whole words are even (measured)
     unsigned *d_out = nullptr;
     HIPCHK(c, hipMalloc((void **)&d_out, 512 * sizeof(unsigned)));
     int per[8], rc = 0;
+    if (cus == base) {
+        // whole words are even on the devices measured; checked all the same (which CUs are fused off differs from chip to chip)
+        rc = cu_mask_probe(c, mask, d_out, per);
+        (void)hipFree(d_out);
+        if (rc) return rc;
+        for (int x = 0; x < 8; x++)
+            if (per[x] != target)
+                return fail(c, QCQPMI_EUNSUPPORTED, "the first %d bits of the CU mask reach %d %d %d %d %d %d %d %d CUs of the XCDs on this device, "
+                            "not %d each", cus, per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7], target);
+        return 0;
+    }
     bool done = false;
     for (int bit = base; bit < cus_total && !done && !rc; bit++) {
         mask[(size_t)bit / 32] |= 1u << (bit % 32);

@@ -802,6 +802,8 @@ def test_cd_ring_scheme_equals_serial_runs():
     env['GPU_MAX_HW_QUEUES'] = '16'
     pr = subprocess.run([sys.executable, tool, '4096', '16', '4', '192', '4'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     lines = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
+    if pr.returncode != 0 and b'CU mask reach' in pr.stderr:
+        pytest.skip('this device offers no even 192-CU partition: ' + pr.stderr.decode().strip().splitlines()[-1][-200:])
     assert pr.returncode == 0 and lines, pr.stderr.decode()[-500:]
     rb = json.loads(lines[-1])
     assert rb['steps_compared'] == 4 and rb['first_steps_equal_serial_tile_bound_kernel'] is True, rb
