@@ -1574,9 +1574,10 @@ __global__ void cu_probe_kernel(unsigned *out, long long ticks) {
 }
 
 // CUs per XCD a stream with this mask reaches (256 probe workgroups of 150 KB LDS: one per CU at a time)
-static int cu_mask_probe(qcqpmi_ctx *c, const std::vector<uint32_t> &mask, unsigned *d_out, int per_xcc[8]) {
+static int cu_mask_probe(qcqpmi_ctx *c, const std::vector<uint32_t> &mask, unsigned *d_out, int per_xcc[8], std::set<unsigned> *ids = nullptr) {
     hipStream_t s = nullptr;
-    HIPCHK(c, hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    if (mask.empty()) HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));      // no mask: every CU
+    else HIPCHK(c, hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
     const int wgs = 256;
@@ -1592,6 +1593,7 @@ static int cu_mask_probe(qcqpmi_ctx *c, const std::vector<uint32_t> &mask, unsig
     std::set<unsigned> seen[8];
     for (int i = 0; i < wgs; i++) seen[h[2 * i] & 7].insert(h[2 * i + 1]);
     for (int x = 0; x < 8; x++) per_xcc[x] = (int)seen[x].size();
+    if (ids) for (int x = 0; x < 8; x++) ids[x] = seen[x];
     return 0;
 }
 
@@ -1605,11 +1607,26 @@ static int cu_mask_balanced(qcqpmi_ctx *c, int cus_total, int cus, std::vector<u
     unsigned *d_out = nullptr;
     HIPCHK(c, hipMalloc((void **)&d_out, 512 * sizeof(unsigned)));
     int per[8], rc = 0;
+    // a precaution: every shader array (HW_ID: SE [15:13], SH [12]) keeps a CU outside the partition, in case workgroups of the
+    // other streams are dealt to the arrays in turn.  (It is NOT what makes partitions other than 192 / 224 stall: masks built
+    // under this rule stall as well.)
+    std::set<unsigned> all[8], in[8];
+    if ((rc = cu_mask_probe(c, std::vector<uint32_t>(), d_out, per, all))) { (void)hipFree(d_out); return rc; }
+    auto arrays_ok = [&](const std::set<unsigned> (&m)[8]) {
+        for (int x = 0; x < 8; x++) {
+            int tot[16] = {0}, used[16] = {0};
+            for (unsigned id : all[x]) tot[(id >> 4) & 15]++;
+            for (unsigned id : m[x]) used[(id >> 4) & 15]++;
+            for (int a = 0; a < 16; a++) if (tot[a] > 0 && used[a] >= tot[a]) return false;
+        }
+        return true;
+    };
     if (cus == base) {
         // whole words are even on the devices measured; checked all the same (which CUs are fused off differs from chip to chip)
-        rc = cu_mask_probe(c, mask, d_out, per);
+        rc = cu_mask_probe(c, mask, d_out, per, in);
         (void)hipFree(d_out);
         if (rc) return rc;
+        if (!arrays_ok(in)) return fail(c, QCQPMI_EUNSUPPORTED, "the first %d bits of the CU mask take every CU of a shader array on this device", cus);
         for (int x = 0; x < 8; x++)
             if (per[x] != target)
                 return fail(c, QCQPMI_EUNSUPPORTED, "the first %d bits of the CU mask reach %d %d %d %d %d %d %d %d CUs of the XCDs on this device, "
@@ -1619,11 +1636,11 @@ static int cu_mask_balanced(qcqpmi_ctx *c, int cus_total, int cus, std::vector<u
     bool done = false;
     for (int bit = base; bit < cus_total && !done && !rc; bit++) {
         mask[(size_t)bit / 32] |= 1u << (bit % 32);
-        if ((rc = cu_mask_probe(c, mask, d_out, per))) break;
-        bool over = false, all = true;
-        for (int x = 0; x < 8; x++) { over = over || per[x] > target; all = all && per[x] == target; }
+        if ((rc = cu_mask_probe(c, mask, d_out, per, in))) break;
+        bool over = !arrays_ok(in), full = true;
+        for (int x = 0; x < 8; x++) { over = over || per[x] > target; full = full && per[x] == target; }
         if (over) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
-        done = all && !over;
+        done = full && !over;
     }
     (void)hipFree(d_out);
     if (rc) return rc;
