@@ -276,7 +276,12 @@ int qcqpmi_cd_partition(qcqpmi_ctx *ctx, int phase2_cus);
  *   qcqpmi_cd_ring_submit   phase 1 + evaluation + gate of the member's resident population on its own stream, then the
  *                            population is published to the launch (asynchronous)
  *   qcqpmi_cd_ring_collect  waits until every restart of that population is done, returns what qcqpmi_cd_run returns
- * Per restart the results are those of qcqpmi_cd_run (they do not depend on the scheduling). */
+ * Per restart the results are those of qcqpmi_cd_run (they do not depend on the scheduling).
+ * Requirements (measured, profiles/r03_queue_chain_ring.md): the process must have started the HIP runtime with
+ * GPU_MAX_HW_QUEUES > 4 (with the default a member's stream shares a hardware queue with the persistent launch and its
+ * kernels never run); phase2_cus must be 0 or a multiple of 32 -- whole words of the CU mask: 192 or 224 of 256 -- and is
+ * verified with a probe kernel (the same number of CUs on every XCD, a free CU in every shader array), else
+ * QCQPMI_EUNSUPPORTED.  The headline step of bench.py runs in 2.7 ms this way (two contexts with a launch per step: 3.4 ms). */
 int qcqpmi_cd_ring_start(qcqpmi_ctx **members, int count, int phase2_cus, int64_t num_iters, double tol);
 int qcqpmi_cd_ring_submit(qcqpmi_ctx *member, int phase1, int64_t num_iters, double viol_tol, double tol, uint64_t seed,
                           uint64_t first_index);
