@@ -267,7 +267,7 @@ int qcqpmi_cd_chain(qcqpmi_ctx *ctx, int pos, qcqpmi_ctx *next, int64_t next_R, 
  * its workgroups are persistent and hold a CU each (LDS), so with chained contexts the kernels that prepare the next
  * populations would otherwise find no free CU until workgroups run out of work. */
 int qcqpmi_cd_partition(qcqpmi_ctx *ctx, int phase2_cus);
-/* Ring mode: ONE persistent slot-queue launch (on `phase2_cus` CUs; 0 = all) serves the populations of 2..4 contexts of the
+/* Ring mode: ONE persistent slot-queue launch (on `phase2_cus` CUs; 0 = all) serves the populations of 2..8 contexts of the
  * same problem in turn -- population j of a run lives in member j mod count -- until qcqpmi_cd_ring_stop: no launch per
  * step, no exposed tail between steps (a slot whose restart is done takes the next restart of whatever population is
  * published), and the kernels that prepare populations always find the remaining CUs free.  Every member must hold a

@@ -30,7 +30,7 @@ struct CdBatch {                 // one population = the restarts of one improve
     int ready_gen;               // generation number the owner of that population publishes when it has prepared it
 };
 
-constexpr int CDQ_MAXB = 4;      // populations a launch can see: its own and the next three
+constexpr int CDQ_MAXB = 8;      // populations a launch can see (chained launches: its own and the next three; ring: the members)
 
 // Ring mode: the queue state of a population lives in 16 device ints of its context (`next` points at them):
 //   [0] queue head  [1] generation published  [2] restarts run ahead (statistics)  [3] restarts done  [4] R
@@ -38,7 +38,7 @@ constexpr int CDQ_MAXB = 4;      // populations a launch can see: its own and th
 // Population number j of a run (j = 0, 1, ...) lives in entry j % nb with generation j / nb + 1.
 struct CdQueueArgs {
     DevProblem P;
-    CdBatch b[4];                // b[0]: the population this launch belongs to; b[1..nb-1]: the next ones (run ahead), in order
+    CdBatch b[CDQ_MAXB];         // b[0]: the population this launch belongs to; b[1..nb-1]: the next ones (run ahead), in order
     int nb;
     int64_t num_iters;
     double tol;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
         for (int f = 0; f < 8; f++) cst[f * 64 + tid0] = (f == 4) ? 1 : 0;
     }
     if (tid0 < 16) { sid[tid0] = -1; sbt[tid0] = 0; sfin[tid0] = 0; }
-    if (tid0 == 0) { if (MULTI) { Bt[0] = a0.b[0]; Bt[1] = a0.b[1]; Bt[2] = a0.b[2]; Bt[3] = a0.b[3]; } ctl[1] = 0; ctl[2] = 0; }
+    if (tid0 == 0) { if (MULTI) for (int q = 0; q < CDQ_MAXB; q++) Bt[q] = a0.b[q]; ctl[1] = 0; ctl[2] = 0; }
     const long long ring_t0 = a.ring ? (long long)wall_clock64() : 0;
     __syncthreads();
     const int64_t gmax = (int64_t)1 << 40;         // the roles end through RQ_STOP

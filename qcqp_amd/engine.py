@@ -337,7 +337,7 @@ class Engine(object):
     # ring mode: one persistent phase-2 launch for the populations of several engines (qcqpmi_cd_ring_*)
     @staticmethod
     def ring_start(engines, phase2_cus=0, num_iters=1000, tol=1e-4):
-        """Start the persistent slot-queue launch for `engines` (2..4, same problem, resident populations of one size, each
+        """Start the persistent slot-queue launch for `engines` (2..8, same problem, resident populations of one size, each
         having run one ordinary cd_run before).  engines[0] owns the launch."""
         arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
         rc = engines[0].L.qcqpmi_cd_ring_start(arr, len(engines), int(phase2_cus), int(num_iters), float(tol))
