@@ -696,7 +696,8 @@ def main():
                                                 if pmc else None),
                          'mfma_busy': pmc['mfma_busy'] if pmc else None,
                          'algorithmic_flops_per_restart_sweep': 2.0 * n * n,
-                         'algorithmic_flops_per_launch': p2_flops / K,
+                         'algorithmic_flops_per_launch': None if ringmode else p2_flops / K,      # (ring: ONE launch serves every step)
+                         'algorithmic_flops_per_step': p2_flops / K,
                          'kernel_ms_per_launch': None if ringmode else p2_ms / K,
                          'persistent_launch': ({'ms': launch_ms, 'flops_served': warm_flops[0] + p2_flops,
                                                 'achieved': (warm_flops[0] + p2_flops) / 1e12 / (launch_ms / 1e3) if launch_ms else None,
@@ -745,7 +746,8 @@ def main():
                     for k_ in ('value', 'ms_per_step', 'timed_region_s', 'phase2_sweeps_per_restart'):
                         res[k_] = rg[k_]
                     res['phase1'] = rg['phase1']
-                    for k_ in ('kernel', 'achieved', 'frac', 'kernel_ms_per_launch', 'timing', 'algorithmic_flops_per_launch', 'persistent_launch'):
+                    for k_ in ('kernel', 'achieved', 'frac', 'kernel_ms_per_launch', 'timing', 'algorithmic_flops_per_launch', 'algorithmic_flops_per_step',
+                               'persistent_launch'):
                         res['roofline'][k_] = rg['roofline'][k_]
                     # counters of the profiled run belong to the tile-bound kernel of the `two` scheme
                     res['roofline']['traffic_note'] = 'traffic / mfma_busy: rocprofv3 counters of cd_phase2_q_kernel (scheme two)'
