@@ -177,6 +177,14 @@ int qcqpmi_admm_setup(qcqpmi_ctx *ctx);
  * eigenvalues given here, not from LAPACK's round-off eigenvalues of the null space: results agree
  * with the full-basis path to the accuracy of the reference's own bisection (1e-6 on every multiplier). */
 int qcqpmi_admm_set_basis(qcqpmi_ctx *ctx, int64_t rp, const double *lam, const double *Bv, const double *qhat);
+/* Optional: the multiplier bracket [slo_k, ehi_k] (m values each, host) that the bisection of onecons_qcqp starts from
+ * (utilities.py:176-186), replacing the one qcqpmi_admm_set_eig / _set_basis / _setup derived from their own eigenvalues;
+ * -inf / +inf = "no eigenvalue of that sign": the reference's doubling search from -1 / +1.  The reference brackets with
+ * EVERY eigenvalue LAPACK returns, round-off eigenvalues of the null space included (a rank-2 PSD matrix has n - 2
+ * eigenvalues ~ +-1e-15, so ehi = -1 / min(lmb) ~ 1e14 instead of the doubling search); with the reference's
+ * bracket the reduced-basis path visits the reference's midpoints and returns its multiplier bit for bit instead of
+ * "within the bisection tolerance 1e-6".  The parity tests pass the bracket of the eigenvalues they hand the oracle. */
+int qcqpmi_admm_set_bracket(qcqpmi_ctx *ctx, const double *slo, const double *ehi);
 /* out[k] = P_k Vin_k for every constraint k (n x p blocks, row-major; shared != 0: one Vin for all): the two passes over
  * the resident dense constraint matrices that a randomised range finder needs (Y = P Omega, Z = P Q) -- the device-side
  * part of building the reduced bases above without an O(n^3) eigendecomposition per constraint. */
@@ -299,6 +307,17 @@ int qcqpmi_debug_cd_pulled(qcqpmi_ctx *ctx, int64_t *out);
  * input noise amplified by the phase-1 bisection) is only comparable as a distribution.  Needs uploaded (not generated)
  * functions with m n^2 <= 2e9 entries.  enable = 0 restores the default dispatch. */
 int qcqpmi_cd_reference_order(qcqpmi_ctx *ctx, int enable);
+/* The UNIT STEP of the default dense-constraint path (products on the matrix cores + dense_chain_mw_kernel) on the resident
+ * points: the coordinate visits [coord_lo, coord_hi) (0, 16 = all) of block `block` in sweep `sweep` of phase 1
+ * (qcqp.py:112-141) or phase 2 (qcqp.py:160-176), started from fresh function values, with the keyed draws of that sweep.
+ * phase 2: slack (R values, host) is the `viol` the reference fixes at the start of the phase (qcqp.py:157); NULL takes the
+ * max violation of the resident points.  This is what the parity tests teacher-force with the states the oracle visits:
+ * coordinate descent with coupled constraints is chaotic in the reference itself (one ulp of x0 moves 40 % of the dense
+ * family's and every beamforming restart by > 1e-6: profiles/r04_reference_sensitivity.md, tests/test_host_cpu.py), so a
+ * free-running trajectory can only be compared for bit-identical arithmetic (qcqpmi_cd_reference_order) -- the fast path is
+ * compared visit by visit and block by block on the reference's own states. */
+int qcqpmi_cd_dense_block_step(qcqpmi_ctx *ctx, int phase, int64_t sweep, int64_t block, int coord_lo, int coord_hi,
+                               double viol_tol, double tol, uint64_t seed, uint64_t first_index, const double *slack);
 /* Chain kernel of the dense-constraint path: 0 (default) dense_chain_mw_kernel -- a workgroup of four waves per restart,
  * the functions dealt to 256 threads -- whenever m + 1 <= 2048; 1: dense_chain_kernel, one wave per restart (round 1-2
  * kernel, the cross-check: the two produce the same points bit for bit). */

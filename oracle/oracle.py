@@ -89,6 +89,10 @@ def lib():
                                        C.c_void_p, _ip]
         L.orc_improve_cd.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_double, C.c_double,
                                      C.c_int, C.c_void_p, _ip, _ip]
+        L.orc_cd_trace.restype = None
+        L.orc_cd_trace.argtypes = [_dp, C.c_int64]
+        L.orc_cd_trace_len.restype = C.c_int64
+        L.orc_cd_trace_len.argtypes = []
         L.orc_cd_phase2_incremental.argtypes = [C.c_void_p, _dp, _dp, C.c_int64, C.c_double, C.c_void_p, _ip]
         L.orc_onecons.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, C.c_double, _dp]
         L.orc_admm_phase1.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, C.c_int64, _ip]
@@ -253,6 +257,43 @@ class Problem:
         if rc:
             raise RuntimeError('oracle improve_cd failed rc=%d' % rc)
         return x, s1, s2
+
+    def improve_cd_traced(self, x, num_iters=1000, viol_tol=1e-2, tol=1e-4, rng=None):
+        """improve_coord_descent (qcqp.py:181-192) with every intermediate state: returns (x, stats1, stats2, tr1, tr2,
+        slack2) -- tr1 / tr2 = the value of x[i] after each coordinate visit of phase 1 / phase 2 in visiting order (visit
+        v is coordinate v mod n of sweep v // n), slack2 = the `viol` phase 2 fixes at its start (qcqp.py:157), None if
+        the gate (qcqp.py:189) kept phase 2 from running.  The state after any visit is x0 with the recorded values
+        applied in order: what the teacher-forced parity tests of the dense path feed the engine."""
+        L = lib()
+        n = self.n
+        rng = rng or Rng(RNG_MT, 0, from_numpy_global=True)
+        x = _vec(x).copy()
+        buf = np.zeros(max(1, num_iters * n))
+        s1 = np.zeros(3, dtype=np.int64)
+        s2 = np.zeros(3, dtype=np.int64)
+        L.orc_cd_trace(_d(buf), buf.size)
+        try:
+            rc = L.orc_cd_phase1(self.h, _d(x), num_iters, viol_tol, tol, rng.h, _i(s1))
+            k1 = int(L.orc_cd_trace_len())
+        finally:
+            L.orc_cd_trace(None, 0)
+        if rc:
+            raise RuntimeError('oracle orc_cd_phase1 failed rc=%d' % rc)
+        tr1 = buf[:k1].copy()
+        tr2, slack2 = np.zeros(0), None
+        mv = self.max_violation(x)
+        if mv < viol_tol:
+            slack2 = mv
+            L.orc_cd_trace(_d(buf), buf.size)
+            try:
+                rc = L.orc_cd_phase2(self.h, _d(x), num_iters, viol_tol, tol, rng.h, _i(s2))
+                k2 = int(L.orc_cd_trace_len())
+            finally:
+                L.orc_cd_trace(None, 0)
+            if rc:
+                raise RuntimeError('oracle orc_cd_phase2 failed rc=%d' % rc)
+            tr2 = buf[:k2].copy()
+        return x, s1, s2, tr1, tr2, slack2
 
     # ---- utilities.py:149-196
     def eig(self):

@@ -506,6 +506,14 @@ static int64_t gather_onevars(const orc_prob *p, const double *x, int64_t i,
     return mf;
 }
 
+/* test hook: the value of x[i] after every coordinate visit of the coordinate-descent runs that follow (phase 1 and
+ * phase 2 append to the same buffer; the state after any visit is x0 with the recorded values applied in order) */
+static double *g_trace = NULL;
+static int64_t g_trace_cap = 0, g_trace_len = 0;
+void orc_cd_trace(double *buf, int64_t cap) { g_trace = buf; g_trace_cap = buf ? cap : 0; g_trace_len = 0; }
+int64_t orc_cd_trace_len(void) { return g_trace_len; }
+#define ORC_TRACE(v) do { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len] = (v); if (g_trace) g_trace_len++; } while (0)
+
 int orc_cd_phase1(const orc_prob *p, double *x, int64_t num_iters, double viol_tol,
                   double tol, orc_rng *g, int64_t *stats) {
     int64_t n = p->n;
@@ -541,8 +549,9 @@ int orc_cd_phase1(const orc_prob *p, double *x, int64_t num_iters, double viol_t
                 else { new_xi = xi; new_viol = s; es = s; }
             }
             if (rc) break;
-            if (new_viol < viol) { x[i] = new_xi; update_counter = 0; accepted++; }
+            if (new_viol < viol) { x[i] = new_xi; update_counter = 0; accepted++; ORC_TRACE(x[i]); }
             else {
+                ORC_TRACE(x[i]);
                 update_counter++;
                 if (update_counter == n) break; /* failed = True; outer loop goes on (qcqp.py:138-141) */
             }
@@ -576,8 +585,9 @@ int orc_cd_phase2(const orc_prob *p, double *x, int64_t num_iters, double viol_t
             int got = orc_onevar_qcqp(obj[0], obj[1], obj[2], fs3, relops, mf, viol, g, &new_xi,
                                       NULL, 0, NULL);
             if (got < 0) { rc = got; break; }
-            if (got && fabs(new_xi - x[i]) > tol) { x[i] = new_xi; update_counter = 0; accepted++; }
+            if (got && fabs(new_xi - x[i]) > tol) { x[i] = new_xi; update_counter = 0; accepted++; ORC_TRACE(x[i]); }
             else {
+                ORC_TRACE(x[i]);
                 update_counter++;
                 if (update_counter == n) { converged = 1; break; }
             }

@@ -52,6 +52,7 @@ PROTOTYPES = [
     ('qcqpmi_admm_set_basis', C.c_int, [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp]),
     ('qcqpmi_admm_apply_constraints', C.c_int, [C.c_void_p, C.c_int, c_dp, C.c_int, c_dp]),
     ('qcqpmi_admm_onecons', C.c_int, [C.c_void_p, C.c_int64, c_dp]),
+    ('qcqpmi_admm_set_bracket', C.c_int, [C.c_void_p, c_dp, c_dp]),
     ('qcqpmi_admm_zsolver_device', C.c_int, [C.c_void_p, C.c_double, C.c_int64, c_dp, c_ip]),
     ('qcqpmi_p0_lambda_min', C.c_int, [C.c_void_p, C.c_int64, C.c_double, c_dp, c_ip]),
     ('qcqpmi_admm_run', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double, c_dp,
@@ -62,6 +63,7 @@ PROTOTYPES = [
     ('qcqpmi_last_kernel_ms', C.c_int, [C.c_void_p, C.c_int, c_dp]),
     ('qcqpmi_last_cd_kernel', C.c_char_p, [C.c_void_p]),
     ('qcqpmi_cd_reference_order', C.c_int, [C.c_void_p, C.c_int]),
+    ('qcqpmi_cd_dense_block_step', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint64, c_dp]),
     ('qcqpmi_cd_queue', C.c_int, [C.c_void_p, C.c_int]),
     ('qcqpmi_cd_ring_start', C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_double]),
     ('qcqpmi_cd_ring_submit', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64]),

@@ -1,6 +1,7 @@
 // C ABI of libqcqp_mi.so (declared in include/qcqp_mi.h): context, problem upload, population
 // management, launches of the kernels in kernels.hip, HIP-event timing, lazy RCCL.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -1514,6 +1515,15 @@ int qcqpmi_cd_run(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol,
                                ran_phase2, f0, maxviol);
 }
 
+int qcqpmi_cd_dense_block_step(qcqpmi_ctx *c, int phase, int64_t sweep, int64_t block, int coord_lo, int coord_hi, double viol_tol,
+                               double tol, uint64_t seed, uint64_t first_index, const double *slack) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!dense_on(c)) return fail(c, QCQPMI_EUNSUPPORTED, "cd_dense_block_step: the problem does not take the dense-constraint path");
+    c->last_cd2_kernel = dense_chain_name(c);
+    return cd_dense_block_step(c, phase, sweep, block, coord_lo, coord_hi, viol_tol, tol, seed, first_index, slack);
+}
+
 int qcqpmi_cd_status(qcqpmi_ctx *c, int *status1, int *status2) {
     if (!c) return QCQPMI_EINVAL;
     if ((int64_t)c->last_st1.size() != c->R || (int64_t)c->last_st2.size() != c->R)
@@ -1742,12 +1752,22 @@ int qcqpmi_cd_ring_collect(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, in
     if (rc) return rc;
     if (!c->ring_owner || c->cd_stage != 2) return fail(c, QCQPMI_ESTATE, "cd_ring_collect: nothing submitted");
     HIPCHK(c, hipSetDevice(c->device));
+    // Wait for the population's `done` counter.  The wait is bounded by the LAUNCH, not by a number of polls (a large population
+    // with slow restarts, or a GPU shared with other members, may legitimately take long): as long as the persistent launch
+    // runs it is working on submitted populations -- it leaves by the quit word or by its own wall-clock limit (ten minutes,
+    // cd_ring_start); once it has ended the counter cannot move any more and an incomplete population is an error.
     int done = 0;
+    bool ended = false;
     for (int64_t spin = 0;; spin++) {
         HIPCHK(c, hipMemcpyAsync(&done, c->d_qnext + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (done >= (int)c->R) break;
-        if (spin > 300000) return fail(c, QCQPMI_EHIP, "cd_ring_collect: the population did not complete (%d of %lld restarts done)", done, (long long)c->R);
+        if (ended) return fail(c, QCQPMI_EHIP, "cd_ring_collect: the ring's launch ended with the population incomplete (%d of %lld restarts done)", done, (long long)c->R);
+        if (spin > 2000) {      // ~ 20 ms of busy polling, then back off
+            qcqpmi_ctx *o = c->ring_owner;
+            ended = o->ring_stream && hipStreamQuery(o->ring_stream) != hipErrorNotReady;    // one more look at the counter, then fail
+            if (!ended) usleep(200);
+        }
     }
     c->cd_stage = 0;
     c->evaluated = true;                   // d_f0 / d_mv hold the values of the final points

@@ -584,6 +584,7 @@ struct DenseChainArgs {
     uint64_t seed, first_index;
     long long *prof;       // optional: 16 tick sums of the wave of restart 0 (qcqpmi_debug_dense_profile), or nullptr
     int mw_Tc, mw_ts;      // dense_chain_mw_kernel: threads that hold constraints, index of the serial thread (mw_geometry)
+    int c_lo = 0, c_hi = 16;   // dense_chain_mw_kernel: coordinates of the block to visit (the unit step of the parity tests visits one)
 };
 
 // stage timer of one wave (s_memtime ticks): 0 set-up, 1 coefficients, 2 bounds + reductions, 3 gaps, 4 segment sweep

@@ -315,10 +315,11 @@ __global__ __launch_bounds__(MW_TMAX) void dense_chain_mw_kernel(DenseChainArgs 
             for (int cc = 1; cc < 16; cc++) dvc[j][cc - 1] = (k < m1 && cc > c && cc < cmax) ? a.Dg[((int64_t)cc * 16 + c) * m1p + k] : 0.0;
         }
     };
-    if (GREG) request_next(0);
+    const int c_first = a.c_lo > 0 ? a.c_lo : 0, c_end = a.c_hi < cmax ? a.c_hi : cmax;
+    if (GREG) request_next(c_first < 16 ? c_first : 0);
     pf.tick(0);
 
-    for (int c = 0; c < cmax && on; c++) {
+    for (int c = c_first; c < c_end && on; c++) {
         const int64_t i = 16 * (int64_t)b + c;
         const double xi = W.xb[c];
         if (pf.on) pf.t[8]++;

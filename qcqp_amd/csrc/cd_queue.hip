@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
         // ================================================================ refill: free slots take the next restarts
         if (tid == 0) {
             ctl[0] = 0;
-            // ring mode: leave when the host asks to, or after the safety limit (60 s of the 100 MHz wall clock)
+            // ring mode: leave when the host asks to, or after the safety limit (a.ring_limit ticks of the 100 MHz wall clock: ten minutes, cd_ring_start)
             ctl[3] = !a.ring ? 0 : ((long long)wall_clock64() - ring_t0 > a.ring_limit) ? 2 : (qs_load_int(a.rctl) != 0 ? 1 : 0);
         }
         __syncthreads();

@@ -207,6 +207,25 @@ class Engine(object):
         assert lam.shape == (self.m, rp) and Bv.shape == (self.m, rp, self.n) and qhat.shape == (self.m, rp)
         self._chk(self.L.qcqpmi_admm_set_basis(self.h, rp, _dp(lam), _dp(Bv), _dp(qhat)))
 
+    def admm_set_bracket(self, slo, ehi):
+        """Start the multiplier bisection of onecons_qcqp from the given bracket per constraint (utilities.py:176-186;
+        -inf / +inf: the reference's doubling search) instead of the one derived from the installed eigenvalues."""
+        slo = np.ascontiguousarray(slo, dtype=np.float64)
+        ehi = np.ascontiguousarray(ehi, dtype=np.float64)
+        assert slo.shape == (self.m,) and ehi.shape == (self.m,)
+        self._chk(self.L.qcqpmi_admm_set_bracket(self.h, _dp(slo), _dp(ehi)))
+
+    @staticmethod
+    def reference_bracket(lmb):
+        """The bracket the reference derives from a FULL eigenvalue list per constraint (utilities.py:176-180): lmb (m, n)
+        -> (slo, ehi); round-off eigenvalues of a null space count like any other."""
+        lmb = np.asarray(lmb, dtype=np.float64)
+        with np.errstate(divide='ignore'):
+            inv = -1.0 / lmb
+        slo = np.where(lmb > 0, inv, -np.inf).max(axis=1)
+        ehi = np.where(lmb < 0, inv, np.inf).min(axis=1)
+        return slo, ehi
+
     def admm_apply_constraints(self, V, shared=True):
         """out[k] = P_k V_k (n x p blocks) on the device; V: (n, p) shared by all constraints or (m, n, p)."""
         V = np.ascontiguousarray(V, dtype=np.float64)
@@ -386,6 +405,18 @@ class Engine(object):
         """Coupled constraints: coordinate descent in the reference's summation order (slow, value-for-value comparable with
         the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""
         self._chk(self.L.qcqpmi_cd_reference_order(self.h, 1 if enable else 0))
+
+    def cd_dense_block_step(self, phase, sweep, block, slack=None, viol_tol=1e-2, tol=1e-4, seed=0, first_index=0, coords=(0, 16)):
+        """The unit step of the default dense-constraint path on the resident points: the 16 coordinate visits of `block` in
+        sweep `sweep` of phase 1 / phase 2 (coords: the sub-range of the block to visit), from fresh function values
+        (qcqpmi_cd_dense_block_step).  slack: the phase-2
+        `viol` of qcqp.py:157 per restart (None: the max violation of the resident points)."""
+        sl = None
+        if slack is not None:
+            sl = np.ascontiguousarray(slack, dtype=np.float64)
+            assert sl.size == self.pop_size
+        self._chk(self.L.qcqpmi_cd_dense_block_step(self.h, int(phase), int(sweep), int(block), int(coords[0]), int(coords[1]), float(viol_tol), float(tol),
+                                                    int(seed), int(first_index), _dp(sl) if sl is not None else None))
 
     def onevar_coeffs(self, coord):
         """QuadraticFunction.get_onevar_func (utilities.py:99-105) on the device: (t2, t1, t0) of every function in the

@@ -59,6 +59,14 @@ def funcs_from_npz(z):
             for k in range(z['P'].shape[0])]
 
 
+def oracle_map(fn, items):
+    """Independent oracle runs side by side (the C oracle runs without the GIL; the GPU box offers 16 host cores)."""
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(items)
+    with ThreadPoolExecutor(max_workers=max(1, min(8, len(items)))) as ex:
+        return list(ex.map(fn, items))
+
+
 @pytest.fixture(scope='session')
 def orc():
     from oracle import oracle

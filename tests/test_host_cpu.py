@@ -424,3 +424,38 @@ def test_own_lbfgs_matches_scipy_on_standard_problems():
     # limits are honoured
     r = _lbfgs(ros, np.zeros(20), 5, 4000, 1e-9, 1e-15)
     assert r.nit == 5
+
+
+def test_reference_cd_is_chaotic_under_one_ulp(orc):
+    """What parity statement a path with another summation order can make at all.  The reference's own coordinate descent with
+    COUPLED constraints (qcqp.py:100-192), restated bit for bit by the oracle (golden G6 / G7: max |delta| = 0 against the
+    reference), is run from x0 and from nextafter(x0) -- every entry ONE ULP up -- with the same keyed draws: a large share of
+    the restarts ends more than the north star's 1e-6 away (phase 1 bisects the slack until the feasible set of a coordinate is
+    nearly a point; its end points are roots of near-degenerate quadratics, d root / d coefficient = 1 / sqrt(discriminant)).
+    The same experiment with /root/reference itself: profiles/r04_reference_sensitivity.md (41 % / 100 %).  Consequence: a
+    free-running trajectory can be held to 1e-6 only by bit-identical arithmetic (the engine's reference-order mode, tested at
+    1e-9); the default MFMA path is held to 1e-6 STEP BY STEP on the reference's own states
+    (tests/test_gpu_scale.py::test_dense_default_path_follows_the_oracle_step_by_step).  The separable families of the headline
+    (Boolean least squares: configs[0..2]) are not chaotic: there the free-running trajectories agree to 1e-9."""
+    from qcqp_amd import problems
+
+    def ends(prob, x0, r):
+        rng = orc.Rng(orc.RNG_KEYED, 13)
+        rng.set_restart(5 + r)
+        return prob.improve_cd(x0, num_iters=5, rng=rng)[0]
+
+    shares = {}
+    for fam, funcs, R in (('dense', problems.dense_indefinite(100, 30, seed=11)[0], 16),
+                          ('beam', problems.beamforming(50, 12, 4, seed=3)[0], 6),
+                          ('bls', problems.boolean_least_squares(96, 40, seed=2)[0], 6)):
+        prob = orc.Problem(funcs)
+        X0 = 1.5 * np.random.RandomState(3).randn(prob.n, R)
+        d = np.zeros(R)
+        for r in range(R):
+            a, b = ends(prob, X0[:, r], r), ends(prob, np.nextafter(X0[:, r], np.inf), r)
+            d[r] = np.max(np.abs(a - b)) / (1 + np.max(np.abs(a)))
+        shares[fam] = (float(np.mean(d > 1e-6)), float(np.median(d)))
+    print('\nshare of restarts that one ulp of x0 moves by > 1e-6 (median move): %s' % shares)
+    assert shares['dense'][0] >= 0.2
+    assert shares['beam'][0] >= 0.8
+    assert shares['bls'][0] == 0.0 and shares['bls'][1] < 1e-12
