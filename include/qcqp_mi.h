@@ -300,6 +300,25 @@ int qcqpmi_cd_ring_stop(qcqpmi_ctx *owner);      /* owner = members[0] */
 int qcqpmi_debug_cd_ring_state(qcqpmi_ctx *ctx, int64_t *out10);
 /* statistics: restarts of this context's populations that were run by the launches of the context chained to it (total) */
 int qcqpmi_debug_cd_pulled(qcqpmi_ctx *ctx, int64_t *out);
+/* POPULATION STREAMING (round 4) -- the reference's user loop `for ...: suggest(); improve(COORD_DESCENT)` (README.md:51-57)
+ * for K populations of R restarts in ONE persistent launch: a workgroup owns 16 restart slots; a slot that becomes free draws
+ * the next restart index of the run and runs that restart's WHOLE step itself -- suggest(RANDOM) (qcqp.py:381-382; the keyed
+ * normals of qcqpmi_pop_randn), phase 1 (qcqp.py:101-149), the gate (qcqp.py:189), phase 2 to convergence (qcqp.py:152-178),
+ * objective and max violation of the result -- so the matrix pipes work on live restarts across population boundaries and no
+ * preparation kernel, second stream or CU partition exists (csrc/cd_queue.hip, lifecycle mode).  Population p uses the seed
+ * seed + p seed_stride and the global restart indices first_index + p first_stride + [0, R): every restart equals the one
+ * qcqpmi_pop_randn(R, seed_p, first_p) + qcqpmi_cd_run would produce (same draws, same moves; the reported objective is a fresh
+ * evaluation of the final point summed from the products of the restart's last sweep instead of the tracked value: 1e-12
+ * relative).  generate = 0: the K R resident points (qcqpmi_pop_upload) are the starts instead of normals.  Outputs: per-restart
+ * arrays of K R entries (population-major; may be NULL) as in qcqpmi_cd_run, and per population the best restart (index within
+ * the population, QCQPForm.better ordering with bucket width select_tol), its objective, max violation and point (K x n).
+ * The K R final points stay resident (qcqpmi_pop_download).  Boolean family only (the headline kernel's: one mirrored equality
+ * class on a positive diagonal, n a multiple of 16, n <= 1024): QCQPMI_EUNSUPPORTED otherwise. */
+int qcqpmi_cd_stream_run(qcqpmi_ctx *ctx, int64_t K, int64_t R, int generate, int phase1, int64_t num_iters, double viol_tol,
+                         double tol, uint64_t seed, uint64_t seed_stride, uint64_t first_index, uint64_t first_stride,
+                         double select_tol, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
+                         uint8_t *ran_phase2, double *f0, double *maxviol, int64_t *best_index, double *best_f0,
+                         double *best_maxviol, double *best_x);
 /* Coordinate descent for constraints that couple coordinates IN THE REFERENCE'S SUMMATION ORDER (test / diagnostic mode, any
  * n): every one-variable coefficient (t2, t1, t0) of get_onevar_func (utilities.py:99-105) is formed by row-sequential sums
  * like the reference's CSR products -- t0 = f_k(z) afresh per coordinate, O((m+1) n^2) per coordinate visit -- so that

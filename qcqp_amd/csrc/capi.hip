@@ -194,6 +194,8 @@ struct qcqpmi_ctx {
     hipEvent_t ev_prep = nullptr;         // "everything phase 2 needs has been enqueued on the main stream"
     uint64_t chain_seed[3] = {0, 0, 0}, chain_first[3] = {0, 0, 0};   // seed / first index / size of those populations (qcqpmi_cd_chain)
     int64_t chain_R[3] = {0, 0, 0};
+    CdLife *d_life = nullptr;    // qcqpmi_cd_stream_run: parameters of the lifecycle launch
+    int64_t *d_bestK_idx = nullptr; double *d_bestK_key = nullptr; int64_t bestK_cap = 0;
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
     std::vector<int> last_st1, last_st2;   // per-restart status codes of the last coordinate-descent run (qcqpmi_cd_status)
@@ -510,7 +512,7 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
             if (!c->q_prepared && (rcq = cd_queue_prepare(c))) return rcq;
             c->q_prepared = false;
             CdQueueArgs qa;
-            qa.P = dp; qa.nb = 1; qa.num_iters = a1.num_iters; qa.tol = a1.tol; qa.ring = 0; qa.rctl = nullptr; qa.ring_limit = 0;
+            qa.P = dp; qa.nb = 1; qa.num_iters = a1.num_iters; qa.tol = a1.tol; qa.ring = 0; qa.rctl = nullptr; qa.ring_limit = 0; qa.life = nullptr; qa.life_on = 0;
             cd_queue_fill_batch(c, qa.b[0], a1.seed, a1.first_index);
             for (int q = 1; q < CDQ_MAXB; q++) { qa.b[q] = qa.b[0]; qa.b[q].R = 0; }
             for (int q = 0; q < 3; q++) {
@@ -773,7 +775,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_bestK_idx, c->d_bestK_key};
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1524,6 +1526,89 @@ int qcqpmi_cd_dense_block_step(qcqpmi_ctx *c, int phase, int64_t sweep, int64_t 
     return cd_dense_block_step(c, phase, sweep, block, coord_lo, coord_hi, viol_tol, tol, seed, first_index, slack);
 }
 
+// ---- lifecycle run: K populations of R restarts through ONE persistent slot-queue launch (cd_queue.h, CdLife)
+int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int phase1, int64_t num_iters, double viol_tol, double tol,
+                         uint64_t seed, uint64_t seed_stride, uint64_t first_index, uint64_t first_stride, double select_tol,
+                         int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2, uint8_t *ran_phase2, double *f0,
+                         double *maxviol, int64_t *best_index, double *best_f0, double *best_maxviol, double *best_x) {
+    int rc = check_ready(c, generate ? false : true);
+    if (rc) return rc;
+    if (K < 1 || R < 1 || num_iters < 0 || !(tol > 0.0) || K * R >= (1LL << 30)) return fail(c, QCQPMI_EINVAL, "cd_stream_run: bad K / R / num_iters / tol");
+    if (!generate && c->R != K * R) return fail(c, QCQPMI_EINVAL, "cd_stream_run: the resident population has %lld points, K R = %lld", (long long)c->R, (long long)(K * R));
+    HIPCHK(c, hipSetDevice(c->device));
+    if (generate && (rc = pop_reserve(c, K * R))) return rc;
+    if (!cd_queue_eligible(c, false))
+        return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernel needs the Boolean family (one mirrored equality class on a positive "
+                    "diagonal, n a multiple of 16, n <= 1024): use qcqpmi_cd_run per population");
+    const int NBq = (int)(c->n16 / 16);
+    int cs = (c->dbg & 128) ? ((c->dbg >> 8) & 7) : 4;
+    cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
+    if (cs >= NBq) cs = 0;
+    cs &= ~1;
+    if (NBq - cs > RQ_NSIMD * RQ_MAXU || NBq < 3) return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: n = %lld outside the slot-queue kernel's range", (long long)c->n);
+    if (!c->d_qnext && (rc = dev_alloc(c, &c->d_qnext, 16))) return rc;
+    if (!c->d_life) HIPCHK(c, hipMalloc((void **)&c->d_life, sizeof(CdLife)));
+    HIPCHK(c, hipMemsetAsync(c->d_qnext, 0, 16 * sizeof(int), c->stream));
+    CdLife L;
+    L.on = 1; L.generate = generate ? 1 : 0; L.phase1 = phase1 ? 1 : 0; L.Rtotal = K * R; L.Rpop = R;
+    L.seed = seed; L.seed_stride = seed_stride; L.first_index = first_index; L.first_stride = first_stride; L.viol_tol = viol_tol;
+    L.sweeps1 = c->d_sweeps1; L.status1 = c->d_status1; L.ran2 = c->d_flag;
+    HIPCHK(c, hipMemcpyAsync(c->d_life, &L, sizeof(L), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));       // (L lives on this stack frame)
+    CdQueueArgs qa;
+    qa.P = c->dp; qa.nb = 1; qa.num_iters = num_iters; qa.tol = tol; qa.ring = 0; qa.rctl = nullptr; qa.ring_limit = 0;
+    qa.life = c->d_life; qa.life_on = 1;
+    cd_queue_fill_batch(c, qa.b[0], seed, first_index);
+    qa.b[0].R = K * R;
+    for (int q = 1; q < CDQ_MAXB; q++) { qa.b[q] = qa.b[0]; qa.b[q].R = 0; }
+    int cus = 0;
+    HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    (void)hipEventRecord(c->timers[2].beg, c->stream);
+    hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, c->stream);
+    (void)hipEventRecord(c->timers[2].end, c->stream);
+    c->timers[2].valid = true;
+    if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_stream_run: %s", hipGetErrorString(qe));
+    c->last_cd2_kernel = "cd_phase2_qs_kernel<lifecycle>";
+    c->cd_stage = 0;
+    c->evaluated = true;                   // d_f0 / d_mv hold the values of the final points
+    std::vector<int> st, st1;
+    if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
+    if ((rc = cd_apply_status(c, st, st1, f0, maxviol, 0))) return rc;
+    if (best_index || best_f0 || best_maxviol || best_x) {
+        // the best restart of every population (QCQPForm.better folded over it, ties -> lowest index)
+        if (K > c->bestK_cap) {
+            if (c->d_bestK_idx) (void)hipFree(c->d_bestK_idx);
+            if (c->d_bestK_key) (void)hipFree(c->d_bestK_key);
+            c->d_bestK_idx = nullptr; c->d_bestK_key = nullptr;
+            HIPCHK(c, hipMalloc((void **)&c->d_bestK_idx, (size_t)K * 2 * sizeof(int64_t)));
+            HIPCHK(c, hipMalloc((void **)&c->d_bestK_key, (size_t)K * 2 * sizeof(double)));
+            c->bestK_cap = K;
+        }
+        for (int64_t p = 0; p < K; p++)
+            hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(1024), 0, c->stream, (const double *)(c->d_f0 + p * R), (const double *)(c->d_mv + p * R),
+                               R, select_tol, c->d_bestK_idx + 2 * p, c->d_bestK_key + 2 * p);
+        HIPCHK(c, hipGetLastError());
+        std::vector<int64_t> idx((size_t)K * 2);
+        std::vector<double> key((size_t)K * 2);
+        HIPCHK(c, hipMemcpyAsync(idx.data(), c->d_bestK_idx, idx.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(key.data(), c->d_bestK_key, key.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int64_t p = 0; p < K; p++) {
+            if (best_index) best_index[p] = idx[(size_t)2 * p];            // index WITHIN the population
+            if (best_f0) best_f0[p] = key[(size_t)2 * p];
+            if (best_maxviol) best_maxviol[p] = key[(size_t)2 * p + 1];
+            if (best_x && idx[(size_t)2 * p] >= 0) {
+                const int64_t r = p * R + idx[(size_t)2 * p];
+                const double *src = c->X + (r >> 4) * c->n16 * 16 + (r & 15);
+                HIPCHK(c, hipMemcpy2DAsync(best_x + p * c->n, sizeof(double), src, 16 * sizeof(double), sizeof(double), (size_t)c->n,
+                                           hipMemcpyDeviceToHost, c->stream));
+            }
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
 int qcqpmi_cd_status(qcqpmi_ctx *c, int *status1, int *status2) {
     if (!c) return QCQPMI_EINVAL;
     if ((int64_t)c->last_st1.size() != c->R || (int64_t)c->last_st2.size() != c->R)
@@ -1678,7 +1763,7 @@ int qcqpmi_cd_ring_start(qcqpmi_ctx **ctxs, int count, int phase2_cus, int64_t n
     if (!o->d_rctl && (rc = dev_alloc(o, &o->d_rctl, 4))) return rc;
     HIPCHK(o, hipMemsetAsync(o->d_rctl, 0, 4 * sizeof(int), o->stream));
     CdQueueArgs qa;
-    qa.P = o->dp; qa.nb = count; qa.num_iters = num_iters; qa.tol = tol; qa.ring = 1; qa.rctl = o->d_rctl;
+    qa.P = o->dp; qa.nb = count; qa.num_iters = num_iters; qa.tol = tol; qa.ring = 1; qa.rctl = o->d_rctl; qa.life = nullptr; qa.life_on = 0;
     {
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, o->device) != hipSuccess || khz <= 0) khz = 100000;

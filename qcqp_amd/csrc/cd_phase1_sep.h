@@ -1,0 +1,127 @@
+// One coordinate visit of coordinate-descent PHASE 1 (qcqp.py:113-136) for separable constraints -- shared by
+// cd_phase1_sep_kernel (kernels.hip: one launch per population) and by the lifecycle mode of the slot-queue kernel
+// (cd_queue.hip: a restart's suggest + phase 1 + gate + phase 2 inside one persistent launch), so that both make the same
+// moves bit for bit.
+//
+// A coordinate's local violation and its update depend on x_i alone (the objective is identically zero in phase 1,
+// qcqp.py:114): the reference's bisection on the achievable slack s in [-tol, viol - viol_tol] (qcqp.py:122-131) with the
+// exact interval sweep of onevar_qcqp per step.  Only the LAST successful bisection step decides the point (qcqp.py:126-131
+// overwrite new_xi each time) and every draw of the counter-based stream is independent of the others, so the Philox draw is
+// deferred: a successful step just remembers its set and its draw index.  A set with an unbounded piece draws at once (the
+// reference may raise there).
+#pragma once
+#include "kernels.h"
+#include "onevar.h"
+
+namespace qcqpmi {
+
+// QuadraticFunction.violation (utilities.py:56-62)
+__device__ inline double viol_of(double f, int relop) {
+    if (relop == RELOP_EQ) return fabs(f);
+    return f > 0.0 ? f : 0.0;
+}
+
+struct P1Visit {
+    bool visited;     // false: the coordinate carries no constraint (python: max([]) -> ValueError; status -3)
+    bool moved;       // the update was accepted (new_viol < viol, qcqp.py:132): xi holds the new value
+    double vafter;    // max violation of the coordinate's constraints at xi after the visit (feeds qcqp.py:142)
+    int status;       // 0, or < 0 where the reference would raise
+};
+
+// the visit for a coordinate whose mf >= 1 constraints (p, q, r, relop) are given
+template <int MAXC>
+__device__ inline void p1_sep_visit_core(int mf, const double (&cp)[MAXC], const double (&cq)[MAXC], const double (&cr)[MAXC],
+                                         const int (&crel)[MAXC], int64_t i, double &xi, double tol, double viol_tol, uint64_t seed,
+                                         uint64_t grestart, int64_t t, P1Visit &V) {
+    V.visited = true; V.moved = false; V.vafter = -QM_INF; V.status = 0;
+    double viol = -QM_INF;
+#pragma unroll
+    for (int k = 0; k < MAXC; k++)
+        if (k < mf) {
+            double v = viol_of(xi * (cp[k] * xi + cq[k]) + cr[k], crel[k]);
+            viol = v > viol ? v : viol;
+        }
+    double new_xi = xi, new_viol = viol;
+    double ss = -tol, es = viol - viol_tol;
+    uint32_t it = 0;
+    FeasSet<MAXC> Cp;
+    uint32_t itp = 0;
+    bool pending = false;
+    // Boolean-type constraint p x^2 + r == 0 (p > tol, no linear term): |f| <= s is the band
+    // a <= |x| <= b with a = sqrt(D2)/(2p), b = sqrt(D1)/(2p), D1 = 4p(s - r), D2 = -4p(r + s)
+    // (utilities.py:209-231 with q = 0).  The set is non-empty iff D1 > 0 and (D2 < 0 or D2 < D1)
+    // -- square root and division are monotone, touching / zero-width pieces vanish in the sweep --
+    // so the bisection only needs the two discriminants; the set itself is built once, for the
+    // last successful slack.
+    const bool band = mf == 1 && cq[0] == 0.0 && crel[0] == RELOP_EQ && cp[0] > 1e-4;
+    double sp = 0.0;
+    while (es - ss > tol) {
+        double s = (ss + es) / 2.0;
+        if (band) {
+            const uint32_t itb = it++;
+            const double D1 = 0.0 - 4.0 * cp[0] * (cr[0] - s);     // q*q - 4 p rs, as the reference forms it
+            const double D2 = 0.0 - 4.0 * (-cp[0]) * (-cr[0] - s);
+            const bool nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
+            if (!nonempty) { ss = s; continue; }
+            sp = s; itp = itb; pending = true;
+            new_viol = s; es = s;
+            continue;
+        }
+        FeasSet<MAXC> C;
+        if (mf == 1) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], s, C);
+        else feasible_set<MAXC>(cp, cq, cr, crel, mf, s, C);
+        const uint32_t itc = it++;
+        if (C.n == 0) { ss = s; continue; }
+        bool unb = false;
+#pragma unroll
+        for (int j = 0; j <= MAXC; j++) unb = unb || (j < C.n && (__builtin_isinf(C.lo[j]) || __builtin_isinf(C.hi[j])));
+        if (unb) {
+            DrawKey dk{seed, grestart, (uint32_t)i, (uint32_t)t, itc};
+            double xn;
+            int got = onevar_minimise<MAXC>(0.0, 0.0, 0.0, C, dk, &xn);
+            if (got < 0) { V.status = got; pending = false; break; }
+            new_xi = xn; pending = false;
+        } else {
+            Cp = C; itp = itc; pending = true;
+        }
+        new_viol = s; es = s;
+    }
+    if (pending && band) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], sp, Cp);
+    if (pending) {
+        DrawKey dk{seed, grestart, (uint32_t)i, (uint32_t)t, itp};
+        double xn = xi;
+        const int got = onevar_minimise<MAXC>(0.0, 0.0, 0.0, Cp, dk, &xn);
+        // the band test decides non-emptiness on the discriminants; the set rebuilt from rounded
+        // end points can collapse to nothing: then the step is infeasible at this slack, as in
+        // the reference (onevar_qcqp returns None -> the move is not made)
+        if (got == 1) new_xi = xn;
+        else { new_viol = viol; if (got < 0) V.status = got; }
+    }
+    if (new_viol < viol) { xi = new_xi; V.moved = true; }
+    // violation of the constraints on x_i after the update (feeds qcqp.py:142)
+#pragma unroll
+    for (int k = 0; k < MAXC; k++)
+        if (k < mf) {
+            double v = viol_of((cp[k] * xi + cq[k]) * xi + cr[k], crel[k]);
+            V.vafter = v > V.vafter ? v : V.vafter;
+        }
+}
+
+template <int MAXC>
+__device__ inline void p1_sep_visit(const DevProblem &P, int64_t i, double &xi, double tol, double viol_tol, uint64_t seed,
+                                    uint64_t grestart, int64_t t, P1Visit &V) {
+    V.visited = false; V.moved = false; V.vafter = -QM_INF; V.status = 0;
+    const int e0 = P.cptr[i], mf = P.cptr[i + 1] - e0;
+    if (mf == 0) { V.status = -3; return; }
+    double cp[MAXC], cq[MAXC], cr[MAXC];
+    int crel[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; k++) {
+        bool ok = k < mf;
+        cp[k] = ok ? P.cp[e0 + k] : 0.0; cq[k] = ok ? P.cq[e0 + k] : 0.0;
+        cr[k] = ok ? P.cr[e0 + k] : 0.0; crel[k] = ok ? P.crel[e0 + k] : RELOP_LE;
+    }
+    p1_sep_visit_core<MAXC>(mf, cp, cq, cr, crel, i, xi, tol, viol_tol, seed, grestart, t, V);
+}
+
+}  // namespace qcqpmi

@@ -36,6 +36,23 @@ constexpr int CDQ_MAXB = 8;      // populations a launch can see (chained launch
 //   [0] queue head  [1] generation published  [2] restarts run ahead (statistics)  [3] restarts done  [4] R
 //   [5,6] seed  [7,8] first global index       (the fields of CdBatch with the same names are ignored)
 // Population number j of a run (j = 0, 1, ...) lives in entry j % nb with generation j / nb + 1.
+// Lifecycle mode (round 4): the launch runs a restart's WHOLE improve step -- suggest(RANDOM) (keyed normals), phase 1,
+// the gate of improve_coord_descent, phase 2, objective and max violation of the result -- for a queue of Rtotal restarts
+// that belong to Rtotal / Rpop populations of Rpop restarts each (population p: seed + p seed_stride, global restart
+// indices first_index + p first_stride + [0, Rpop)).  No preparation kernels, no second stream, no CU partition: a slot
+// that becomes free draws the next restart index and builds the column itself.
+struct CdLife {
+    int on;
+    int generate;                // 1: x0 = keyed normals (suggest RANDOM, qcqp.py:381-382); 0: the columns of b[0].X
+    int phase1;                  // run phase 1 (qcqp.py:186-187)
+    int64_t Rtotal, Rpop;
+    uint64_t seed, seed_stride, first_index, first_stride;
+    double viol_tol;
+    int64_t *sweeps1;            // [Rtotal] phase-1 sweeps
+    int *status1;                // [Rtotal] phase-1 status
+    uint8_t *ran2;               // [Rtotal] passed the gate (qcqp.py:189)
+};
+
 struct CdQueueArgs {
     DevProblem P;
     CdBatch b[CDQ_MAXB];         // b[0]: the population this launch belongs to; b[1..nb-1]: the next ones (run ahead), in order
@@ -45,6 +62,10 @@ struct CdQueueArgs {
     int ring;                    // 1: ONE persistent launch serves the populations of nb contexts in turn until *rctl != 0
     int *rctl;                   // [0] quit
     long long ring_limit;        // safety: the launch ends after this many ticks of wall_clock64() whatever happens
+    const CdLife *life;          // lifecycle mode: parameters in DEVICE memory (b[0] holds the outputs of all Rtotal restarts; nb = 1, no
+                                 // ring); nullptr: off.  (By value they cost scalar registers for the whole kernel -- the multiplying
+                                 // waves sit exactly at the register limit and spill when the spilled scalars take two more VGPRs.)
+    int life_on;
 };
 
 // LDS bytes of the kernel for this problem (0: does not fit / not eligible)

@@ -15,6 +15,7 @@
 #include "cd_queue.h"
 
 #include "onevar.h"
+#include "cd_phase1_sep.h"
 
 namespace qcqpmi {
 // (cd_phase2.h, which the role helpers come with, expects the MFMA building block of kernels.hip to be declared)
@@ -71,9 +72,45 @@ __device__ inline int qs_add(QG int *p, int v) { return __hip_atomic_fetch_add(p
 // MULTI = false: ONE population and no ring -- the descriptor is the kernel argument itself, the chain / ring branches are
 // compiled out.  (With the four descriptors in LDS and the ring branches in place the single-population launch was 30 %
 // slower: 12.9 instead of 9.8 ms at 16384 restarts; measured late in round 3, tools/queue_rate.py.)
-template <int CS, int QM>      // QM: 0 one population, 1 chained populations (descriptor table), 2 ring
+// order-preserving map double -> u64 and back (LDS integer atomics as max-reductions over the threads)
+__device__ inline unsigned long long qs_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ inline double qs_unkey(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__device__ inline double qs_wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+
+// Lifecycle mode: the heavy scalar code of a restart's start -- Box-Muller normals, the phase-1 visit (bisection, Philox,
+// square roots) -- as REAL FUNCTION CALLS.  Inlined into the kernel they cost it 150 VGPR spills in the multiplying waves'
+// product loop (the kernel sits exactly at the 256-register limit there); called, they have register allocations of their own.
+__device__ __attribute__((noinline)) double qs_keyed_normal(uint64_t seed, uint64_t restart, uint64_t elem) {
+    return keyed_normal(seed, restart, elem);
+}
+// one phase-1 visit of coordinate i (value x) of a problem whose coordinates all carry the one constraint (p, q, r, relop);
+// returns the new value, *flags: bit 0 moved, bits 8.. = -status; *vafter: the constraint's violation afterwards
+__device__ __attribute__((noinline)) double qs_p1_visit(double p, double q, double r, int relop, int64_t i, double x, double tol,
+                                                        double viol_tol, uint64_t seed, uint64_t restart, int64_t t, int *flags,
+                                                        double *vafter) {
+    const double cp[1] = {p}, cq[1] = {q}, cr[1] = {r};
+    const int crel[1] = {relop};
+    P1Visit V;
+    p1_sep_visit_core<1>(1, cp, cq, cr, crel, i, x, tol, viol_tol, seed, restart, t, V);
+    *flags = (V.moved ? 1 : 0) | ((-V.status) << 8);
+    *vafter = V.vafter;
+    return x;
+}
+
+template <int CS, int QM>      // QM: 0 one population, 1 chained populations (descriptor table), 2 ring, 3 lifecycle (cd_queue.h)
 __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
-    constexpr bool MULTI = QM != 0;
+    constexpr bool MULTI = QM == 1 || QM == 2;
+    constexpr bool LIFE = QM == 3;
     // the compiler sees constants where the other modes read the arguments
     CdQueueArgs a = a0;
     a.ring = (QM == 2) ? 1 : 0;
@@ -115,18 +152,27 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
     int *sfin = (int *)sp; sp += 8;                // slot's restart finished in this episode
     int *ost = (int *)sp; sp += 8;
     int *ctl = (int *)sp; sp += 8;                 // [0] occupied slots
-    long long *cst = (long long *)sp; sp += 64 * 8; // the chain wave's per-lane state between episodes: [field][lane]
+    long long *cst = (long long *)sp; sp += 64 * 10; // the chain wave's per-lane state between episodes: [field][lane]
     CdBatch *Bt = (CdBatch *)sp; sp += (CDQ_MAXB * sizeof(CdBatch) + 7) / 8;
     unsigned long long *sseed = (unsigned long long *)sp; sp += 16;     // ring mode: seed / first global index of the slot's population
     unsigned long long *sfirst = (unsigned long long *)sp; sp += 16;   // the populations this launch may draw from (dynamic indexing: LDS, not kernel arguments)
+    // lifecycle mode: phase 1 of the restarts just taken -- per slot: max-violation key (reduction), "a coordinate moved",
+    // finished, sweeps, status; passed the gate
+    unsigned long long *p1key = (unsigned long long *)sp; sp += 16;
+    int *p1upd = (int *)sp; sp += 8;
+    int *p1fin = (int *)sp; sp += 8;
+    int *p1sw = (int *)sp; sp += 8;
+    int *p1st = (int *)sp; sp += 8;
+    int *gatep = (int *)sp; sp += 8;
 
     // ---- the chain wave's per-restart state (lane 4 r + g: restart slot r) is parked in LDS between episodes: fields
-    // 0 upd_counter, 1 visits, 2 accepted, 3 sweeps, 4 conv, 5 status, 6 fpart (bits); inside an episode it lives in the
+    // 0 upd_counter, 1 visits, 2 accepted, 3 sweeps, 4 conv, 5 status, 6 fpart (bits), 7 lifecycle flags (1 frozen sweep, 2 done),
+    // 8 window sum (bits); inside an episode it lives in the
     // chain role's registers like in cd_phase2_q_kernel (keeping it in registers of the whole kernel made the multiplying
     // waves spill)
     if (tid0 < 64) {
 #pragma unroll
-        for (int f = 0; f < 8; f++) cst[f * 64 + tid0] = (f == 4) ? 1 : 0;
+        for (int f = 0; f < 10; f++) cst[f * 64 + tid0] = (f == 4) ? 1 : 0;
     }
     if (tid0 < 16) { sid[tid0] = -1; sbt[tid0] = 0; sfin[tid0] = 0; }
     if (tid0 == 0) { if (MULTI) for (int q = 0; q < CDQ_MAXB; q++) Bt[q] = a0.b[q]; ctl[1] = 0; ctl[2] = 0; }
@@ -139,6 +185,8 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
         // role out of the episode loop and keeps them all alive through all roles (70+ VGPR spills in the chain's loop).
         int tid = tid0;
         asm volatile("" : "+v"(tid));
+        const CdLife *lifep = a0.life;               // (opaque per episode as well: its fields are read where they are used)
+        asm volatile("" : "+s"(lifep));
         const int lane = tid & 63, r = lane >> 2, gq = lane & 3;
         // ================================================================ refill: free slots take the next restarts
         if (tid == 0) {
@@ -170,6 +218,16 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                     qs_add(qe + 3, 1);                            // did not pass the gate (qcqp.py:189): nothing to run, done
                 }
                 atomicMax(&ctl[2], j);
+            } else if (id < 0 && LIFE) {
+                // lifecycle mode: the queue is a counter over all restarts of the run; the column is built below
+                QG const CdLife *lf = qs_g(lifep);
+                const int idx = qs_add(qs_g(a0.b[0].next), 1);
+                if (idx < (int)lf->Rtotal) {
+                    id = idx; bt = 0; nw = 1;
+                    const uint64_t pop = (uint64_t)idx / (uint64_t)lf->Rpop, rho = (uint64_t)idx % (uint64_t)lf->Rpop;
+                    sseed[tid] = lf->seed + pop * lf->seed_stride;
+                    sfirst[tid] = lf->first_index + pop * lf->first_stride + rho - (uint64_t)idx;    // + id = the global restart index
+                }
             } else if (id < 0) {
                 for (int q = 0; q < a.nb && id < 0; q++) {
                     const CdBatchG B = qs_batch(QB(q));
@@ -187,7 +245,8 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                 }
             }
             sid[tid] = id; sbt[tid] = bt; snew[tid] = nw;
-            if (nw) {
+            if (LIFE) { if (nw) { p1fin[tid] = 0; p1sw[tid] = 0; p1st[tid] = 0; gatep[tid] = 0; } }
+            if (nw && !LIFE) {
                 const CdBatchG B = qs_batch(QB(bt));
                 slk[tid] = qs_load_d(B.slack + id);
                 f0new[tid] = qs_load_d(B.f0cur + id);
@@ -215,7 +274,88 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
             __syncthreads();
             continue;
         }
-        {
+        if (LIFE) {
+            // ---- lifecycle mode: build the columns of the restarts just taken -- suggest(RANDOM) (qcqp.py:381-382: keyed
+            // normals, the stream of randn_tiles_kernel), phase 1 (qcqp.py:101-149 through p1_sep_visit: the moves of
+            // cd_phase1_sep_kernel bit for bit), the max violation = slack of phase 2 (qcqp.py:157) and the gate (qcqp.py:189)
+            QG const CdLife *lf = qs_g(lifep);
+            const int lf_generate = lf->generate, lf_phase1 = lf->phase1;
+            const double lf_viol_tol = lf->viol_tol;
+            const int e0 = P.cptr[P.krep[0]];
+            const double cp = P.cp[e0], cq = P.cq[e0], cr = P.cr[e0];
+            const int rel = P.crel[e0];
+            for (int c = 0; c < 16; c++) {
+                if (!snew[c]) {
+                    if (sid[c] < 0) for (int64_t j = tid; j < n16; j += 512) Xs[j * 16 + c] = 0.0;
+                    continue;
+                }
+                if (lf_generate) {
+                    const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
+                    for (int64_t j = tid; j < n16; j += 512) Xs[j * 16 + c] = (j < P.n) ? qs_keyed_normal(sd, gidx, (uint64_t)j) : 0.0;
+                } else {
+                    QG const double *src = qs_g(a0.b[0].X) + ((int64_t)(sid[c] >> 4) * n16) * 16 + (sid[c] & 15);
+                    for (int64_t j = tid; j < n16; j += 512) Xs[j * 16 + c] = src[j * 16];
+                }
+            }
+            __syncthreads();
+            if (lf_phase1) {
+                for (int64_t t = 0; t < a.num_iters; t++) {
+                    if (tid == 0) { int cnt = 0; for (int k = 0; k < 16; k++) cnt += (snew[k] && !p1fin[k]) ? 1 : 0; ctl[4] = cnt; }
+                    if (tid < 16) { p1key[tid] = qs_key(-QM_INF); p1upd[tid] = 0; }
+                    __syncthreads();
+                    if (ctl[4] == 0) break;
+                    for (int c = 0; c < 16; c++) {
+                        if (!snew[c] || p1fin[c]) continue;       // workgroup-uniform
+                        const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
+                        double vmax = -QM_INF;
+                        int upd = 0, st = 0;
+                        for (int64_t i = tid; i < P.n; i += 512) {
+                            int fl;
+                            double va;
+                            const double xi = qs_p1_visit(cp, cq, cr, rel, i, Xs[i * 16 + c], a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
+                            if (fl >> 8) st = -(fl >> 8);
+                            if (fl & 1) { Xs[i * 16 + c] = xi; upd = 1; }
+                            vmax = va > vmax ? va : vmax;
+                        }
+                        vmax = qs_wave_max(vmax);
+                        if (lane == 0) atomicMax(&p1key[c], qs_key(vmax));
+                        if (upd) p1upd[c] = 1;
+                        if (st) p1st[c] = st;
+                    }
+                    __syncthreads();
+                    if (tid < 16 && snew[tid] && !p1fin[tid]) {
+                        p1sw[tid]++;
+                        // done when feasible enough (qcqp.py:111); a sweep without any update is a fixed point of the map
+                        if (qs_unkey(p1key[tid]) < lf_viol_tol || !p1upd[tid]) p1fin[tid] = 1;
+                    }
+                    __syncthreads();
+                }
+            }
+            if (tid < 16) p1key[tid] = qs_key(-QM_INF);
+            __syncthreads();
+            for (int c = 0; c < 16; c++) {
+                if (!snew[c]) continue;
+                double v = -QM_INF;
+                for (int64_t i = tid; i < P.n; i += 512) {
+                    const double x = Xs[i * 16 + c];
+                    const double f = (cp * x + cq) * x + cr;
+                    const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+                    v = w > v ? w : v;
+                }
+                v = qs_wave_max(v);
+                if (lane == 0) atomicMax(&p1key[c], qs_key(v));
+            }
+            __syncthreads();
+            if (tid < 16 && snew[tid]) {
+                const double mvx = qs_unkey(p1key[tid]);
+                slk[tid] = mvx;
+                gatep[tid] = (mvx < lf_viol_tol && p1st[tid] == 0) ? 1 : 0;
+                FeasSet<MAXC> C;
+                compute_set<MAXC>(P, P.krep[0], mvx, C);
+                store_set<MAXC>(TC, tid, C);
+            }
+            __syncthreads();
+        } else {
             // columns of the restarts just taken (sc1 loads: the next population was written by kernels of another stream
             // while this one was running), zero columns for empty slots
             const int col = tid & 15;
@@ -243,9 +383,19 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
             if (snew[r]) {
 #pragma unroll
                 for (int f = 0; f < 6; f++) cst[f * 64 + lane] = 0;
-                cst[6 * 64 + lane] = __double_as_longlong((gq == 0) ? f0new[r] : 0.0);
+                if (LIFE) {
+                    // the objective is tracked RELATIVE to the start of phase 2 (its value comes from the converged window or
+                    // from a frozen sweep, see the chain role); a restart that did not pass the gate only takes a frozen sweep
+                    cst[6 * 64 + lane] = 0;
+                    cst[4 * 64 + lane] = gatep[r] ? 0 : 1;
+                    cst[7 * 64 + lane] = gatep[r] ? 0 : 1;
+                    cst[8 * 64 + lane] = 0;
+                } else {
+                    cst[6 * 64 + lane] = __double_as_longlong((gq == 0) ? f0new[r] : 0.0);
+                }
             } else if (sid[r] < 0) {
                 cst[4 * 64 + lane] = 1; cst[6 * 64 + lane] = 0;
+                if (LIFE) { cst[7 * 64 + lane] = 2; cst[8 * 64 + lane] = 0; }
             }
         }
         __syncthreads();
@@ -424,6 +574,13 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
             S.fcur = 0.0; S.upd_counter = cst[0 * 64 + lane]; S.visits = cst[1 * 64 + lane]; S.accepted = cst[2 * 64 + lane];
             S.sweeps = cst[3 * 64 + lane]; S.conv = cst[4 * 64 + lane] != 0; S.status = (int)cst[5 * 64 + lane];
             double fpart = __longlong_as_double(cst[6 * 64 + lane]);
+            // lifecycle mode.  The objective of the result is not tracked from an evaluated start value (there is no
+            // evaluation pass): `facc` sums x_i ((P0 x)_i + q_i) over the visits since the restart's last move -- when it
+            // converges (n visits without a move, qcqp.py:172-176) those are all n coordinates at the FINAL point, i.e.
+            // f0(x) - r0 freshly evaluated from the products the sweep computed anyway.  A restart that stops otherwise (sweep
+            // limit, gate not passed) takes one FROZEN sweep (no moves, not counted) that sums the same terms.
+            bool frz = LIFE && (cst[7 * 64 + lane] & 1) != 0, done = LIFE && (cst[7 * 64 + lane] & 2) != 0;
+            double facc = LIFE ? __longlong_as_double(cst[8 * 64 + lane]) : 0.0;
             const bool occupied = sid[r] >= 0;                  // a restart sits in this lane's slot
             const RqOwn cown = rq_own(NB, CS, RQ_NSIMD);
             v2d_ arC[2 * CSU];
@@ -482,13 +639,14 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                     __builtin_amdgcn_s_sleep(1);
                 }
                 // ---- G + q/2 of the lane's own columns: its own plane, then the three partial tiles, in a fixed order, then q/2
-                double gb[4], g0[4], xo[4], xn[4], rto[4], t2o[4];
+                double gb[4], g0[4], xo[4], xn[4], rto[4], t2o[4], hq4[4];
     #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     double s = fixp[v * 64 + lane];
     #pragma unroll
                     for (int w = 0; w < RQ_NSIMD; w++) s += part[w * 256 + v * 64 + lane];
-                    s += hqb[4 * v + gq];
+                    hq4[v] = hqb[4 * v + gq];
+                    s += hq4[v];
                     gb[v] = s;
                     g0[v] = s;
                 }
@@ -505,7 +663,10 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
     #pragma unroll
                     for (int u = 0; u < 4; u++) { afix[u] = ap[u * 64]; afix2[u] = ap2[u * 64]; }
                 }
-                if (b == 0 && !S.conv && S.sweeps >= a.num_iters) S.conv = true;      // sweep limit reached (qcqp.py:160): the restart is done
+                if (b == 0 && !S.conv && S.sweeps >= a.num_iters) {      // sweep limit reached (qcqp.py:160): the restart is done
+                    S.conv = true;
+                    if (LIFE) { frz = true; facc = 0.0; }                 // ... after one frozen sweep that evaluates its objective
+                }
                 if (b == 0 && !S.conv) S.sweeps++;
                 const bool act = !S.conv;
                 const bool actn = act && Un > 0;
@@ -563,6 +724,24 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                         S.visits += 16 - (over > 0 ? over : 0);
                         S.upd_counter = upd;
                         if (over >= 0) S.conv = true;
+                        if (LIFE) {
+                            // the window: visits after the block's last move (all of them if none moved), up to the visit that
+                            // completes the n consecutive visits without a move
+                            const int cl = mv ? 31 - __builtin_clz(mv) : -1, ce = 15 - (over > 0 ? over : 0);
+                            double w = 0.0;
+#pragma unroll
+                            for (int v = 0; v < 4; v++) {
+                                const int c = 4 * v + gq;
+                                w = (c > cl && c <= ce) ? __builtin_fma(xn[v], gb[v] + hq4[v], w) : w;
+                            }
+                            facc = (cl >= 0 ? 0.0 : facc) + w;
+                            if (over >= 0) done = true;
+                        }
+                    } else if (LIFE && frz) {
+                        double w = 0.0;
+#pragma unroll
+                        for (int v = 0; v < 4; v++) w = __builtin_fma(xo[v], gb[v] + hq4[v], w);
+                        facc += w;
                     }
 #pragma unroll
                     for (int v = 0; v < 4; v++) Xs[(16 * b + 4 * v + gq) * 16 + r] = xn[v];
@@ -576,6 +755,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                     if (!redo) fast_commit();
                     else {
                         S.fcur = rq_quad_sum(fpart);
+                        double fa = LIFE ? rq_quad_sum(facc) : 0.0;
                         double *Gsc = fixp;
                         const int bsel = sbt[r];
                         const uint64_t dseed = sseed[r], dfirst = sfirst[r];
@@ -596,27 +776,31 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                             int got = S.conv ? 0 : onevar_minimise<MAXC>(t2g, t1, t0, C, dk, &xnew);
                             bool moved;
                             double delta;
+                            const bool wasconv = S.conv;
                             chain_commit<MAXC>(S, got, xnew, xi, t2g, t1, t0, a.tol, P.n, moved, delta);
+                            if (LIFE && !wasconv) fa = moved ? 0.0 : fa + xi * (Gsc[c * 16 + r] + hq);
                             if (moved) {
                                 Xs[i * 16 + r] = xnew;
                                 for (int c2 = c + 1; c2 < 16; c2++) Gsc[c2 * 16 + r] += DU[c * 16 + c2] * delta;
                             }
                         }
                         fpart = (gq == 0) ? S.fcur : 0.0;
+                        if (LIFE) { facc = (gq == 0) ? fa : 0.0; if (S.conv) done = true; }
                     }
                 }
                 rq_sync_write(sy, RQ_COMMIT, (int)g + 1, lane);   // block b is in the X tile; its staged operands are free
-                const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv);
+                if (LIFE && frz && b == NB - 1) { frz = false; done = true; }      // the frozen sweep is complete
+                const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv || frz);
                 if (livem == 0ull) break;
                 if (b == NB - 1 && a.ring && (long long)wall_clock64() - ring_t0 > a.ring_limit) break;
                 if (b == NB - 1) {
                     // sweep boundary: slots whose restart is done (converged, or at the sweep limit) can take a new restart --
                     // end the episode if the queue has one
-                    const bool fin = !occupied || S.conv || S.sweeps >= a.num_iters;
+                    const bool fin = LIFE ? (!occupied || done) : (!occupied || S.conv || S.sweeps >= a.num_iters);
                     const unsigned long long finm = __builtin_amdgcn_ballot_w64(fin);
                     if (finm == ~0ull) break;
                     if (finm != 0ull) {
-                        bool more = false;
+                        bool more = LIFE && qs_load_int(qs_g(a0.b[0].next)) < (int)qs_g(lifep)->Rtotal;
                         if (a.ring) {
                             for (int j = ctl[1], tries = 0; tries < 2 && !more; j++, tries++) {
                                 QG int *qe = qs_g(QB(j % a.nb).next);
@@ -625,7 +809,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                                 more = gen == want && qs_load_int(qe) < qs_load_int(qe + 4);
                             }
                         }
-                        if (!a.ring) {
+                        if (!a.ring && !LIFE) {
                             // own population from the kernel arguments (scalar registers), the others from the table
                             more = (!a0.b[0].ready || qs_load_int(a0.b[0].ready) == a0.b[0].ready_gen) && qs_load_int(a0.b[0].next) < (int)a0.b[0].R;
                             for (int q = 1; q < a.nb && !more; q++) {
@@ -667,8 +851,9 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                 cst[0 * 64 + lane] = S.upd_counter; cst[1 * 64 + lane] = S.visits; cst[2 * 64 + lane] = S.accepted;
                 cst[3 * 64 + lane] = S.sweeps; cst[4 * 64 + lane] = S.conv ? 1 : 0; cst[5 * 64 + lane] = S.status;
                 cst[6 * 64 + lane] = __double_as_longlong(fpart);
-                const double ftot = rq_quad_sum(fpart);
-                const bool fin = occupied && (S.conv || S.sweeps >= a.num_iters);
+                if (LIFE) { cst[7 * 64 + lane] = (frz ? 1 : 0) | (done ? 2 : 0); cst[8 * 64 + lane] = __double_as_longlong(facc); }
+                const double ftot = LIFE ? rq_quad_sum(facc) + P.r0 : rq_quad_sum(fpart);
+                const bool fin = LIFE ? (occupied && done) : (occupied && (S.conv || S.sweeps >= a.num_iters));
                 if (gq == 0) {
                     sfin[r] = fin ? 1 : 0;
                     if (fin) { ovis[r] = S.visits; oacc[r] = S.accepted; oswp[r] = S.sweeps; ost[r] = S.status; of0[r] = ftot; }
@@ -721,6 +906,11 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                     B.visits[id] = ovis[tid]; B.accepted[id] = oacc[tid]; B.sweeps[id] = oswp[tid]; B.status[id] = ost[tid];
                     if (B.f0out) B.f0out[id] = of0[tid];
                     if (B.mvout) B.mvout[id] = m;
+                    if (LIFE) {
+                        QG const CdLife *lf = qs_g(lifep);
+                        qs_g(lf->sweeps1)[id] = p1sw[tid]; qs_g(lf->status1)[id] = p1st[tid];
+                        qs_g(lf->ran2)[id] = (uint8_t)gatep[tid];
+                    }
                 }
                 sid[tid] = -1; sfin[tid] = 0;
             }
@@ -736,7 +926,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
 size_t cd_queue_lds_bytes(const DevProblem &P) {
     const int NB = (int)P.NB;
     if (P.n % 16 != 0 || NB < 3) return 0;
-    size_t bytes = ((size_t)RQ_LDS_COMMON + 8 + 16 * 5 + 8 * 6 + 64 * 8 + (CDQ_MAXB * sizeof(CdBatch) + 7) / 8 + 32 + (size_t)P.n16 * 16) * sizeof(double);
+    size_t bytes = ((size_t)RQ_LDS_COMMON + 8 + 16 * 5 + 8 * 6 + 64 * 10 + (CDQ_MAXB * sizeof(CdBatch) + 7) / 8 + 32 + 16 + 8 * 5 + (size_t)P.n16 * 16) * sizeof(double);
     if (bytes < RQ_LDS_MIN + 1024) bytes = RQ_LDS_MIN + 1024;
     return bytes <= 160 * 1024 ? bytes : 0;
 }
@@ -749,14 +939,15 @@ int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st) {
     if (cs >= NB) cs = 0;
     cs &= ~1;
     if (NB - cs > RQ_NSIMD * RQ_MAXU) return (int)hipErrorInvalidValue;
-    int qm = a.ring ? 2 : (a.nb > 1 ? 1 : 0);
-    if (const char *e = getenv("QCQPMI_QS_MODE")) { const int v = atoi(e); if (!a.ring && v >= qm && v <= 1) qm = v; }     // experiments: the chained variant on one population
-    auto k = qm == 2 ? (cs == 0 ? cd_phase2_qs_kernel<0, 2> : cs == 2 ? cd_phase2_qs_kernel<2, 2> : cs == 4 ? cd_phase2_qs_kernel<4, 2> : cd_phase2_qs_kernel<6, 2>)
+    int qm = a.life_on ? 3 : a.ring ? 2 : (a.nb > 1 ? 1 : 0);
+    if (const char *e = getenv("QCQPMI_QS_MODE")) { const int v = atoi(e); if (!a.ring && !a.life_on && v >= qm && v <= 1) qm = v; }     // experiments: the chained variant on one population
+    auto k = qm == 3 ? (cs == 0 ? cd_phase2_qs_kernel<0, 3> : cs == 2 ? cd_phase2_qs_kernel<2, 3> : cs == 4 ? cd_phase2_qs_kernel<4, 3> : cd_phase2_qs_kernel<6, 3>)
+           : qm == 2 ? (cs == 0 ? cd_phase2_qs_kernel<0, 2> : cs == 2 ? cd_phase2_qs_kernel<2, 2> : cs == 4 ? cd_phase2_qs_kernel<4, 2> : cd_phase2_qs_kernel<6, 2>)
            : qm == 1 ? (cs == 0 ? cd_phase2_qs_kernel<0, 1> : cs == 2 ? cd_phase2_qs_kernel<2, 1> : cs == 4 ? cd_phase2_qs_kernel<4, 1> : cd_phase2_qs_kernel<6, 1>)
                      : (cs == 0 ? cd_phase2_qs_kernel<0, 0> : cs == 2 ? cd_phase2_qs_kernel<2, 0> : cs == 4 ? cd_phase2_qs_kernel<4, 0> : cd_phase2_qs_kernel<6, 0>);
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    int64_t wgs = (a.b[0].R + 15) / 16;
+    int64_t wgs = (a.b[0].R + 15) / 16;     // lifecycle mode: b[0].R = all restarts of the run
     if (wgs > max_wgs || a.ring) wgs = max_wgs;
     if (wgs < 1) wgs = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3(512), lds, st, a);

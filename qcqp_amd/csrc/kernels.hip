@@ -14,6 +14,7 @@
 // fp64 MFMA tile is (16 coordinates of a block) x (16 candidates).
 #include "kernels.h"
 #include "onevar.h"
+#include "cd_phase1_sep.h"
 
 namespace qcqpmi {
 
@@ -122,11 +123,6 @@ __global__ __launch_bounds__(256) void affine_tiles_kernel(const double *__restr
 }
 
 // ----------------------------------------------------------------------------------- evaluation
-
-__device__ inline double viol_of(double f, int relop) {
-    if (relop == RELOP_EQ) return fabs(f);
-    return f > 0.0 ? f : 0.0;
-}
 
 // One workgroup (4 waves) per tile of 16 candidates.
 //   objective: y = P0 x by MFMA (wave w owns row blocks w, w+4, ...), f0 = sum_i x_i (y_i + q_i) + r
@@ -270,93 +266,14 @@ __global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
         if (run) {
             if (slot == 0) sweeps_done++;
             for (int64_t i = slot; i < P.n; i += P1_SLOTS) {
-                const int e0 = P.cptr[i], mf = P.cptr[i + 1] - e0;
                 double xi = Xs[i * 16 + r];
-                if (mf == 0) { my_status = -3; continue; }  // python: max([]) -> ValueError
-                double cp[MAXC], cq[MAXC], cr[MAXC];
-                int crel[MAXC];
-#pragma unroll
-                for (int k = 0; k < MAXC; k++) {
-                    bool ok = k < mf;
-                    cp[k] = ok ? P.cp[e0 + k] : 0.0; cq[k] = ok ? P.cq[e0 + k] : 0.0;
-                    cr[k] = ok ? P.cr[e0 + k] : 0.0; crel[k] = ok ? P.crel[e0 + k] : RELOP_LE;
-                }
-                double viol = -QM_INF;
-#pragma unroll
-                for (int k = 0; k < MAXC; k++)
-                    if (k < mf) {
-                        double v = viol_of(xi * (cp[k] * xi + cq[k]) + cr[k], crel[k]);
-                        viol = v > viol ? v : viol;
-                    }
-                double new_xi = xi, new_viol = viol;
-                double ss = -a.tol, es = viol - a.viol_tol;
-                uint32_t it = 0;
+                P1Visit V;
+                p1_sep_visit<MAXC>(P, i, xi, a.tol, a.viol_tol, a.seed, a.first_index + (uint64_t)gr, t, V);
+                if (V.status) my_status = V.status;
+                if (!V.visited) continue;
                 my_visits++;
-                // Only the LAST successful bisection step decides the point (qcqp.py:126-131 overwrite new_xi
-                // each time) and every draw of the counter-based stream is independent of the others, so
-                // the Philox draw is deferred: a successful step just remembers its set and its draw
-                // index.  A set with an unbounded piece draws at once (the reference may raise there).
-                FeasSet<MAXC> Cp;
-                uint32_t itp = 0;
-                bool pending = false;
-                // Boolean-type constraint p x^2 + r == 0 (p > tol, no linear term): |f| <= s is the band
-                // a <= |x| <= b with a = sqrt(D2)/(2p), b = sqrt(D1)/(2p), D1 = 4p(s - r), D2 = -4p(r + s)
-                // (utilities.py:209-231 with q = 0).  The set is non-empty iff D1 > 0 and (D2 < 0 or D2 < D1)
-                // -- square root and division are monotone, touching / zero-width pieces vanish in the sweep --
-                // so the bisection only needs the two discriminants; the set itself is built once, for the
-                // last successful slack.
-                const bool band = mf == 1 && cq[0] == 0.0 && crel[0] == RELOP_EQ && cp[0] > 1e-4;
-                double sp = 0.0;
-                while (es - ss > a.tol) {
-                    double s = (ss + es) / 2.0;
-                    if (band) {
-                        const uint32_t itb = it++;
-                        const double D1 = 0.0 - 4.0 * cp[0] * (cr[0] - s);     // q*q - 4 p rs, as the reference forms it
-                        const double D2 = 0.0 - 4.0 * (-cp[0]) * (-cr[0] - s);
-                        const bool nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
-                        if (!nonempty) { ss = s; continue; }
-                        sp = s; itp = itb; pending = true;
-                        new_viol = s; es = s;
-                        continue;
-                    }
-                    FeasSet<MAXC> C;
-                    if (mf == 1) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], s, C);
-                    else feasible_set<MAXC>(cp, cq, cr, crel, mf, s, C);
-                    const uint32_t itc = it++;
-                    if (C.n == 0) { ss = s; continue; }
-                    bool unb = false;
-#pragma unroll
-                    for (int j = 0; j <= MAXC; j++) unb = unb || (j < C.n && (__builtin_isinf(C.lo[j]) || __builtin_isinf(C.hi[j])));
-                    if (unb) {
-                        DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t, itc};
-                        double xn;
-                        int got = onevar_minimise<MAXC>(0.0, 0.0, 0.0, C, dk, &xn);
-                        if (got < 0) { my_status = got; pending = false; break; }
-                        new_xi = xn; pending = false;
-                    } else {
-                        Cp = C; itp = itc; pending = true;
-                    }
-                    new_viol = s; es = s;
-                }
-                if (pending && band) feasible_set_single<MAXC>(cp[0], cq[0], cr[0], crel[0], sp, Cp);
-                if (pending) {
-                    DrawKey dk{a.seed, a.first_index + (uint64_t)gr, (uint32_t)i, (uint32_t)t, itp};
-                    double xn = xi;
-                    const int got = onevar_minimise<MAXC>(0.0, 0.0, 0.0, Cp, dk, &xn);
-                    // the band test decides non-emptiness on the discriminants; the set rebuilt from rounded
-                    // end points can collapse to nothing: then the step is infeasible at this slack, as in
-                    // the reference (onevar_qcqp returns None -> the move is not made)
-                    if (got == 1) new_xi = xn;
-                    else { new_viol = viol; if (got < 0) my_status = got; }
-                }
-                if (new_viol < viol) { xi = new_xi; Xs[i * 16 + r] = xi; upd = 1; my_acc++; }
-                // violation of the constraints on x_i after the update (feeds qcqp.py:142)
-#pragma unroll
-                for (int k = 0; k < MAXC; k++)
-                    if (k < mf) {
-                        double v = viol_of((cp[k] * xi + cq[k]) * xi + cr[k], crel[k]);
-                        vmax = v > vmax ? v : vmax;
-                    }
+                if (V.moved) { Xs[i * 16 + r] = xi; upd = 1; my_acc++; }
+                vmax = V.vafter > vmax ? V.vafter : vmax;
             }
         }
         vred[tid] = vmax; ured[tid] = upd;

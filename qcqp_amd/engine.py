@@ -158,6 +158,31 @@ class Engine(object):
         out['status1'], out['status2'] = st1, st2     # != 0: the reference would raise on this restart (f0 = inf)
         return out
 
+    def cd_stream_run(self, K, R, generate=True, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=0, seed_stride=1,
+                      first_index=0, first_stride=0, select_tol=1e-4, want_best_x=True):
+        """K populations of R restarts -- suggest(RANDOM) + improve(COORD_DESCENT) + best point each -- in ONE persistent launch
+        (qcqpmi_cd_stream_run, Boolean family).  Population p: seed + p seed_stride, global restart indices first_index +
+        p first_stride + [0, R).  Returns the dictionary of cd_run over all K R restarts (population-major) plus
+        best_index / best_f0 / best_maxviol (K,) and best_x (K, n)."""
+        K, R = int(K), int(R)
+        T = K * R
+        out = dict(sweeps1=np.zeros(T, dtype=np.int64), sweeps2=np.zeros(T, dtype=np.int64),
+                   visits2=np.zeros(T, dtype=np.int64), accepted2=np.zeros(T, dtype=np.int64),
+                   ran_phase2=np.zeros(T, dtype=np.uint8), f0=np.empty(T), maxviol=np.empty(T),
+                   best_index=np.zeros(K, dtype=np.int64), best_f0=np.empty(K), best_maxviol=np.empty(K),
+                   best_x=np.zeros((K, self.n)) if want_best_x else None)
+        self._chk(self.L.qcqpmi_cd_stream_run(self.h, K, R, int(bool(generate)), int(bool(phase1)), int(num_iters), float(viol_tol),
+                                              float(tol), int(seed), int(seed_stride), int(first_index), int(first_stride),
+                                              float(select_tol), _ip(out['sweeps1']), _ip(out['sweeps2']), _ip(out['visits2']),
+                                              _ip(out['accepted2']), _bp(out['ran_phase2']), _dp(out['f0']), _dp(out['maxviol']),
+                                              _ip(out['best_index']), _dp(out['best_f0']), _dp(out['best_maxviol']),
+                                              _dp(out['best_x']) if want_best_x else None))
+        st1 = np.zeros(T, dtype=np.int32)
+        st2 = np.zeros(T, dtype=np.int32)
+        self._chk(self.L.qcqpmi_cd_status(self.h, st1.ctypes.data_as(C.POINTER(C.c_int)), st2.ctypes.data_as(C.POINTER(C.c_int))))
+        out['status1'], out['status2'] = st1, st2
+        return out
+
     # the same run in stages (see qcqpmi_cd_run_stage): cd_begin and cd_phase2 only enqueue work on this context's stream
     def cd_begin(self, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=0, first_index=0):
         """Phase 1 + evaluation + gate of the resident population, asynchronous."""
