@@ -13,17 +13,17 @@ or -- plain `python bench.py --gpus N` -- this process becomes rank 0 and starts
 (qcqp_amd.dist.spawn_local_ranks; the RCCL unique id travels through a file rendezvous, no torch).
 Weak scaling (default): every rank runs --restarts restarts with disjoint GLOBAL restart indices;
 strong: --restarts restarts in total, split over the ranks.  The only collective is the best-point
-selection (RCCL all-gather + broadcast inside libqcqp_mi.so).
+selection (RCCL inside libqcqp_mi.so: two all-reduces for all steps of a streamed run).
 
 `value` counts PHASE-2 restart-sweeps only (the unit SURVEY.md section 8d defines: 2 n^2 flops each);
 phase-1 sweeps (element-wise for this family) are reported separately.
 
-How the steps are scheduled (--scheme, DESIGN.md sections 4.1c / 6).  `two`: two contexts per GPU, the preparation of step
-k + 1 runs in the tail of the phase-2 kernel of step k, phase-2 launches never overlap.  `ring`: ONE persistent phase-2 launch
-on 192 CUs serves the populations of four contexts in turn, the other 64 CUs prepare the next populations.  `auto` (default):
-the K steps after W warm-up steps are measured with `two` in this process and then -- on one GPU -- with `ring` in a child
-process with a time limit (the ring needs the HIP runtime started with more hardware queues, and a stall must not cost the
-line); the faster scheme is reported, both are in the line (`schemes`), the best point must be the same.
+How the steps are scheduled (--scheme, DESIGN.md sections 4.1d / 6).  `stream` (default): the K timed steps are ONE persistent
+launch of the lifecycle kernel per GPU (qcqpmi_cd_stream_run): a workgroup owns 16 restart slots and a slot that becomes free
+draws the next restart of the run and runs its whole step itself -- keyed normals, phase 1, gate, phase 2, objective -- so no
+step waits for the slowest restart of the previous one; then one selection launch per step and ONE exchange over the ranks for
+all steps.  `two` (rounds 2 / 3): two contexts per GPU, one phase-2 launch per step, the preparation of step k + 1 in the tail of
+launch k.  `auto`: stream, and on one GPU the same steps through `two` as well (`schemes` in the line; same best point).
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,11 +41,12 @@ sys.path.insert(0, REPO)
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (AMD datasheet); see DESIGN.md section 4
 
 
-def profiled_counters():
-    """PMC-derived numbers of the phase-2 kernel from the committed profile summary of this round
+def profiled_counters(kernel_name):
+    """PMC-derived numbers of the headline kernel from the committed profile summary of this round
     (profiles/rNN_summary.json, written by tools/summarize_profile.py from separate rocprofv3 --pmc passes of
     THIS command line).  Not measured in this run: returned with their provenance (file, git commit of the
-    profile, date) so that the bench line says where they come from; None if absent."""
+    profile, date, kernel, what one launch was) so that the bench line says where they come from; only a summary of the
+    kernel this run reports is used; None if absent."""
     pdir = os.path.join(REPO, 'profiles')
     best = None
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -54,10 +55,10 @@ def profiled_counters():
                 d = json.load(open(os.path.join(pdir, name)))
             except Exception:
                 continue
-            if 'cd_phase2_hbm_bytes_per_launch' in d:
+            if 'cd_phase2_hbm_bytes_per_launch' in d and (d.get('kernel') or '').split('<')[0] == (kernel_name or '').split('<')[0]:
                 best = dict(traffic=d['cd_phase2_hbm_bytes_per_launch'], mfma_busy=d.get('cd_phase2_mfma_busy_frac'),
                             source='profiles/' + name, profile_commit=d.get('git_commit'), profile_date=d.get('date'),
-                            kernel=d.get('kernel'))
+                            kernel=d.get('kernel'), launch=d.get('launch'))
     return best
 
 
@@ -424,7 +425,7 @@ def cpu_baseline(n, m_rows, seed, winner, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=320)      # > 1 s of timed work at N = 1
+    ap.add_argument('--steps', type=int, default=200)      # 0.5 s of timed work at N = 1 (all steps resident: 64 MiB per step)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--n', type=int, default=1024)
     ap.add_argument('--m-rows', type=int, default=256)
@@ -433,27 +434,20 @@ def main():
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--cpu-cores', type=int, default=0, help='host cores for the CPU baselines (0 = all usable, at most 32)')
     ap.add_argument('--no-overlap', dest='overlap', action='store_false',
-                    help='one context only: every step runs strictly after the previous one')
-    ap.add_argument('--chain', dest='chain', action='store_true',
-                    help='experimental: ring of chained contexts, phase 2 through the slot-queue kernel, launches run restarts of the next '
-                         'populations (qcqpmi_cd_chain); default: two contexts, phase-2 launches never overlap (DESIGN.md section 4.1c)')
-    ap.add_argument('--p2-cus', type=int, default=0, help='chained mode: CUs the phase-2 launches are confined to (0 = no partition)')
-    ap.add_argument('--scheme', choices=['auto', 'two', 'ring'], default='auto',
-                    help='two: two contexts, phase-2 launches never overlap; ring: ONE persistent slot-queue launch on 192 CUs serves the '
-                         'populations of four contexts in turn (DESIGN.md section 4.1c); auto (default): `two` in this process, then -- on one '
-                         'GPU -- `ring` in a child process with a time limit, and the faster of the two is reported (both are in the line)')
-    ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)
+                    help='scheme two with one context only: every step runs strictly after the previous one')
+    ap.add_argument('--scheme', choices=['auto', 'stream', 'two'], default='auto',
+                    help='stream: the K steps as ONE persistent launch of the lifecycle kernel (qcqpmi_cd_stream_run: every restart runs its '
+                         'whole step -- suggest, phase 1, gate, phase 2, objective -- in a slot of a workgroup; DESIGN.md section 4.1d); two: '
+                         'round 2/3 scheme, two contexts per GPU, one phase-2 launch per step, the preparation of step k + 1 in the tail of launch k; '
+                         'auto (default): stream, and on one GPU the same steps through `two` as well (in the line under `schemes`; the best point '
+                         'must be the same)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the bounded records of the other BASELINE.json configs')
     ap.add_argument('--sdr-full', action='store_true', help='add the SDP relaxation of configs[4] at FULL size (137.6 GB, about 100 s) to the secondary records')
     args = ap.parse_args()
-    ringmode = args.scheme == 'ring'
-    if ringmode:
-        # more hardware queues than the runtime's default of 4: a member's stream must not share one with the persistent launch
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
     from qcqp_amd import dist, problems
-    from qcqp_amd.engine import Engine
+    from qcqp_amd.engine import Engine, EngineError
     from qcqp_amd.form import QCQPForm
 
     kids = dist.spawn_local_ranks(args.gpus)       # no-op under a launcher or for 1 GPU
@@ -468,121 +462,49 @@ def main():
     form = QCQPForm.from_arrays(funcs)
     eng = Engine(form, device=local_rank)
     boot = dist.init_rccl(eng, rank, world)
-    # A second context (= a second HIP stream) on the same GPU.  The steps alternate between the two: while the phase-2
-    # kernel of step k runs -- its tail leaves most CUs idle: 4096 restarts are one tile per CU and the launch lasts as long
-    # as the slowest restart -- suggest, phase 1, evaluation and gate of step k + 1 are already being worked on in the
-    # other stream.  The phase-2 kernels themselves never overlap (the next one is launched after the results of the
-    # current one have been fetched), so their HIP-event durations stay those of a kernel that owns the chip.
-    eng2 = None
-    if args.overlap and not ringmode:
-        try:
-            eng2 = Engine(form, device=local_rank)
-            dist.init_rccl(eng2, rank, world, bootstrap=boot)   # its own communicator (same rendezvous object)
-            ok = 1.0
-        except Exception as ex:     # never lose the run over the optimisation: fall back to strictly serial steps
-            sys.stderr.write('bench: second context unavailable (%r): steps will not overlap\n' % (ex,))
-            eng2, ok = None, 0.0
-        if world > 1:               # every rank must take the same path (the collectives alternate between the communicators)
-            if float(eng.comm_allreduce([ok], 'sum')[0]) < world:
-                eng2 = None
-    engs = [eng, eng2] if eng2 is not None else [eng]
-    # Chained mode (default): THREE contexts in a ring.  Phase 2 runs through the slot-queue kernel (cd_phase2_qs_kernel): a
-    # workgroup owns 16 slots, a restart that is done is written out at the next sweep boundary and its slot takes the next
-    # restart of the population -- or, once that queue is empty, of the NEXT step's population, which the next context has
-    # prepared meanwhile (qcqpmi_cd_chain).  The launches of consecutive steps therefore overlap and the matrix pipes do not
-    # idle while the last restarts of a step converge.
-    chained = False
-    LA = 2          # a launch may run restarts of the next LA populations
-    DL = 2          # results of step k are fetched DL steps after its launch (its launch ends when population k + LA is exhausted)
-    if args.chain and eng2 is not None:
-        ring = [eng, eng2]
-        try:
-            while len(ring) < LA + DL + 2:
-                ex_ = Engine(form, device=local_rank)
-                dist.init_rccl(ex_, rank, world, bootstrap=boot)
-                ring.append(ex_)
-            ok = 1.0
-        except Exception as ex:
-            sys.stderr.write('bench: contexts for the chained mode unavailable (%r): steps will not be chained\n' % (ex,))
-            ok = 0.0
-        if world > 1 and float(eng.comm_allreduce([ok], 'sum')[0]) < world:
-            ok = 0.0
-        if ok:
-            engs = ring
-            chained = True
-            for e_ in engs:
-                e_.cd_queue(1)
-                e_.cd_partition(args.p2_cus)
+    K = max(args.steps, 1)
 
-    RING_CUS, RING_N = 192, 4
-    ring_pos = [0]
-    if ringmode:
-        ring = [eng]
-        while len(ring) < RING_N:
-            ex_ = Engine(form, device=local_rank)
-            if world > 1:               # (one rank: no communicator per context -- every RCCL communicator brings streams of its own,
-                dist.init_rccl(ex_, rank, world, bootstrap=boot)      # and the ring needs its hardware queues)
-            ring.append(ex_)
-        engs = ring
-        for e_ in engs:                 # every buffer exists before the persistent launch starts
-            e_.randn(R, seed=1, first_index=first)
-            e_.cd_run(phase1=True, seed=1, first_index=first)
-        Engine.ring_start(engs, phase2_cus=RING_CUS)
+    def allreduce_sum(a):
+        return eng.comm_allreduce(a, 'sum')
 
-    def prepare(e, k):
-        e.randn(R, seed=args.seed + k, first_index=first)
-        e.cd_begin(phase1=True, seed=args.seed + k, first_index=first)
+    # ------------------------------------------------------------------ scheme `stream` (default): one launch for all steps
+    def run_stream(count, base):
+        """`count` steps -- step k = suggest(RANDOM) with seed + k, improve(COORD_DESCENT), best point -- through ONE launch of the
+        lifecycle kernel on this rank's restarts, then ONE exchange over the ranks for the global best of every step (two
+        all-reduces: the keys, the winners' points)."""
+        o = eng.cd_stream_run(count, R, generate=True, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=args.seed + base,
+                              seed_stride=1, first_index=first, first_stride=0, select_tol=1e-4)
+        ms = eng.kernel_ms(Engine.KERNEL_CD2)
+        keys, X = dist.global_best_of_populations(allreduce_sum, rank, world, o['best_f0'], o['best_maxviol'], first + o['best_index'], o['best_x'])
+        return o, keys, X, ms
 
-    def run_steps(count, base, record):
-        """`count` steps; step k = suggest(RANDOM) + improve(COORD_DESCENT) + selection of the best point."""
+    # ------------------------------------------------------------------ scheme `two` (rounds 2 / 3): one phase-2 launch per step
+    # A second context (= a second HIP stream) on the same GPU.  The steps alternate between the two: while the phase-2 kernel of
+    # step k runs -- its tail leaves most CUs idle: 4096 restarts are one tile per CU and the launch lasts as long as the slowest
+    # restart -- suggest, phase 1, evaluation and gate of step k + 1 are already being worked on in the other stream.  The phase-2
+    # kernels themselves never overlap (the next one is launched after the results of the current one have been fetched).
+    def make_two():
+        engs = [Engine(form, device=local_rank)]
+        dist.init_rccl(engs[0], rank, world, bootstrap=boot)
+        if args.overlap:
+            try:
+                e2 = Engine(form, device=local_rank)
+                dist.init_rccl(e2, rank, world, bootstrap=boot)   # its own communicator (same rendezvous object)
+                ok = 1.0
+            except Exception as ex:     # never lose the run over the optimisation: fall back to strictly serial steps
+                sys.stderr.write('bench: second context unavailable (%r): steps will not overlap\n' % (ex,))
+                e2, ok = None, 0.0
+            if world > 1 and float(eng.comm_allreduce([ok], 'sum')[0]) < world:     # every rank must take the same path
+                e2 = None
+            if e2 is not None:
+                engs.append(e2)
+        return engs
+
+    def run_two(engs, count, base, record):
+        def prepare(e, k):
+            e.randn(R, seed=args.seed + k, first_index=first)
+            e.cd_begin(phase1=True, seed=args.seed + k, first_index=first)
         if count <= 0:
-            return
-        if ringmode:
-            NC = len(engs)
-            p0 = ring_pos[0]            # the populations of a run visit the members in turn: the count goes on across calls
-            ring_pos[0] += count
-
-            def submit(j):
-                e = engs[(p0 + j) % NC]
-                e.randn(R, seed=args.seed + base + j, first_index=first)
-                e.ring_submit(phase1=True, seed=args.seed + base + j, first_index=first)
-            for j in range(min(NC - 1, count)):
-                submit(j)
-            for k in range(count):
-                e = engs[(p0 + k) % NC]
-                out = e.ring_collect()
-                if world > 1:
-                    b = e.comm_select_best(1e-4, index_offset=first)
-                else:
-                    sb = e.select_best(1e-4)
-                    b = (sb[0] + first, sb[1], sb[2], sb[3])
-                record(k, e, out, b)
-                if k + NC - 1 < count:
-                    submit(k + NC - 1)
-            return
-        if chained:
-            NC = len(engs)
-
-            def finish(j):
-                e = engs[j % NC]
-                out = e.cd_fetch()          # waits for launch j and for the launches j - LA .. j - 1 (they may have run restarts of step j)
-                record(j, e, out, e.comm_select_best(1e-4, index_offset=first))
-            for j in range(min(LA + 1, count)):
-                prepare(engs[j % NC], base + j)
-            for k in range(count):
-                cur = engs[k % NC]
-                for p_ in range(1, LA + 1):
-                    cur.cd_chain(engs[(k + p_) % NC] if k + p_ < count else None, R, args.seed + base + k + p_, first, pos=p_)
-                cur.cd_phase2()
-                if k + LA + 1 < count:
-                    prepare(engs[(k + LA + 1) % NC], base + k + LA + 1)   # ready long before the launches reach it
-                if k >= DL:
-                    finish(k - DL)
-            for j in range(max(count - DL, 0), count):
-                finish(j)
-            for e in engs:
-                for p_ in range(1, 4):
-                    e.cd_chain(None, pos=p_)
             return
         prepare(engs[0], base)
         engs[0].cd_phase2()
@@ -605,36 +527,65 @@ def main():
                     cur.cd_phase2()
             record(k, cur, out, b)
 
-    warm_flops = [0.0]
-    run_steps(args.warmup, -1000, lambda k_, c_, out_, b_: warm_flops.__setitem__(0, warm_flops[0] + float(out_['visits2'].sum()) * 2.0 * n))
-    for e_ in engs:
-        e_.sync()
-    eng.comm_barrier()
-    acc = dict(sweeps1=0.0, sweeps2=0.0, p2_flops=0.0, p2_ms=0.0, p1_ms=0.0, best=None, best_step=-1)
+    def measure_two():
+        engs = make_two()
+        run_two(engs, args.warmup, -1000, lambda *a_: None)
+        for e_ in engs:
+            e_.sync()
+        eng.comm_barrier()
+        acc = dict(sweeps1=0.0, sweeps2=0.0, p2_flops=0.0, p2_ms=0.0, p1_ms=0.0, best=None, best_step=-1)
 
-    def record(k, cur, out, b):
-        acc['sweeps1'] += float(out['sweeps1'].sum())
-        acc['sweeps2'] += float(out['visits2'].sum()) / n
-        acc['p2_flops'] += float(out['visits2'].sum()) * 2.0 * n   # algorithmic: 2n flops per visit
-        acc['p2_ms'] += 0.0 if ringmode else cur.kernel_ms(Engine.KERNEL_CD2)      # (ring: one launch for the whole run)
-        acc['p1_ms'] += cur.kernel_ms(Engine.KERNEL_CD1)
-        best = acc['best']
-        if best is None or dist.better_key(b[1], b[2], b[0]) < dist.better_key(best[1], best[2], best[0]):
-            acc['best'], acc['best_step'] = b, k
+        def record(k, cur, out, b):
+            acc['sweeps1'] += float(out['sweeps1'].sum())
+            acc['sweeps2'] += float(out['visits2'].sum()) / n
+            acc['p2_flops'] += float(out['visits2'].sum()) * 2.0 * n   # algorithmic: 2n flops per visit
+            acc['p2_ms'] += cur.kernel_ms(Engine.KERNEL_CD2)
+            acc['p1_ms'] += cur.kernel_ms(Engine.KERNEL_CD1)
+            best = acc['best']
+            if best is None or dist.better_key(b[1], b[2], b[0]) < dist.better_key(best[1], best[2], best[0]):
+                acc['best'], acc['best_step'] = b, k
+        t0 = time.perf_counter()
+        run_two(engs, args.steps, 0, record)
+        for e_ in engs:
+            e_.sync()
+        eng.comm_barrier()
+        acc['dt'] = time.perf_counter() - t0
+        acc['kernel'] = engs[0].last_cd_kernel()
+        acc['contexts'] = len(engs)
+        return acc
 
-    t0 = time.perf_counter()
-    run_steps(args.steps, 0, record)
-    for e_ in engs:
-        e_.sync()
-    sweeps1, sweeps2, p2_flops, p2_ms, p1_ms = acc['sweeps1'], acc['sweeps2'], acc['p2_flops'], acc['p2_ms'], acc['p1_ms']
-    best, best_step = acc['best'], acc['best_step']
-    eng.sync()
-    eng.comm_barrier()
-    dt = time.perf_counter() - t0
+    scheme = args.scheme
+    if scheme in ('auto', 'stream'):
+        try:
+            run_stream(args.warmup, -1000)
+            ok = 1.0
+        except EngineError as ex:       # a problem family the lifecycle kernel does not take (--n not a multiple of 16, ...)
+            if scheme == 'stream':
+                raise
+            sys.stderr.write('bench: scheme stream not available (%s): scheme two\n' % (ex,))
+            ok = 0.0
+        if world > 1:                   # every rank must take the same path
+            ok = 1.0 if float(eng.comm_allreduce([ok], 'sum')[0]) >= world else 0.0
+        scheme = 'stream' if ok else 'two'
+
     launch_ms = None
-    if ringmode:
-        engs[0].ring_stop()
-        launch_ms = engs[0].kernel_ms(Engine.KERNEL_CD2)      # HIP events on the ring's stream around the ONE persistent launch
+    if scheme == 'stream':
+        eng.sync()
+        eng.comm_barrier()
+        t0 = time.perf_counter()
+        o, keys, Xbest, launch_ms = run_stream(args.steps, 0)
+        eng.sync()
+        eng.comm_barrier()
+        dt = time.perf_counter() - t0
+        sweeps1, sweeps2 = float(o['sweeps1'].sum()), float(o['visits2'].sum()) / n
+        p2_flops, p2_ms, p1_ms = float(o['visits2'].sum()) * 2.0 * n, launch_ms, 0.0
+        best_step = min(range(K), key=lambda k: dist.better_key(keys[k][1], keys[k][2], keys[k][0]) + (k,))
+        best = (keys[best_step][0], keys[best_step][1], keys[best_step][2], Xbest[best_step])
+        kernel_name, contexts = eng.last_cd_kernel(), 1
+    else:
+        acc = measure_two()
+        dt, sweeps1, sweeps2, p2_flops, p2_ms, p1_ms = acc['dt'], acc['sweeps1'], acc['sweeps2'], acc['p2_flops'], acc['p2_ms'], acc['p1_ms']
+        best, best_step, kernel_name, contexts = acc['best'], acc['best_step'], acc['kernel'], acc['contexts']
     dt = float(eng.comm_allreduce([dt], 'max')[0])
     tot = eng.comm_allreduce([sweeps1, sweeps2, p2_flops, p2_ms], 'sum')
     p2_ms_max = float(eng.comm_allreduce([p2_ms], 'max')[0])
@@ -642,12 +593,16 @@ def main():
 
     rc = 0
     if rank == 0:
-        K = max(args.steps, 1)
-        achieved = (p2_flops / 1e12) / (p2_ms / 1e3) if p2_ms > 0 else 0.0      # rank 0's GPU, its own launches
-        if chained or ringmode:
-            # the launches of consecutive steps overlap / one launch serves all steps: the busy time of phase 2 is the timed region itself
-            achieved = (p2_flops / 1e12) / dt
-        pmc = profiled_counters()
+        achieved = (p2_flops / 1e12) / (p2_ms / 1e3) if p2_ms > 0 else 0.0      # rank 0's GPU, its own launches (HIP events)
+        pmc = profiled_counters(kernel_name)
+        overlap_text = {
+            'stream': 'ONE persistent launch of the lifecycle kernel per GPU for all %d steps: a workgroup owns 16 restart slots, a slot that becomes '
+                      'free draws the next restart index of the run (steps in order) and runs that restart\'s whole step itself -- keyed normals, '
+                      'phase 1, gate, phase 2 to convergence, objective and max violation -- so the matrix pipes work on live restarts across step '
+                      'boundaries; no preparation kernels, no second stream, no CU partition; per step the best point is selected on the device, '
+                      'then ONE exchange over the ranks (two all-reduces) for all steps; results per restart do not depend on the scheduling' % K,
+            'two': ('two contexts per GPU: suggest + phase 1 + evaluation + gate of step k+1 run in a second stream while the phase-2 kernel of '
+                    'step k finishes; phase-2 kernels never overlap each other') if contexts > 1 else 'none (steps strictly one after the other)'}
         res = {
             'metric': 'restarts x coord-sweeps / sec (improve COORD_DESCENT, phase-2 coordinate sweeps of 2 n^2 flops; '
                       'suggest + phase 1 + gate + phase 2 to convergence + selection inside the timed step)',
@@ -668,98 +623,53 @@ def main():
                                                                     'per GPU' if args.scaling == 'weak' else 'in total'),
                        'restarts_per_gpu': R, 'num_iters': 1000, 'viol_tol': 1e-2, 'tol': 1e-4,
                        'sharding': 'restarts by global index, replicas of P',
-                       'scheme': 'ring' if ringmode else ('chain' if chained else 'two'),
-                       'step_overlap': ('ring: ONE persistent slot-queue launch (cd_phase2_qs_kernel: 16 restart slots per workgroup, refilled from '
-                                        'device-side queues at sweep boundaries) on %d CUs serves the populations of %d contexts in turn; suggest, '
-                                        'phase 1, evaluation and gate of the next populations run on the other CUs; no launch per step, no '
-                                        'exposed tail; results per restart do not depend on the scheduling' % (RING_CUS, RING_N)) if ringmode else
-                                       ('%d chained contexts per GPU (populations prepared %d steps ahead, a launch may run restarts of the next %d populations; phase-2 launches confined to %d CUs): the phase-2 launch of step k (slot-queue kernel: 16 restart slots '
-                                        'per workgroup) takes restarts of step k+1 -- prepared meanwhile in the next context: suggest, '
-                                        'phase 1, evaluation, gate -- once its own queue is empty; results per restart do not depend on '
-                                        'the scheduling' % (len(engs), LA + 1, LA, args.p2_cus or 256)) if chained else
-                                       ('two contexts per GPU: suggest + phase 1 + evaluation + gate of step k+1 run in a second stream '
-                                        'while the phase-2 kernel of step k finishes; phase-2 kernels never overlap each other')
-                                       if len(engs) > 1 else 'none (steps strictly one after the other)'},
+                       'scheme': scheme, 'step_overlap': overlap_text[scheme]},
             'phase2_sweeps_per_restart': sweeps2_all / (K * world * max(R, 1)),
             'phase1': {'restart_sweeps_per_s_incl': (sweeps1_all + sweeps2_all) / dt,
                        'sweeps_per_restart': sweeps1_all / (K * world * max(R, 1)),
-                       'kernel_ms_per_launch': p1_ms / K,
+                       'kernel_ms_per_launch': None if scheme == 'stream' else p1_ms / K,
                        'note': 'phase 1 is element-wise for separable constraints (objective identically 0, '
-                               'qcqp.py:114): not counted in value'},
+                               'qcqp.py:114): not counted in value' + ('; it runs inside the lifecycle launch' if scheme == 'stream' else '')},
             'best': {'objective': best[1], 'max_violation': best[2], 'global_restart_index': best[0],
                      'step': best_step},
-            'roofline': {'bound': 'mfma', 'kernel': eng.last_cd_kernel() or 'cd_general_kernel', 'achieved': achieved,
+            'roofline': {'bound': 'mfma', 'kernel': kernel_name or 'cd_general_kernel', 'achieved': achieved,
                          'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_PEAK_TFLOPS,
                          'traffic': pmc['traffic'] if pmc else None,
-                         'traffic_provenance': ({k: pmc[k] for k in ('source', 'profile_commit', 'profile_date', 'kernel')}
+                         'traffic_provenance': ({k: pmc[k] for k in ('source', 'profile_commit', 'profile_date', 'kernel', 'launch')}
                                                 if pmc else None),
                          'mfma_busy': pmc['mfma_busy'] if pmc else None,
                          'algorithmic_flops_per_restart_sweep': 2.0 * n * n,
-                         'algorithmic_flops_per_launch': None if ringmode else p2_flops / K,      # (ring: ONE launch serves every step)
+                         'algorithmic_flops_per_launch': p2_flops if scheme == 'stream' else p2_flops / K,
                          'algorithmic_flops_per_step': p2_flops / K,
-                         'kernel_ms_per_launch': None if ringmode else p2_ms / K,
-                         'persistent_launch': ({'ms': launch_ms, 'flops_served': warm_flops[0] + p2_flops,
-                                                'achieved': (warm_flops[0] + p2_flops) / 1e12 / (launch_ms / 1e3) if launch_ms else None,
-                                                'note': 'HIP events on the ring stream around the ONE launch that served the %d warm-up and the %d '
-                                                        'timed steps: it also spans the waits before, between and after them (the duration '
-                                                        'rocprofv3 reports for cd_phase2_qs_kernel)' % (args.warmup, args.steps)}
-                                               if ringmode else None),
-                         'restarts_run_ahead_per_step': (sum(e_.cd_pulled() for e_ in engs) / float(args.steps + args.warmup)) if chained else None,
-                         'timing': ('one persistent launch serves every step (busy throughout): flops of the timed steps / wall time of the '
-                                    'timed region (%.4f s)' % dt) if ringmode else
-                                   ('chained launches overlap each other: flops of all timed steps / wall time of the timed region (%.4f s); '
-                                    'the sum of the HIP-event durations of the launches is %.1f ms per step' % (dt, p2_ms / K)) if chained
-                                   else 'HIP events on the engine stream around every phase-2 launch of the timed steps'},
+                         'kernel_ms_per_launch': p2_ms if scheme == 'stream' else p2_ms / K,
+                         'launches': 1 if scheme == 'stream' else K,
+                         'timing': ('HIP events on the engine stream around the ONE launch that runs all %d timed steps (everything a step does '
+                                    'happens inside it except the %d one-workgroup selection launches and the copies of the results): flops of '
+                                    'the phase-2 visits / that duration; the wall clock of the timed region is %.4f s' % (K, K, dt))
+                                   if scheme == 'stream' else 'HIP events on the engine stream around every phase-2 launch of the timed steps'},
         }
         if world > 1:
-            res['roofline']['kernel_ms_per_launch_max_over_ranks'] = p2_ms_max / K
+            res['roofline']['kernel_ms_per_launch_max_over_ranks'] = p2_ms_max if scheme == 'stream' else p2_ms_max / K
             res['roofline']['achieved_all_gpus'] = (flops_all / 1e12) / (p2_ms_max / 1e3) if p2_ms_max > 0 else 0.0
-        if world == 1 and args.scheme == 'auto' and not args.child and not args.chain and args.overlap:
-            # The same K steps after the same W warm-up steps through the ring scheme, in a CHILD process with a time limit (the
-            # scheme needs the runtime started with more hardware queues, and a stall must not take the line down).  The faster
-            # scheme is the one reported; the other stays in the line.
-            two = {k_: res[k_] for k_ in ('value', 'ms_per_step', 'timed_region_s', 'phase2_sweeps_per_restart')}
-            two['roofline'] = {k_: res['roofline'][k_] for k_ in ('kernel', 'achieved', 'frac', 'kernel_ms_per_launch', 'timing')}
-            two['best'] = dict(res['best'])
-            two['step_overlap'] = res['config']['step_overlap']
+        if world == 1 and args.scheme == 'auto' and scheme == 'stream':
+            # the same K steps (same seeds) through the scheme of rounds 2 / 3, for comparison: the best point must be the same one
             try:
-                import subprocess
-                env = dict(os.environ)
-                env['GPU_MAX_HW_QUEUES'] = '16'
-                cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
-                       '--n', str(n), '--m-rows', str(args.m_rows), '--restarts', str(args.restarts), '--scaling', args.scaling,
-                       '--seed', str(args.seed), '--scheme', 'ring', '--child', '--no-secondary', '--no-cpu-baseline']
-                pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=90 + 0.02 * (args.steps + args.warmup))
-                line = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
-                if pr.returncode != 0 or not line:
-                    raise RuntimeError('child failed (rc %d): %s' % (pr.returncode, pr.stderr.decode()[-300:]))
-                rg = json.loads(line[-1])
-                same_best = (rg['best']['global_restart_index'] == res['best']['global_restart_index'] and rg['best']['step'] == res['best']['step']
-                             and abs(rg['best']['objective'] - res['best']['objective']) <= 1e-9 * (1.0 + abs(res['best']['objective'])))
-                res['schemes'] = {'two': two, 'ring': {k_: rg[k_] for k_ in ('value', 'ms_per_step', 'timed_region_s', 'phase2_sweeps_per_restart')}}
-                res['schemes']['ring']['roofline'] = {k_: rg['roofline'][k_] for k_ in ('kernel', 'achieved', 'frac', 'timing')}
-                res['schemes']['ring']['best'] = rg['best']
-                res['schemes']['ring']['same_best_point_as_two'] = bool(same_best)
-                res['schemes']['ring']['step_overlap'] = rg['config']['step_overlap']
-                if same_best and rg['value'] > res['value']:
-                    for k_ in ('value', 'ms_per_step', 'timed_region_s', 'phase2_sweeps_per_restart'):
-                        res[k_] = rg[k_]
-                    res['phase1'] = rg['phase1']
-                    for k_ in ('kernel', 'achieved', 'frac', 'kernel_ms_per_launch', 'timing', 'algorithmic_flops_per_launch', 'algorithmic_flops_per_step',
-                               'persistent_launch'):
-                        res['roofline'][k_] = rg['roofline'][k_]
-                    # counters of the profiled run belong to the tile-bound kernel of the `two` scheme
-                    res['roofline']['traffic_note'] = 'traffic / mfma_busy: rocprofv3 counters of cd_phase2_q_kernel (scheme two)'
-                    res['config']['scheme'] = 'ring'
-                    res['config']['step_overlap'] = rg['config']['step_overlap']
-                    res['schemes']['reported'] = 'ring'
-                    res['schemes']['note'] = ('runs on more than one GPU use scheme two (the ring has not run on several GPUs yet): compare their '
-                                              'per-GPU value with schemes.two.value, not with value')
-                else:
-                    res['schemes']['reported'] = 'two'
-            except Exception as ex:      # time limit, missing runtime feature, ...: the line of this process stands
-                res['schemes'] = {'two': two, 'ring': {'error': repr(ex)[:400]}, 'reported': 'two'}
+                acc = measure_two()
+                ach2 = (acc['p2_flops'] / 1e12) / (acc['p2_ms'] / 1e3) if acc['p2_ms'] > 0 else 0.0
+                b2 = acc['best']
+                same_best = (int(b2[0]) == int(best[0]) and acc['best_step'] == best_step
+                             and abs(b2[1] - best[1]) <= 1e-9 * (1.0 + abs(best[1])) and float(np.max(np.abs(np.asarray(b2[3]) - np.asarray(best[3])))) <= 1e-9)
+                res['schemes'] = {'reported': 'stream',
+                                  'two': {'value': acc['sweeps2'] / acc['dt'], 'ms_per_step': 1e3 * acc['dt'] / K, 'timed_region_s': acc['dt'],
+                                          'roofline': {'kernel': acc['kernel'], 'achieved': ach2, 'frac': ach2 / FP64_PEAK_TFLOPS,
+                                                       'kernel_ms_per_launch': acc['p2_ms'] / K,
+                                                       'timing': 'HIP events around every phase-2 launch (the launches own the chip; preparation and '
+                                                                 'selection are outside them)'},
+                                          'best': {'objective': b2[1], 'max_violation': b2[2], 'global_restart_index': b2[0], 'step': acc['best_step']},
+                                          'same_best_point_as_stream': bool(same_best), 'step_overlap': overlap_text['two']}}
+            except Exception as ex:
+                res['schemes'] = {'reported': 'stream', 'two': {'error': repr(ex)[:400]}}
         if world == 1 and not args.no_secondary:
             res['secondary'] = secondary_records(local_rank, sdr_full=args.sdr_full)
         if world == 1 and not args.no_cpu_baseline:      # a reported baseline of rank 0 at N = 1 only

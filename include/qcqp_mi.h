@@ -296,6 +296,9 @@ int qcqpmi_cd_ring_submit(qcqpmi_ctx *member, int phase1, int64_t num_iters, dou
 int qcqpmi_cd_ring_collect(qcqpmi_ctx *member, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
                            uint8_t *ran_phase2, double *f0, double *maxviol);
 int qcqpmi_cd_ring_stop(qcqpmi_ctx *owner);      /* owner = members[0] */
+/* debug (after qcqpmi_debug_profile enabled profiling): tick sums (s_memtime, 100 MHz) over the workgroups of the last
+ * qcqpmi_cd_stream_run launch -- [0] column build (suggest + phase 1 + gate), [1] whole launch, [2] episodes, [3] columns built */
+int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out8);
 /* debug: the 9 queue-state words of the context's population (see csrc/cd_queue.h) and hipStreamQuery of the ring's launch */
 int qcqpmi_debug_cd_ring_state(qcqpmi_ctx *ctx, int64_t *out10);
 /* statistics: restarts of this context's populations that were run by the launches of the context chained to it (total) */

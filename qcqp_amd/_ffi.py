@@ -79,6 +79,7 @@ PROTOTYPES = [
     ('qcqpmi_debug_profile', C.c_int, [C.c_void_p, C.c_int, c_ip]),
     ('qcqpmi_debug_admm_profile', C.c_int, [C.c_void_p, c_ip]),
     ('qcqpmi_debug_dense_profile', C.c_int, [C.c_void_p, c_ip]),
+    ('qcqpmi_debug_life_profile', C.c_int, [C.c_void_p, c_ip]),
     ('qcqpmi_dense_chain_mode', C.c_int, [C.c_void_p, C.c_int]),
     ('qcqpmi_dense_chain_geometry', C.c_int, [C.c_int64, C.POINTER(C.c_int)]),
     ('qcqpmi_debug_trace', C.c_int, [C.c_void_p, c_ip, C.c_int]),

@@ -195,6 +195,7 @@ struct qcqpmi_ctx {
     uint64_t chain_seed[3] = {0, 0, 0}, chain_first[3] = {0, 0, 0};   // seed / first index / size of those populations (qcqpmi_cd_chain)
     int64_t chain_R[3] = {0, 0, 0};
     CdLife *d_life = nullptr;    // qcqpmi_cd_stream_run: parameters of the lifecycle launch
+    long long *d_life_prof = nullptr;
     int64_t *d_bestK_idx = nullptr; double *d_bestK_key = nullptr; int64_t bestK_cap = 0;
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
@@ -775,7 +776,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_bestK_idx, c->d_bestK_key};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key};
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1553,6 +1554,12 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     L.on = 1; L.generate = generate ? 1 : 0; L.phase1 = phase1 ? 1 : 0; L.Rtotal = K * R; L.Rpop = R;
     L.seed = seed; L.seed_stride = seed_stride; L.first_index = first_index; L.first_stride = first_stride; L.viol_tol = viol_tol;
     L.sweeps1 = c->d_sweeps1; L.status1 = c->d_status1; L.ran2 = c->d_flag;
+    L.prof = nullptr;
+    if (c->profile) {      // qcqpmi_debug_profile: tick sums of the launch (qcqpmi_debug_life_profile)
+        if (!c->d_life_prof) HIPCHK(c, hipMalloc((void **)&c->d_life_prof, 8 * sizeof(long long)));
+        HIPCHK(c, hipMemsetAsync(c->d_life_prof, 0, 8 * sizeof(long long), c->stream));
+        L.prof = c->d_life_prof;
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_life, &L, sizeof(L), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));       // (L lives on this stack frame)
     CdQueueArgs qa;
@@ -1606,6 +1613,16 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+int qcqpmi_debug_life_profile(qcqpmi_ctx *c, int64_t *out8) {
+    if (!c || !out8) return QCQPMI_EINVAL;
+    for (int k = 0; k < 8; k++) out8[k] = 0;
+    if (!c->d_life_prof) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out8, c->d_life_prof, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -51,6 +51,8 @@ struct CdLife {
     int64_t *sweeps1;            // [Rtotal] phase-1 sweeps
     int *status1;                // [Rtotal] phase-1 status
     uint8_t *ran2;               // [Rtotal] passed the gate (qcqp.py:189)
+    long long *prof;             // optional [8]: ticks (s_memtime) summed over the workgroups -- 0 column build, 1 whole launch, 2 episodes,
+                                 // 3 columns built, 4 write-out; nullptr: off
 };
 
 struct CdQueueArgs {

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
     if (tid0 < 16) { sid[tid0] = -1; sbt[tid0] = 0; sfin[tid0] = 0; }
     if (tid0 == 0) { if (MULTI) for (int q = 0; q < CDQ_MAXB; q++) Bt[q] = a0.b[q]; ctl[1] = 0; ctl[2] = 0; }
     const long long ring_t0 = a.ring ? (long long)wall_clock64() : 0;
+    const long long life_t0 = (LIFE && tid0 == 0) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     __syncthreads();
     const int64_t gmax = (int64_t)1 << 40;         // the roles end through RQ_STOP
 
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
             // normals, the stream of randn_tiles_kernel), phase 1 (qcqp.py:101-149 through p1_sep_visit: the moves of
             // cd_phase1_sep_kernel bit for bit), the max violation = slack of phase 2 (qcqp.py:157) and the gate (qcqp.py:189)
             QG const CdLife *lf = qs_g(lifep);
+            const long long pt0 = lf->prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
             const int lf_generate = lf->generate, lf_phase1 = lf->phase1;
             const double lf_viol_tol = lf->viol_tol;
             const int e0 = P.cptr[P.krep[0]];
@@ -355,6 +357,13 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                 store_set<MAXC>(TC, tid, C);
             }
             __syncthreads();
+            if (lf->prof && tid == 0) {
+                int nn = 0;
+                for (int k = 0; k < 16; k++) nn += snew[k] ? 1 : 0;
+                atomicAdd((unsigned long long *)lf->prof + 0, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pt0));
+                atomicAdd((unsigned long long *)lf->prof + 2, 1ull);
+                atomicAdd((unsigned long long *)lf->prof + 3, (unsigned long long)nn);
+            }
         } else {
             // columns of the restarts just taken (sc1 loads: the next population was written by kernels of another stream
             // while this one was running), zero columns for empty slots
@@ -917,6 +926,8 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
             __syncthreads();
         }
     }
+    if (LIFE && tid0 == 0 && qs_g(a0.life)->prof)
+        atomicAdd((unsigned long long *)qs_g(a0.life)->prof + 1, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - life_t0));
 }
 
 }  // namespace

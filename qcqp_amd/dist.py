@@ -59,6 +59,30 @@ def select_best_host(f0, maxviol, tol=1e-4, index_offset=0):
     return best
 
 
+def global_best_of_populations(allreduce_sum, rank, world, f0, maxviol, gindex, xs, tol=1e-4):
+    """The global best of K populations at once -- ONE exchange for a whole streamed run instead of one per population.
+    Every rank holds, per population k, its local winner (f0[k], maxviol[k], gindex[k] = GLOBAL restart index, xs[k] = the
+    point); `allreduce_sum(array) -> array` sums a float64 array over the ranks (RCCL all-reduce: Engine.comm_allreduce).
+    Round 1: the (world, K, 3) table of keys with only the own row filled; everyone then knows every rank's winners and
+    picks the owner per population (QCQPForm.better ordering, ties -> lowest global index).  Round 2: the (K, n) table of
+    points with only the rows this rank owns filled.  Returns ([(gindex, f0, maxviol)] * K, X (K, n)), identical on every rank."""
+    f0 = np.asarray(f0, dtype=np.float64)
+    K = f0.size
+    xs = np.asarray(xs, dtype=np.float64).reshape(K, -1)
+    keys = np.zeros((world, K, 3))
+    keys[rank, :, 0], keys[rank, :, 1], keys[rank, :, 2] = f0, np.asarray(maxviol, dtype=np.float64), np.asarray(gindex, dtype=np.float64)
+    if world > 1:
+        keys = np.asarray(allreduce_sum(keys.ravel())).reshape(world, K, 3)
+    owner = [min(range(world), key=lambda g: better_key(keys[g, k, 0], keys[g, k, 1], int(keys[g, k, 2]), tol)) for k in range(K)]
+    X = np.zeros_like(xs)
+    for k in range(K):
+        if owner[k] == rank:
+            X[k] = xs[k]
+    if world > 1:
+        X = np.asarray(allreduce_sum(X.ravel())).reshape(K, -1)
+    return [(int(keys[owner[k], k, 2]), float(keys[owner[k], k, 0]), float(keys[owner[k], k, 1])) for k in range(K)], X
+
+
 def _job_key():
     """Directory name every rank of one job agrees on without talking to each other."""
     key = os.environ.get(RDZV_ENV)

@@ -459,3 +459,46 @@ def test_reference_cd_is_chaotic_under_one_ulp(orc):
     assert shares['dense'][0] >= 0.2
     assert shares['beam'][0] >= 0.8
     assert shares['bls'][0] == 0.0 and shares['bls'][1] < 1e-12
+
+
+def test_global_best_of_populations_two_ranks():
+    """dist.global_best_of_populations -- the one exchange of a streamed run (K populations): two ranks (threads here, the
+    all-reduce is a barrier + sum) end with the same winners as the selection rule folded over both shards, population by
+    population, incl. a tie on (bucket, objective) that the lower GLOBAL index must win and a rank whose restarts all failed."""
+    import threading
+    from qcqp_amd import dist
+    K, n, world = 5, 7, 2
+    rs = np.random.RandomState(4)
+    f0 = rs.randn(world, K)
+    mv = np.abs(rs.randn(world, K)) * 1e-5
+    gi = np.stack([rs.randint(0, 100, K), 100 + rs.randint(0, 100, K)])
+    f0[1, 2], mv[1, 2] = f0[0, 2], mv[0, 2]              # a tie: rank 0 holds the lower global index
+    mv[0, 3] = 0.5                                        # another violation bucket: rank 1 wins whatever the objectives
+    f0[1, 4], mv[1, 4] = np.inf, np.inf                   # every restart of rank 1 failed in population 4
+    xs = rs.randn(world, K, n)
+    slots, bar, res = [None, None], threading.Barrier(world), [None, None]
+
+    def allreduce_for(rank):
+        def allreduce(a):
+            slots[rank] = np.array(a, dtype=np.float64)
+            bar.wait()
+            out = slots[0] + slots[1]
+            bar.wait()
+            return out
+        return allreduce
+
+    def run(rank):
+        res[rank] = dist.global_best_of_populations(allreduce_for(rank), rank, world, f0[rank], mv[rank], gi[rank], xs[rank])
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    (k0, X0), (k1, X1) = res
+    assert k0 == k1 and np.array_equal(X0, X1)
+    for k in range(K):
+        want = min(range(world), key=lambda g: dist.better_key(f0[g, k], mv[g, k], gi[g, k]))
+        assert k0[k] == (int(gi[want, k]), float(f0[want, k]), float(mv[want, k])), k
+        assert np.array_equal(X0[k], xs[want, k])
+    assert k0[2][0] == gi[0, 2] and k0[3][0] == gi[1, 3] and k0[4][0] == gi[0, 4]
+    # one rank: no exchange at all
+    ks, Xs = dist.global_best_of_populations(None, 0, 1, f0[0], mv[0], gi[0], xs[0])
+    assert [k[0] for k in ks] == list(gi[0]) and np.array_equal(Xs, xs[0])

@@ -35,6 +35,14 @@ def main():
         sweeps = float(o['visits2'].sum()) / n
         print('stream run %d: wall %.2f ms, kernel %.3f ms, %.3e restart-sweeps/s (kernel), frac %.3f; per population %.3f ms' % (
             rep, 1e3 * dt, ms, sweeps / (ms * 1e-3), sweeps * 2.0 * n * n / (ms * 1e-3) / 78.6e12, ms / K))
+    import ctypes as C
+    es.L.qcqpmi_debug_profile(es.h, 1, None)
+    o2 = es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
+    pr = np.zeros(8, dtype=np.int64)
+    es.L.qcqpmi_debug_life_profile(es.h, pr.ctypes.data_as(C.POINTER(C.c_int64)))
+    es.L.qcqpmi_debug_profile(es.h, 0, None)
+    print('profile: column build %.1f %% of the workgroups\' time; %d episodes, %d columns, %.1f us per column built, %.1f us per episode' % (
+        100.0 * pr[0] / max(pr[1], 1), pr[2], pr[3], pr[0] / 100.0 / max(pr[3], 1), pr[0] / 100.0 / max(pr[2], 1)))
     X = es.download()
     print('kernels:', ref[0][3], '/', es.last_cd_kernel())
     worst = 0.0
