@@ -18,7 +18,7 @@ import logging
 import numpy as np
 
 from . import settings as s
-from .engine import Engine
+from .engine import Engine, EngineError
 from .form import QCQPForm
 
 # module logger (the reference configures the ROOT logger at import, qcqp.py:39, and logs per iteration; this engine
@@ -147,6 +147,11 @@ class QCQP(object):
     def population(self):
         return self.engine.download()
 
+    def _resident_batches(self):
+        """Is the engine's population still the K batches suggest(batches=K) drew (nobody wrote the variables since)?"""
+        b = getattr(self, '_batches', None)
+        return b is not None and self._resident and self.engine.pop_size == b[0] * b[1]
+
     # ------------------------------------------------------------------ suggest
     def suggest(self, method=s.RANDOM, eps=1e-8, *args, **kwargs):
         if method not in s.suggest_methods:
@@ -154,12 +159,25 @@ class QCQP(object):
         R = int(kwargs.pop('num_samples', kwargs.pop('num_restarts', 1)))
         seed = kwargs.pop('seed', None)
         compat = kwargs.pop('compat', True)
+        # batches = K: the reference's user loop `for ...: suggest(); improve()` (README.md:51-57) for K populations of
+        # num_samples points at once -- batch b holds the global restart indices b R .. (b + 1) R - 1 of one keyed stream, i.e.
+        # exactly the points K calls suggest(RANDOM, num_samples=R, first_index=b R) would draw; the improve() that follows
+        # streams them through one persistent launch where the problem allows it (batch_results: the best point of each)
+        K = int(kwargs.pop('batches', 1))
+        first_index = int(kwargs.pop('first_index', 0))
+        self._batches = None
+        self.batch_results = None
+        if K > 1:
+            if method != s.RANDOM:
+                raise Exception("suggest(batches=K) is defined for the RANDOM method")
+            self._batches = (K, R, first_index)
+            R = K * R
         if method == s.RANDOM:
-            if R == 1 and seed is None:
+            if R == 1 and seed is None and first_index == 0:
                 x = np.random.randn(self.n)          # qcqp.py:382, same global-RNG draw
                 self.engine.upload(x)
             else:
-                self.engine.randn(R, seed=0 if seed is None else seed)
+                self.engine.randn(R, seed=0 if seed is None else seed, first_index=first_index)
         elif method == s.SPECTRAL:
             if self.spectral_sol is None:
                 # solve_spectral (qcqp.py:41-70): aggregated constraints, solved by the engine's own SDP solver
@@ -252,8 +270,31 @@ class QCQP(object):
             # reference_order=True: constraints that couple coordinates are walked in the reference's summation order
             # (slow; trajectories comparable with the reference value for value at any n -- qcqpmi_cd_reference_order)
             self.engine.cd_reference_order(bool(kwargs.get('reference_order', False)))
-            out = self.engine.cd_run(phase1=phase1, num_iters=num_iters, viol_tol=viol_tol, tol=tol,
-                                     seed=seed)
+            first_index = int(kwargs.get('first_index', 0))
+            batches = getattr(self, '_batches', None) if self._resident_batches() else None
+            out = None
+            if batches is not None:
+                # population streaming: K batches of R restarts in ONE persistent launch (qcqpmi_cd_stream_run); families the
+                # lifecycle kernel does not take run as one population of K R restarts -- the same restarts either way
+                Kb, Rb, first_index = batches
+                try:
+                    out = self.engine.cd_stream_run(Kb, Rb, generate=False, phase1=phase1, num_iters=num_iters, viol_tol=viol_tol,
+                                                    tol=tol, seed=seed, seed_stride=0, first_index=first_index, first_stride=Rb)
+                except EngineError as ex:
+                    if 'lifecycle' not in str(ex):
+                        raise
+                    log.info('coord_descent: %s', ex)
+            if out is None:
+                out = self.engine.cd_run(phase1=phase1, num_iters=num_iters, viol_tol=viol_tol, tol=tol,
+                                         seed=seed, first_index=first_index)
+            if batches is not None:
+                from .dist import select_best_host
+                Kb, Rb, _ = batches
+                self.batch_results = []
+                for b in range(Kb):
+                    key = select_best_host(out['f0'][b * Rb:(b + 1) * Rb], out['maxviol'][b * Rb:(b + 1) * Rb], 1e-4)
+                    i = key[2]
+                    self.batch_results.append(dict(f=self._sign(out['f0'][b * Rb + i]), v=out['maxviol'][b * Rb + i], index=i))
             self.last_stats = dict(out, method=method, num_restarts=len(out['f0']),
                                    failed_restarts=int(np.count_nonzero(out['status1']) + np.count_nonzero(out['status2'] * (out['status1'] == 0))))
             log.info('coord_descent: %d restarts, phase-1 sweeps %.2f (max %d), phase-2 sweeps %.2f (max %.1f), accepted '

@@ -370,3 +370,35 @@ def test_cvxpy_adapter_drives_the_gpu_path():
     qa.suggest(RANDOM)
     f1, v1 = qa.improve(COORD_DESCENT, seed=11)
     assert abs(f1 - oa[1][0]) <= 1e-9 * (1 + abs(f1)) and abs(v1 - oa[1][1]) <= 1e-9
+
+
+@pytest.mark.parametrize('n', [64, 40])
+def test_suggest_batches_streams_improve(n):
+    """Population streaming behind the drop-in API: the reference's user loop `for ...: suggest(); improve()` (README.md:51-57)
+    for K batches at once -- suggest(RANDOM, num_samples=R, batches=K) draws the K R points of one keyed stream (batch b = global
+    restart indices b R ..), improve(COORD_DESCENT) runs them through ONE persistent launch of the lifecycle kernel (n = 64:
+    Boolean family, n a multiple of 16) or, where that kernel does not apply (n = 40), as one population -- either way batch b
+    must end exactly where the b-th of K serial suggest + improve calls ends, and the variables hold the best of all batches."""
+    from qcqp_amd import QCQP, COORD_DESCENT, RANDOM, problems
+    from qcqp_amd.form import QCQPForm
+    funcs, _, _ = problems.boolean_least_squares(n, 24, seed=6)
+    form = QCQPForm.from_arrays(funcs)
+    K, R = 3, 40
+    q = QCQP(form)
+    q.suggest(RANDOM, num_samples=R, batches=K, seed=5)
+    f, v = q.improve(COORD_DESCENT, seed=7)
+    if n == 64:
+        assert q.engine.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
+    assert len(q.batch_results) == K
+    q2 = QCQP(form)
+    serial = []
+    for b in range(K):
+        q2.suggest(RANDOM, num_samples=R, seed=5, first_index=b * R)
+        fb, vb = q2.improve(COORD_DESCENT, seed=7, first_index=b * R)
+        serial.append((fb, vb, q2.best_index, np.array(q2.prob.variables()[0].value).ravel()))
+        assert abs(q.batch_results[b]['f'] - fb) <= 1e-11 * (1 + abs(fb)) and abs(q.batch_results[b]['v'] - vb) <= 1e-12, b
+        assert q.batch_results[b]['index'] == q2.best_index, b
+    from qcqp_amd.dist import better_key
+    w = min(range(K), key=lambda b: better_key(serial[b][0], serial[b][1], b))
+    assert abs(f - serial[w][0]) <= 1e-11 * (1 + abs(f)) and abs(v - serial[w][1]) <= 1e-12
+    assert np.max(np.abs(np.array(q.prob.variables()[0].value).ravel() - serial[w][3])) < 1e-12

@@ -7,7 +7,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
+# the driver's step count; warm-up of the same size, so that every launch of the lifecycle kernel in the trace is 20 steps
+CMD="python $ROOT/bench.py --scheme stream --steps 20 --warmup 20 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write --output-format csv -- $CMD > $OUT/write.log 2>&1

@@ -26,7 +26,8 @@ def short(name):
 import datetime
 import subprocess
 
-out = {'tag': tag, 'date': datetime.date.today().isoformat()}
+out = {'tag': tag, 'date': datetime.date.today().isoformat(),
+       'launch': 'one launch of the lifecycle kernel = 20 steps of 4096 restarts (bench.py --scheme stream --steps 20 --warmup 20)'}
 try:
     out['git_commit'] = subprocess.check_output(['git', '-C', REPO, 'rev-parse', '--short', 'HEAD']).decode().strip()
 except Exception:
@@ -99,14 +100,13 @@ bj = os.path.join(src, 'bench_under_profiler.json')
 if os.path.exists(bj) and os.path.getsize(bj):
     out['bench_under_profiler'] = json.load(open(bj))
 hdr = ['# rocprofv3 summary %s' % tag, '',
-       'Command: `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary` (tools/profile_round.sh).',
+       'Command: `python bench.py --scheme stream --steps 20 --warmup 20 --no-cpu-baseline --no-secondary` (tools/profile_round.sh):',
+       'two launches of `cd_phase2_qs_kernel<4, 3>` (the lifecycle mode of the slot-queue kernel), each = 20 steps of 4096 restarts --',
+       'suggest, phase 1, gate, phase 2, objective of 81920 restarts inside the launch.',
        'Pass 1 `--kernel-trace --stats`; passes 2-4 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc TCC_HIT_sum TCC_MISS_sum`',
        '(separate runs, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled (gfx950 reports half the bytes of',
        'wide coalesced reads); WRITE_SIZE is taken as is (uncalibrated).  Pass 5 `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`:',
-       'fraction of the SIMD-cycles of the launch during which the matrix pipe is busy (all MFMAs issued, useful or not).',
-       'The bench overlaps the preparation of step k+1 and the selection of step k with the phase-2 kernel of the other context:',
-       'small kernels of the other stream (select_best, dense_products<2>, cd_phase1) wait for CUs the phase-2 tiles release, and',
-       'the trace counts that wait as their duration.  Phase-2 kernels never overlap each other.', '']
+       'fraction of the SIMD-cycles of the launch during which the matrix pipe is busy (all MFMAs issued, useful or not).', '']
 open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(hdr + lines) + '\n')
 json.dump(out, open(os.path.join(dst, tag + '_summary.json'), 'w'), indent=1, sort_keys=True)
 print('\n'.join(lines))
