@@ -71,7 +71,10 @@ def test_cd_stream_run_equals_serial_runs(eng_mod, orc, n, m_rows, R, K, iters):
             rng.set_restart(fi + r)
             x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
             assert rel(X[:, p * R + r], x) < 1e-9, (p, r)
-            assert o['sweeps1'][p * R + r] == s1[0] and o['visits2'][p * R + r] == s2[1] and o['accepted2'][p * R + r] == s2[2]
+            # (a restart that phase 1 cannot improve any further stops after its first sweep without an update; the reference
+            #  burns all num_iters sweeps on the same point: documented deviation 4)
+            assert o['sweeps1'][p * R + r] == s1[0] or (s1[0] == iters and not o['ran_phase2'][p * R + r])
+            assert o['visits2'][p * R + r] == s2[1] and o['accepted2'][p * R + r] == s2[2]
             assert abs(o['f0'][p * R + r] - prob.eval(0, x)) <= 1e-9 * (1 + abs(prob.eval(0, x)))
             assert abs(o['maxviol'][p * R + r] - prob.max_violation(x)) <= 1e-9
 
