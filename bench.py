@@ -108,44 +108,52 @@ def secondary_records(device, sdr_full=False):
         del e
     except Exception as ex:
         recs.append({'config': 'headline family, 16384 restarts', 'error': repr(ex)})
-    # the headline steps software-pipelined: two contexts (two streams) alternate the steps, each driven by its own host
-    # thread -- the tiles of step k + 1 fill the CUs that the stragglers of step k have left idle, and the host-side
-    # fetch / selection of one step hides behind the kernels of the other.  Same work per step, same results.
+    # the lifecycle kernel in steady state (40 steps of 4096 restarts in one launch) and at the STRONG-SCALING share of the named
+    # configuration: 4096 restarts over 8 GPUs = 512 restarts per GPU and step -- streamed, a step of 512 restarts costs an eighth of
+    # a step of 4096 (the slots never wait for a step to end), where one launch per step is tile-bound (32 tiles on 256 CUs)
     try:
-        import threading
-        n, R, K = 1024, 4096, 40
+        n = 1024
         funcs, _, _ = problems.boolean_least_squares(n, 256, seed=1)
-        engs = [Engine(QCQPForm.from_arrays(funcs), device=device) for _ in range(2)]
-        tot = [0.0, 0.0]
-
-        def worker(w, count, base):
-            for k in range(count):
-                engs[w].randn(R, seed=base + 2 * k + w)
-                out = engs[w].cd_run(phase1=True, seed=base + 2 * k + w)
-                engs[w].select_best(1e-4, want_x=False)
-                tot[w] += float(out['visits2'].sum()) / n
-
-        for w in range(2):
-            worker(w, 2, 700)
-        tot = [0.0, 0.0]
-        for e_ in engs:
-            e_.sync()
+        e = Engine(QCQPForm.from_arrays(funcs), device=device)
+        pts = []
+        for R, K in ((4096, 40), (512, 160)):
+            e.cd_stream_run(K, R, seed=300, seed_stride=1)
+            e.sync()
+            t0 = time.perf_counter()
+            o = e.cd_stream_run(K, R, seed=400, seed_stride=1)
+            e.sync()
+            dt = time.perf_counter() - t0
+            ms = e.kernel_ms(Engine.KERNEL_CD2)
+            sw = float(o['visits2'].sum()) / n
+            pts.append({'restarts_per_step': R, 'steps': K, 'value': sw / dt, 'ms_per_step': 1e3 * dt / K, 'kernel_ms_per_launch': ms,
+                        'kernel_ms_per_step': ms / K, 'achieved': sw * 2.0 * n * n / 1e12 / (ms / 1e3),
+                        'frac': sw * 2.0 * n * n / 1e12 / (ms / 1e3) / FP64_PEAK_TFLOPS})
+        # the same 512-restart steps one launch per step (tile-bound kernel, what rounds 1-3 would run on each of 8 GPUs)
+        e.cd_queue(0)
+        e.randn(512, seed=77)
+        e.cd_run(phase1=True, seed=77)
+        e.sync()
         t0 = time.perf_counter()
-        th = [threading.Thread(target=worker, args=(w, K // 2, 800)) for w in range(2)]
-        for t_ in th:
-            t_.start()
-        for t_ in th:
-            t_.join()
-        for e_ in engs:
-            e_.sync()
-        dt = time.perf_counter() - t0
-        recs.append({'config': 'headline workload, steps software-pipelined over two contexts / streams (4096 restarts per step)',
-                     'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': (tot[0] + tot[1]) / dt, 'unit': 'restart-sweeps/s',
-                     'steps': K, 'ms_per_step': 1e3 * dt / K,
-                     'note': 'not the headline: `value` above runs its steps strictly one after the other'})
-        del engs
+        reps = 6
+        for k in range(reps):
+            e.randn(512, seed=78 + k)
+            e.cd_run(phase1=True, seed=78 + k)
+            e.select_best(1e-4, want_x=False)
+        e.sync()
+        dt1 = (time.perf_counter() - t0) / reps
+        recs.append({'config': 'headline workload through the lifecycle kernel: 40 steps of 4096 restarts in one launch (steady state), and the '
+                               'strong-scaling share of BASELINE.json configs[1] on 8 GPUs -- 512 restarts per GPU and step, 160 steps in one launch',
+                     'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': pts[0]['value'], 'unit': 'restart-sweeps/s',
+                     'kernel': e.last_cd_kernel(), 'by_restarts_per_step': pts,
+                     'one_launch_per_step_512_restarts_ms': 1e3 * dt1,
+                     'note': 'a streamed step of 512 restarts takes %.3f ms against %.3f ms for a step of 4096 (ratio %.2f; 8.0 = perfect strong '
+                             'scaling of the step rate) and against %.2f ms with one launch per step (suggest + improve + selection, tile-bound '
+                             'phase 2: 32 tiles on 256 CUs)' % (pts[1]['ms_per_step'], pts[0]['ms_per_step'], pts[0]['ms_per_step'] / pts[1]['ms_per_step'], 1e3 * dt1),
+                     'roofline': {'bound': 'mfma', 'kernel': 'cd_phase2_qs_kernel<lifecycle>', 'achieved': pts[0]['achieved'], 'peak': FP64_PEAK_TFLOPS,
+                                  'unit': 'TFLOP/s', 'frac': pts[0]['frac'], 'kernel_ms_per_launch': pts[0]['kernel_ms_per_launch']}})
+        del e
     except Exception as ex:
-        recs.append({'config': 'headline workload, pipelined steps', 'error': repr(ex)})
+        recs.append({'config': 'headline workload, streamed steps', 'error': repr(ex)})
     # configs[2]: MAXCUT n = 2000, 8192 Goemans-Williamson samples: x = F xi (MFMA GEMM sampler) + batched evaluation
     try:
         n, S, rk = 2000, 8192, 40
@@ -228,7 +236,8 @@ def secondary_records(device, sdr_full=False):
                      'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': tile_its * flops_it / (kms / 1e3) / 1e12, 'peak': 78.6,
                                   'unit': 'TFLOP/s', 'frac': tile_its * flops_it / (kms / 1e3) / 1e12 / 78.6,
                                   'algorithmic_flops_per_restart_iteration': flops_it,
-                                  'note': 'flops of the lock-step tile iterations (16 restarts per tile until the slowest stops) / kernel time (HIP '
+                                  'achieved_useful': its * flops_it / (kms / 1e3) / 1e12, 'frac_useful': its * flops_it / (kms / 1e3) / 1e12 / 78.6,
+                                  'note': 'frac_useful counts the restart-iterations the reference would run (a restart stops by its own rule); frac the flops of the lock-step tile iterations (16 restarts per tile until the slowest stops) / kernel time (HIP '
                                           'events); the two products stream their A fragments from L2 (512 B per MFMA), the secular solves, the two '
                                           'cluster exchanges per iteration and the bookkeeping are latency, not flops: profiles/r03_admm_summary.md'}})
         # full eigenbasis (what the reference computes: any rank) at n = 512, m = 40: the multi-launch path
@@ -338,6 +347,91 @@ def sdr_record(e, form, n, m):
                              'profiles/r03_cfg5_sdr.md'}
     except Exception as ex:      # a secondary record must never take the headline down
         return {'config': 'configs[4] SDP relaxation (n = %d, m = %d)' % (n, m), 'error': repr(ex)}
+
+
+def secondary_cpu_baselines(cores):
+    """The reference's CPU path beside the SECONDARY records, through the oracle (C restatement in the
+    reference's per-call structure, one core) and, where the survey asks for it, the hoisted-BLAS NumPy form on `cores`
+    threads -- bounded samples of a few seconds each.  Returns {key: cpu_baseline} for the records that start with the key."""
+    from oracle import oracle as orc
+    from qcqp_amd import problems
+    out = {}
+    try:        # configs[2]: the reference evaluates sample by sample (qcqp.py:396-401: f0.eval + m one-coordinate evals)
+        n, S = 2000, 8192
+        funcs, _, _ = problems.maxcut(n, 0.5, seed=1)
+        prob = orc.Problem(funcs)
+        rs = np.random.RandomState(5)
+        X = rs.randn(n, 3)
+        t0 = time.perf_counter()
+        prob.eval_batch(X)
+        dt = (time.perf_counter() - t0) / 3
+        P0 = np.asarray(funcs[0][0].todense() if hasattr(funcs[0][0], 'todense') else funcs[0][0])
+        Xb = rs.randn(n, S)
+        t0 = time.perf_counter()
+        f = np.einsum('ij,ij->j', P0.dot(Xb), Xb)
+        mv = np.max(np.abs(Xb * Xb - 1.0), axis=0)
+        dtb = time.perf_counter() - t0
+        out['BASELINE.json configs[2]'] = {
+            'value': 1.0 / dt, 'unit': 'samples evaluated/s', 'cores': 1, 'kind': 'port',
+            'sample': '3 samples through the oracle (objective + 2000 one-coordinate constraints per sample, the reference\'s per-sample '
+                      'structure; its np.random.multivariate_normal draw -- an SVD of the 2000 x 2000 covariance PER SAMPLE, 2.9 s each, '
+                      'SURVEY.md section 6 -- is not included)',
+            'hoisted_blas': {'value': S / dtb, 'unit': 'samples evaluated/s', 'cores': cores, 'kind': 'port (NumPy: one GEMM P0 X for all samples)',
+                             'sample': '8192 samples, %.2f s' % dtb, 'check': float(f[0] + mv[0])}}
+    except Exception as ex:
+        out['BASELINE.json configs[2]'] = {'error': repr(ex)[:300]}
+    try:        # configs[3]: improve_admm restart-iterations / s / core (full eigenbasis like the reference; exact rank-2 eigenpairs)
+        funcs, _, _ = problems.beamforming(512, 16, 64, seed=1)
+        prob = orc.Problem(funcs)
+        n, m = prob.n, prob.m
+        rs = np.random.RandomState(0)
+        lm = np.zeros((m, n))
+        Q = np.zeros((m, n, n))
+        for k in range(m):      # eigenpairs of a rank-2 matrix in O(n^2): range, 2 x 2 eigenproblem, null space by a complete QR
+            Pk = np.asarray(funcs[k + 1][0])
+            U, _ = np.linalg.qr(Pk.dot(rs.randn(n, 4)))
+            w, V = np.linalg.eigh(U.T.dot(Pk).dot(U))
+            keep = np.argsort(-np.abs(w))[:2]
+            W = U.dot(V[:, keep])
+            Qc, _ = np.linalg.qr(W, mode='complete')
+            vals = np.concatenate([w[keep], np.zeros(n - 2)])
+            vecs = np.concatenate([W, Qc[:, 2:]], axis=1)
+            order = np.argsort(vals, kind='stable')
+            lm[k], Q[k] = vals[order], vecs[:, order]
+        prob._eig = (np.ascontiguousarray(lm), np.ascontiguousarray(Q))
+        x0 = rs.randn(n)
+        t0 = time.perf_counter()
+        prob.improve_admm(x0, num_iters=3, rho=1.0)
+        dt = time.perf_counter() - t0
+        out['BASELINE.json configs[3]'] = {
+            'value': 6.0 / dt, 'unit': 'restart-iterations/s', 'cores': 1, 'kind': 'port',
+            'sample': 'one restart, 3 + 3 iterations of improve_admm through the oracle (80 onecons_qcqp calls of three dense 1024 x 1024 '
+                      'products each per iteration, utilities.py:149-196), %.1f s; the 80 eigendecompositions the reference computes first '
+                      '(about 1 s each) are not included' % dt}
+    except Exception as ex:
+        out['BASELINE.json configs[3]'] = {'error': repr(ex)[:300]}
+    try:        # configs[4] family: get_onevar_func for every function at one coordinate = one coordinate update of the reference
+        n, m = 1024, 32
+        funcs, _, _ = problems.dense_indefinite(n, m, seed=7)
+        prob = orc.Problem(funcs)
+        x = 0.1 * np.random.RandomState(1).randn(n)
+        t0 = time.perf_counter()
+        cnt = 0
+        for c in (3, 500, 1000):
+            for k in range(m + 1):
+                prob.onevar_coeffs(k, x, c)
+                cnt += 1
+        dt = time.perf_counter() - t0
+        per_fc = dt / cnt
+        out['BASELINE.json configs[4]'] = {
+            'value': 1.0 / (per_fc * 257 * 1024), 'unit': 'restart-sweeps/s', 'cores': 1, 'kind': 'port',
+            'per_function_and_coordinate_s': per_fc,
+            'sample': 'get_onevar_func (utilities.py:99-105: a full P z per call) for %d (function, coordinate) pairs of a dense n = 1024 problem through '
+                      'the oracle, %.2f s; a sweep at n = 1024, m = 256 is 257 x 1024 such calls (the interval arithmetic of onevar_qcqp is negligible '
+                      'beside them): extrapolated' % (cnt, dt)}
+    except Exception as ex:
+        out['BASELINE.json configs[4]'] = {'error': repr(ex)[:300]}
+    return out
 
 
 # ------------------------------------------------------------------------------------- CPU baselines
@@ -674,6 +768,15 @@ def main():
             res['secondary'] = secondary_records(local_rank, sdr_full=args.sdr_full)
         if world == 1 and not args.no_cpu_baseline:      # a reported baseline of rank 0 at N = 1 only
             cores = args.cpu_cores or min(effective_cores(), 32)
+            if res.get('secondary'):
+                try:
+                    extra = secondary_cpu_baselines(cores)
+                    for rec in res['secondary']:
+                        for key, val in extra.items():
+                            if str(rec.get('config', '')).startswith(key):
+                                rec['cpu_baseline'] = val
+                except Exception as ex:
+                    sys.stderr.write('bench: CPU baselines of the secondary records failed: %r\n' % (ex,))
             # the winning restart of the winning step again on the CPU: the cross-check of `best`
             wseed = args.seed + best_step
             port, wall_port, opt, wall_opt, win = cpu_baseline(n, args.m_rows, wseed, int(best[0]), cores)

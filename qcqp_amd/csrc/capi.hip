@@ -196,7 +196,7 @@ struct qcqpmi_ctx {
     int64_t chain_R[3] = {0, 0, 0};
     CdLife *d_life = nullptr;    // qcqpmi_cd_stream_run: parameters of the lifecycle launch
     long long *d_life_prof = nullptr;
-    int64_t *d_bestK_idx = nullptr; double *d_bestK_key = nullptr; int64_t bestK_cap = 0;
+    int64_t *d_bestK_idx = nullptr; double *d_bestK_key = nullptr, *d_bestK_x = nullptr; int64_t bestK_cap = 0;
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
     bool force_generic = false;  // debug/tests: run the general phase-2 kernel even when the pipelined one applies
     std::vector<int> last_st1, last_st2;   // per-restart status codes of the last coordinate-descent run (qcqpmi_cd_status)
@@ -776,7 +776,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key, c->d_bestK_x};
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1586,32 +1586,33 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         if (K > c->bestK_cap) {
             if (c->d_bestK_idx) (void)hipFree(c->d_bestK_idx);
             if (c->d_bestK_key) (void)hipFree(c->d_bestK_key);
-            c->d_bestK_idx = nullptr; c->d_bestK_key = nullptr;
+            if (c->d_bestK_x) (void)hipFree(c->d_bestK_x);
+            c->d_bestK_idx = nullptr; c->d_bestK_key = nullptr; c->d_bestK_x = nullptr;
             HIPCHK(c, hipMalloc((void **)&c->d_bestK_idx, (size_t)K * 2 * sizeof(int64_t)));
             HIPCHK(c, hipMalloc((void **)&c->d_bestK_key, (size_t)K * 2 * sizeof(double)));
+            HIPCHK(c, hipMalloc((void **)&c->d_bestK_x, (size_t)K * c->n * sizeof(double)));
             c->bestK_cap = K;
         }
-        for (int64_t p = 0; p < K; p++)
-            hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(1024), 0, c->stream, (const double *)(c->d_f0 + p * R), (const double *)(c->d_mv + p * R),
-                               R, select_tol, c->d_bestK_idx + 2 * p, c->d_bestK_key + 2 * p);
+        // one workgroup per population, then one gather of the winners' columns: three launches and three copies whatever K
+        hipLaunchKernelGGL(select_best_kernel, dim3((unsigned)K), dim3(1024), 0, c->stream, (const double *)c->d_f0, (const double *)c->d_mv,
+                           R, select_tol, c->d_bestK_idx, c->d_bestK_key);
+        if (best_x) {
+            HIPCHK(c, hipMemsetAsync(c->d_bestK_x, 0, (size_t)K * c->n * sizeof(double), c->stream));
+            hipLaunchKernelGGL(gather_best_x_kernel, dim3((unsigned)K), dim3(256), 0, c->stream, (const double *)c->X, c->n, c->n16, R,
+                               (const int64_t *)c->d_bestK_idx, c->d_bestK_x);
+        }
         HIPCHK(c, hipGetLastError());
         std::vector<int64_t> idx((size_t)K * 2);
         std::vector<double> key((size_t)K * 2);
         HIPCHK(c, hipMemcpyAsync(idx.data(), c->d_bestK_idx, idx.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(key.data(), c->d_bestK_key, key.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (best_x) HIPCHK(c, hipMemcpyAsync(best_x, c->d_bestK_x, (size_t)K * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (int64_t p = 0; p < K; p++) {
             if (best_index) best_index[p] = idx[(size_t)2 * p];            // index WITHIN the population
             if (best_f0) best_f0[p] = key[(size_t)2 * p];
             if (best_maxviol) best_maxviol[p] = key[(size_t)2 * p + 1];
-            if (best_x && idx[(size_t)2 * p] >= 0) {
-                const int64_t r = p * R + idx[(size_t)2 * p];
-                const double *src = c->X + (r >> 4) * c->n16 * 16 + (r & 15);
-                HIPCHK(c, hipMemcpy2DAsync(best_x + p * c->n, sizeof(double), src, 16 * sizeof(double), sizeof(double), (size_t)c->n,
-                                           hipMemcpyDeviceToHost, c->stream));
-            }
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return 0;
 }

@@ -305,6 +305,16 @@ __global__ __launch_bounds__(P1_THREADS) void cd_phase1_sep_kernel(CdArgs a) {
     if (slot == 0 && live) a.sweeps[gr] = sweeps_done;
 }
 
+// the winners of K populations (select_best_kernel with grid K: out_idx[2 p] = index within population p) -> out[p][0..n)
+__global__ void gather_best_x_kernel(const double *__restrict__ Xt, int64_t n, int64_t n16, int64_t R, const int64_t *__restrict__ idx,
+                                     double *__restrict__ out) {
+    const int64_t p = blockIdx.x, w = idx[2 * p];
+    if (w < 0) return;
+    const int64_t r = p * R + w;
+    const double *src = Xt + (r >> 4) * n16 * 16 + (r & 15);
+    for (int64_t j = threadIdx.x; j < n; j += blockDim.x) out[p * n + j] = src[j * 16];
+}
+
 // coordinate descent phase 2: cd_phase2.h (general kernel), cd_phase2_rs.h / cd_phase2_q.h (role-split pipelined kernels)
 
 }  // namespace qcqpmi
@@ -330,6 +340,9 @@ __global__ __launch_bounds__(1024) void select_best_kernel(const double *__restr
                                                            int64_t R, double tol,
                                                            int64_t *__restrict__ out_idx,
                                                            double *__restrict__ out_key) {
+    // one workgroup per population: population blockIdx.x is the slice [blockIdx.x R, (blockIdx.x + 1) R) (grid 1: the whole array)
+    f0 += (int64_t)blockIdx.x * R; maxviol += (int64_t)blockIdx.x * R;
+    out_idx += 2 * (int64_t)blockIdx.x; out_key += 2 * (int64_t)blockIdx.x;
     __shared__ long long sb[1024];
     __shared__ double sf[1024];
     __shared__ long long si[1024];
