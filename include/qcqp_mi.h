@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QCQPMI_ABI_VERSION 3
+#define QCQPMI_ABI_VERSION 4
 
 enum {
     QCQPMI_OK = 0,

@@ -98,9 +98,27 @@ def _job_epoch():
     is predictable, so files of a crashed earlier job with a recycled pid must not be read as messages)."""
     if os.environ.get(RDZV_ENV):
         return 0.0                      # uuid key: the directory cannot pre-exist
+    return _proc_start_time(os.getppid()) - 2.0
+
+
+def _proc_start_time(pid):
+    """Start time of a process as seconds since the epoch: field 22 of /proc/<pid>/stat (clock ticks since boot) + btime of
+    /proc/stat.  (The mtime of /proc/<pid> is NOT the start time: Linux stamps the inode when it is first looked up, so ranks
+    that start at different moments would compute different epochs and reject each other's files.)  0.0 if unavailable."""
     try:
-        return os.stat('/proc/%d' % os.getppid()).st_mtime - 2.0
-    except OSError:
+        with open('/proc/%d/stat' % pid) as f:
+            fields = f.read().rsplit(')', 1)[1].split()      # the command name may contain spaces and parentheses
+        ticks = float(fields[19])                            # field 22 overall = index 19 after "pid (comm)"
+        btime = None
+        with open('/proc/stat') as f:
+            for line in f:
+                if line.startswith('btime'):
+                    btime = float(line.split()[1])
+                    break
+        if btime is None:
+            return 0.0
+        return btime + ticks / float(os.sysconf('SC_CLK_TCK'))
+    except (OSError, ValueError, IndexError):
         return 0.0
 
 

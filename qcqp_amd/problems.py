@@ -9,6 +9,7 @@ with the objective first (relop ``None``) -- the raw-array form accepted by
 * ``maxcut``                 -- examples/maxcut.py:9-21
 * ``beamforming``            -- examples/secondary_user_beamforming.py:18-41
 * ``dense_indefinite``       -- SURVEY.md section 8(d) cfg5 generator
+* ``circle_packing``         -- examples/circle_packing.py:6-17 (two variables: centres 2 x N and the radius)
 """
 import numpy as np
 import scipy.sparse as sp
@@ -96,6 +97,45 @@ def dense_indefinite(n, m, seed=7, easy=True):
         funcs.append((sym(), rs.randn(n), r, '<='))
     funcs.append((np.eye(n), np.zeros(n), -float(n), '<='))
     return funcs, False, {}
+
+
+def circle_packing(N, B=10., minimize_form=False):
+    """maximize r  s.t.  r <= X <= B - r, r >= 0, (2r)^2 <= ||X[:, i] - X[:, j]||^2 for i < j
+    (examples/circle_packing.py:6-17: N circles of radius r in the box [0, B]^2).  Two cvxpy variables in the reference --
+    X (2, N) and the scalar r; get_qcqp_form (utilities.py:318-347) stacks them in the order prob.variables() gives them,
+    each flattened COLUMN-major (utilities.py:298-316): here x = [X[0,0], X[1,0], X[0,1], ..., X[1,N-1], r], n = 2 N + 1,
+    var_sizes [(2, N), (1, 1)].  Constraints in the order of the example's list: 2 N of r - X[d, i] <= 0 (column-major),
+    2 N of X[d, i] + r - B <= 0, -r <= 0, then the N (N - 1) / 2 separation constraints 4 r^2 - ||X_i - X_j||^2 <= 0 (sparse,
+    indefinite, five coordinates each).  Returns (funcs, maximize, info): funcs as stated (objective = r, to be maximised;
+    minimize_form=True: already negated, what QCQPForm holds), info['var_sizes']."""
+    import scipy.sparse as sp
+    n = 2 * N + 1
+    ir = 2 * N
+    q0 = np.zeros(n)
+    q0[ir] = -1.0 if minimize_form else 1.0
+    funcs = [(sp.csr_matrix((n, n)), q0, 0.0, None)]
+    Z = sp.csr_matrix((n, n))
+    for j in range(2 * N):                       # X >= r
+        q = np.zeros(n)
+        q[ir], q[j] = 1.0, -1.0
+        funcs.append((Z, q, 0.0, '<='))
+    for j in range(2 * N):                       # X <= B - r
+        q = np.zeros(n)
+        q[ir], q[j] = 1.0, 1.0
+        funcs.append((Z, q, -float(B), '<='))
+    q = np.zeros(n)
+    q[ir] = -1.0
+    funcs.append((Z, q, 0.0, '<='))              # r >= 0
+    for i in range(N):
+        for j in range(i + 1, N):
+            rows, cols, vals = [ir], [ir], [4.0]
+            for d in range(2):
+                a, b = 2 * i + d, 2 * j + d
+                rows += [a, b, a, b]
+                cols += [a, b, b, a]
+                vals += [-1.0, -1.0, 1.0, 1.0]
+            funcs.append((sp.csr_matrix((vals, (rows, cols)), shape=(n, n)), np.zeros(n), 0.0, '<='))
+    return funcs, (not minimize_form), dict(var_sizes=[(2, N), (1, 1)], B=float(B))
 
 
 class GeneratedForm(object):

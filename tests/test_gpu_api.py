@@ -402,3 +402,90 @@ def test_suggest_batches_streams_improve(n):
     w = min(range(K), key=lambda b: better_key(serial[b][0], serial[b][1], b))
     assert abs(f - serial[w][0]) <= 1e-11 * (1 + abs(f)) and abs(v - serial[w][1]) <= 1e-12
     assert np.max(np.abs(np.array(q.prob.variables()[0].value).ravel() - serial[w][3])) < 1e-12
+
+
+def test_circle_packing_two_variables(orc):
+    """The fourth example family of the reference (examples/circle_packing.py:6-17): TWO variables -- the centres X (2, N) and
+    the radius r -- stacked column-major in the order of prob.variables() (assign_vars / flatten_vars, utilities.py:298-316,
+    with the index advanced: SURVEY.md A.3), a linear objective (maximise r), 4 N + 1 linear constraints and N (N - 1) / 2
+    sparse indefinite separation constraints that couple five coordinates each.  (1) phase 2 from the reference's golden start
+    (G6 circle5: the oracle reproduces the reference's own result on this family, tests/test_oracle_golden.py) through
+    Problem(var_sizes=...) and the variables' values: the engine's point against the oracle with the same keyed stream (the
+    objective is identically zero in every centre coordinate: each visit draws a uniform point of the feasible set), shapes
+    and (f, v) with the maximise sign; (2) a population from suggest(RANDOM) through improve(COORD_DESCENT), restart by restart
+    against the oracle; (3) N = 40 (n = 81 > 64: the default dense-constraint path, 941 constraints) by outcome: reported values
+    equal to the oracle's evaluation of the returned points, the reference-order mode value for value."""
+    from qcqp_amd import QCQP, COORD_DESCENT, RANDOM, Problem, problems
+    z = load_golden('g6_cd_circle5')
+    N = 5
+    funcs, maxi, info = problems.circle_packing(N)
+    assert maxi and info['var_sizes'] == [(2, N), (1, 1)]
+    prob = Problem(funcs, maximize=True, var_sizes=info['var_sizes'])
+    assert rel_eq_forms(prob.qcqp_form, funcs_from_npz(z))
+    po = orc.Problem(funcs_from_npz(z))                      # minimise form, as the reference holds it
+    q = QCQP(prob)
+    Xv, rv = prob.variables()
+    x0 = z['X0'][:, 0]
+    Xv.value = x0[:2 * N].reshape((2, N), order='F')
+    rv.value = x0[2 * N:].reshape((1, 1))
+    f, v = q.improve(COORD_DESCENT, phase1=False, seed=11)
+    assert q.engine.last_cd_kernel() == 'cd_general_kernel'
+    rng = orc.Rng(orc.RNG_KEYED, 11)
+    rng.set_restart(0)
+    xo, s1, s2 = po.improve_cd(x0, phase1=False, rng=rng)
+    assert Xv.value.shape == (2, N) and rv.value.shape == (1, 1)
+    xg = np.concatenate([np.ravel(Xv.value, order='F'), np.ravel(rv.value)])
+    assert np.max(np.abs(xg - xo)) <= 1e-9 * (1 + np.max(np.abs(xo)))
+    assert abs(f - float(rv.value[0, 0])) <= 1e-12 and abs(f + po.eval(0, xo)) <= 1e-9      # maximise: f = r
+    assert abs(v - po.max_violation(xo)) <= 1e-9
+    # (2) a population of random starts, phase 1 + phase 2
+    R = 48
+    q.suggest(RANDOM, num_samples=R, seed=3)
+    X0 = q.population()
+    q.improve(COORD_DESCENT, seed=5, num_iters=40)
+    X = q.population()
+    for r in range(0, R, 5):
+        rng = orc.Rng(orc.RNG_KEYED, 5)
+        rng.set_restart(r)
+        xo, s1, s2 = po.improve_cd(X0[:, r], num_iters=40, rng=rng)
+        assert np.max(np.abs(X[:, r] - xo)) <= 1e-9 * (1 + np.max(np.abs(xo))), r
+    best = int(np.argmax(np.where(q.population_v < 1e-2, q.population_f, -np.inf)))
+    assert abs(float(rv.value[0, 0]) - X[2 * N, q.best_index]) <= 1e-12 and q.population_v[q.best_index] < 1e-2
+    assert q.population_f[q.best_index] >= q.population_f[best] - 1e-4 - 1e-9        # better(): violation bucket first
+    # (3) N = 40: the default dense-constraint path by outcome, the reference-order mode value for value
+    N2 = 40
+    funcs2, _, info2 = problems.circle_packing(N2)
+    q2 = QCQP(Problem(funcs2, maximize=True, var_sizes=info2['var_sizes']))
+    po2 = orc.Problem(problems.circle_packing(N2, minimize_form=True)[0])
+    R2 = 16
+    q2.suggest(RANDOM, num_samples=R2, seed=2)
+    Y0 = q2.population()
+    q2.improve(COORD_DESCENT, seed=6, num_iters=3)
+    assert q2.engine.last_cd_kernel().startswith('dense_chain')
+    Y = q2.population()
+    for r in range(R2):
+        assert abs(q2.population_f[r] + po2.eval(0, Y[:, r])) <= 1e-9 * (1 + abs(q2.population_f[r]))
+        assert abs(q2.population_v[r] - po2.max_violation(Y[:, r])) <= 1e-9 * (1 + q2.population_v[r])
+    q2.engine.upload(Y0)
+    q2._resident = False
+    q2.engine.cd_reference_order(True)
+    out = q2.engine.cd_run(phase1=True, num_iters=3, seed=6)
+    Yr = q2.engine.download()
+    assert q2.engine.last_cd_kernel() == 'cd_general_kernel'
+    for r in (0, R2 - 1):
+        rng = orc.Rng(orc.RNG_KEYED, 6)
+        rng.set_restart(r)
+        xo, s1, s2 = po2.improve_cd(Y0[:, r], num_iters=3, rng=rng)
+        assert np.max(np.abs(Yr[:, r] - xo)) <= 1e-9 * (1 + np.max(np.abs(xo))), r
+
+
+def rel_eq_forms(form, funcs):
+    """The QCQPForm a Problem holds equals a raw-array problem (objective first), entry by entry."""
+    fs = [form.f0] + list(form.fs)
+    if len(fs) != len(funcs):
+        return False
+    for f, (P, q, r, relop) in zip(fs, funcs):
+        Pf = np.asarray(f.P.todense()) if hasattr(f.P, 'todense') else np.asarray(f.P)
+        if not (np.array_equal(Pf, np.asarray(P)) and np.array_equal(np.ravel(f.qarray), np.ravel(q)) and f.r == r and f.relop == relop):
+            return False
+    return True

@@ -103,7 +103,7 @@ def test_dense_path_scale_dispatch_vs_oracle(eng_mod, orc, R):
 
     What can be asserted: phase 1 drives every coordinate to a point where the feasible set of the bisection is
     nearly degenerate, so a 1e-13 difference in a tracked f_k (MFMA summation order vs the oracle's sequential
-    sums) is amplified by 1/sqrt(discriminant) per coordinate: tools/dense_diag.py shows half of the restarts
+    sums) is amplified by 1/sqrt(discriminant) per coordinate: the oracle itself (tests/test_host_cpu.py::test_reference_cd_is_chaotic_under_one_ulp) shows a quarter of the restarts
     1e-9 off the oracle after ONE phase-1 sweep and drifting apart from there, for every R and K-split alike.
     Per-restart trajectories are therefore compared as outcomes, not bit patterns: every restart's reported
     values are a fresh evaluation of its point (exact), sampled restarts end in the same feasibility class as

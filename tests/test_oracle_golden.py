@@ -98,7 +98,7 @@ def test_g5_onecons(orc):
         assert np.max(np.abs(x2 - z['x'][i])) <= 1e-7 * (1 + np.max(np.abs(z['x'][i]))), i
 
 
-CD = ['bls10', 'bls32', 'bls64', 'maxcut12', 'dense16', 'dense32']
+CD = ['bls10', 'bls32', 'bls64', 'maxcut12', 'dense16', 'dense32', 'circle5']
 
 
 @pytest.mark.parametrize('name', CD)

@@ -246,8 +246,13 @@ def g6_g7():
         'maxcut12': problems.maxcut(12, 0.5, seed=2),
         'dense16': problems.dense_indefinite(16, 5, seed=7),
         'dense32': problems.dense_indefinite(32, 8, seed=7),
+        # examples/circle_packing.py: two variables (centres 2 x 5, radius), sparse separation constraints; minimise form
+        'circle5': (problems.circle_packing(5, minimize_form=True)[0], True, {}),
     }
+    only = [a_[7:] for a_ in sys.argv[1:] if a_.startswith('--only=')]
     for name, (funcs, maxi, _) in fams.items():
+        if only and name not in only:
+            continue
         prob = ref_prob(funcs)
         n = prob.n
         rs = np.random.RandomState(21)
@@ -255,6 +260,8 @@ def g6_g7():
         # phase 2 from feasible-within-slack starts: x0 = sign*(1+delta)
         if name.startswith('bls') or name.startswith('maxcut'):
             X0 = np.sign(rs.randn(n, R)) * (1 + 2e-5 * rs.rand(n, R))
+        elif name.startswith('circle'):
+            X0 = np.vstack([1.0 + 8.0 * rs.rand(n - 1, R), 0.05 + 0.1 * rs.rand(1, R)])     # centres in the box, a small radius
         else:
             X0 = 0.05 * rs.randn(n, R)
         p2_x, p2_seed = [], []
@@ -397,6 +404,9 @@ def g9_g10():
 
 
 if __name__ == '__main__':
+    if any(a_.startswith('--only=') for a_ in sys.argv[1:]):      # --only=circle5: one family of G6 / G7
+        g6_g7()
+        sys.exit(0)
     g1_g2()
     g3()
     g4()
