@@ -696,7 +696,7 @@ def main():
                       'boundaries; no preparation kernels, no second stream, no CU partition; per step the best point is selected on the device, '
                       'then ONE exchange over the ranks (two all-reduces) for all steps; results per restart do not depend on the scheduling' % K,
             'two': ('two contexts per GPU: suggest + phase 1 + evaluation + gate of step k+1 run in a second stream while the phase-2 kernel of '
-                    'step k finishes; phase-2 kernels never overlap each other') if contexts > 1 else 'none (steps strictly one after the other)'}
+                    'step k finishes; phase-2 kernels never overlap each other') if (scheme == 'stream' or contexts > 1) else 'none (steps strictly one after the other)'}
         res = {
             'metric': 'restarts x coord-sweeps / sec (improve COORD_DESCENT, phase-2 coordinate sweeps of 2 n^2 flops; '
                       'suggest + phase 1 + gate + phase 2 to convergence + selection inside the timed step)',
@@ -761,7 +761,8 @@ def main():
                                                        'timing': 'HIP events around every phase-2 launch (the launches own the chip; preparation and '
                                                                  'selection are outside them)'},
                                           'best': {'objective': b2[1], 'max_violation': b2[2], 'global_restart_index': b2[0], 'step': acc['best_step']},
-                                          'same_best_point_as_stream': bool(same_best), 'step_overlap': overlap_text['two']}}
+                                          'same_best_point_as_stream': bool(same_best), 'contexts': acc['contexts'],
+                                          'step_overlap': overlap_text['two'] if acc['contexts'] > 1 else 'none (steps strictly one after the other)'}}
             except Exception as ex:
                 res['schemes'] = {'reported': 'stream', 'two': {'error': repr(ex)[:400]}}
         if world == 1 and not args.no_secondary:

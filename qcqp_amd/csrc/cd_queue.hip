@@ -93,6 +93,18 @@ __device__ inline double qs_wave_max(double v) {
 __device__ __attribute__((noinline)) double qs_keyed_normal(uint64_t seed, uint64_t restart, uint64_t elem) {
     return keyed_normal(seed, restart, elem);
 }
+// the normals of the element pair (elem, elem + 1), elem even: keyed_normal's own expressions (philox.h) -- the two share the
+// counter block elem >> 1, the radius and the angle; the even element takes the cosine, the odd one the sine -- evaluated once
+__device__ __attribute__((noinline)) double qs_keyed_normal_pair(uint64_t seed, uint64_t restart, uint64_t elem, double *odd) {
+    const U4 o = philox4x32_10((uint32_t)(elem >> 1), (uint32_t)(elem >> 33), 0xA5A50000u, (uint32_t)restart, (uint32_t)seed,
+                               (uint32_t)(seed >> 32) ^ (uint32_t)(restart >> 32));
+    const double u1 = (((double)(o.x >> 5) * 67108864.0 + (double)(o.y >> 6)) + 0.5) / 9007199254740992.0;
+    const double u2 = u53(o.z, o.w);
+    const double rad = sqrt(-2.0 * log(u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
+    *odd = rad * sin(ang);
+    return rad * cos(ang);
+}
 // one phase-1 visit of coordinate i (value x) of a problem whose coordinates all carry the one constraint (p, q, r, relop);
 // returns the new value, *flags: bit 0 moved, bits 8.. = -status; *vafter: the constraint's violation afterwards
 __device__ __attribute__((noinline)) double qs_p1_visit(double p, double q, double r, int relop, int64_t i, double x, double tol,
@@ -293,13 +305,19 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                 }
                 if (lf_generate) {
                     const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
-                    for (int64_t j = tid; j < n16; j += 512) Xs[j * 16 + c] = (j < P.n) ? qs_keyed_normal(sd, gidx, (uint64_t)j) : 0.0;
+                    for (int64_t j = 2 * (int64_t)tid; j < n16; j += 1024) {      // n is a multiple of 16 here: pairs never straddle n
+                        double xo = 0.0;
+                        const double xe = (j < P.n) ? qs_keyed_normal_pair(sd, gidx, (uint64_t)j, &xo) : 0.0;
+                        Xs[j * 16 + c] = xe;
+                        Xs[(j + 1) * 16 + c] = xo;
+                    }
                 } else {
                     QG const double *src = qs_g(a0.b[0].X) + ((int64_t)(sid[c] >> 4) * n16) * 16 + (sid[c] & 15);
                     for (int64_t j = tid; j < n16; j += 512) Xs[j * 16 + c] = src[j * 16];
                 }
             }
             __syncthreads();
+            if (lf->prof && tid == 0) atomicAdd((unsigned long long *)lf->prof + 4, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pt0));
             if (lf_phase1) {
                 for (int64_t t = 0; t < a.num_iters; t++) {
                     if (tid == 0) { int cnt = 0; for (int k = 0; k < 16; k++) cnt += (snew[k] && !p1fin[k]) ? 1 : 0; ctl[4] = cnt; }

@@ -17,6 +17,7 @@ def main():
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     iters = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+    cs = int(sys.argv[5]) if len(sys.argv) > 5 else -1      # experiments: blocks of the contraction the chain wave multiplies (default 4)
     funcs, _, _ = problems.boolean_least_squares(n, max(4, n // 4), seed=1)
     form = QCQPForm.from_arrays(funcs)
     e = Engine(form)
@@ -27,6 +28,8 @@ def main():
         out = e.cd_run(phase1=True, num_iters=iters, seed=seed0 + p, first_index=first0 + p * fstride)
         ref.append((e.download(), out, e.select_best(), e.last_cd_kernel()))
     es = Engine(form)
+    if cs >= 0:
+        es.L.qcqpmi_debug_profile(es.h, (128 | (cs << 8)) << 4, None)
     for rep in range(3):
         t0 = time.perf_counter()
         o = es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
@@ -36,13 +39,13 @@ def main():
         print('stream run %d: wall %.2f ms, kernel %.3f ms, %.3e restart-sweeps/s (kernel), frac %.3f; per population %.3f ms' % (
             rep, 1e3 * dt, ms, sweeps / (ms * 1e-3), sweeps * 2.0 * n * n / (ms * 1e-3) / 78.6e12, ms / K))
     import ctypes as C
-    es.L.qcqpmi_debug_profile(es.h, 1, None)
+    es.L.qcqpmi_debug_profile(es.h, 1 | (((128 | (cs << 8)) << 4) if cs >= 0 else 0), None)
     o2 = es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
     pr = np.zeros(8, dtype=np.int64)
     es.L.qcqpmi_debug_life_profile(es.h, pr.ctypes.data_as(C.POINTER(C.c_int64)))
-    es.L.qcqpmi_debug_profile(es.h, 0, None)
-    print('profile: column build %.1f %% of the workgroups\' time; %d episodes, %d columns, %.1f us per column built, %.1f us per episode' % (
-        100.0 * pr[0] / max(pr[1], 1), pr[2], pr[3], pr[0] / 100.0 / max(pr[3], 1), pr[0] / 100.0 / max(pr[2], 1)))
+    es.L.qcqpmi_debug_profile(es.h, ((128 | (cs << 8)) << 4) if cs >= 0 else 0, None)
+    print('profile: column build %.1f %% of the workgroups\' time (normals %.1f %%); %d episodes, %d columns' % (
+        100.0 * pr[0] / max(pr[1], 1), 100.0 * pr[4] / max(pr[1], 1), pr[2], pr[3]))
     X = es.download()
     print('kernels:', ref[0][3], '/', es.last_cd_kernel())
     worst = 0.0
