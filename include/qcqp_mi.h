@@ -260,49 +260,14 @@ const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *ctx);
  * restart that is done (qcqp.py:172-176, or num_iters sweeps) is written out at the next sweep boundary and its slot takes the
  * next restart from a device-side queue (cd_phase2_qs_kernel, csrc/cd_queue.hip).  Per restart the same arithmetic; results
  * do not depend on the scheduling (every product is summed in one association).  qcqpmi_last_cd_kernel names the kernel. */
-int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);     /* 0 off, 1 on wherever it applies, 2 (default) auto: more tiles than CUs, or chained */
-/* Chain contexts of the same problem on one GPU (the staged run above, bench.py): the phase-2 launch of `ctx` (stage 2) may
- * also run restarts of the NEXT populations of up to three other contexts -- pos = 1: the population that follows ctx's own,
- * pos = 2: the one after that, pos = 3 -- which those contexts prepare in their own streams (stage 1: suggest, phase 1,
- * evaluation, gate; a population is published to the running kernels when its stage 1 has executed), once the queues before
- * them are empty: the matrix pipes do not idle while the last restarts of a population converge (4096 restarts are one tile
- * per CU: a launch lasts as long as its slowest restart, the average one needs half).  next_R / next_seed /
- * next_first_index: size, seed and first global index `next` passes to its stage 1 / 2 calls for that population (they key
- * the random draws of restarts that are run ahead).  A population is complete when its own launch and the launches that
- * could run its restarts are: stage 3 waits for all of them.  next = NULL ends the chain at pos. */
-int qcqpmi_cd_chain(qcqpmi_ctx *ctx, int pos, qcqpmi_ctx *next, int64_t next_R, uint64_t next_seed, uint64_t next_first_index);
-/* Confine the slot-queue launches of this context to `phase2_cus` compute units (a stream with a CU mask; 0 = whole chip):
- * its workgroups are persistent and hold a CU each (LDS), so with chained contexts the kernels that prepare the next
- * populations would otherwise find no free CU until workgroups run out of work. */
-int qcqpmi_cd_partition(qcqpmi_ctx *ctx, int phase2_cus);
-/* Ring mode: ONE persistent slot-queue launch (on `phase2_cus` CUs; 0 = all) serves the populations of 2..8 contexts of the
- * same problem in turn -- population j of a run lives in member j mod count -- until qcqpmi_cd_ring_stop: no launch per
- * step, no exposed tail between steps (a slot whose restart is done takes the next restart of whatever population is
- * published), and the kernels that prepare populations always find the remaining CUs free.  Every member must hold a
- * resident population of the final size and have run one ordinary qcqpmi_cd_run before (all buffers exist: nothing may be
- * allocated or freed on the device while the launch is resident).
- *   qcqpmi_cd_ring_submit   phase 1 + evaluation + gate of the member's resident population on its own stream, then the
- *                            population is published to the launch (asynchronous)
- *   qcqpmi_cd_ring_collect  waits until every restart of that population is done, returns what qcqpmi_cd_run returns
- * Per restart the results are those of qcqpmi_cd_run (they do not depend on the scheduling).
- * Requirements (measured, profiles/r03_queue_chain_ring.md): the process must have started the HIP runtime with
- * GPU_MAX_HW_QUEUES > 4 (with the default a member's stream shares a hardware queue with the persistent launch and its
- * kernels never run); phase2_cus must be 0 or a multiple of 32 -- whole words of the CU mask: 192 or 224 of 256 -- and is
- * verified with a probe kernel (the same number of CUs on every XCD, a free CU in every shader array), else
- * QCQPMI_EUNSUPPORTED.  The headline step of bench.py runs in 2.7 ms this way (two contexts with a launch per step: 3.4 ms). */
-int qcqpmi_cd_ring_start(qcqpmi_ctx **members, int count, int phase2_cus, int64_t num_iters, double tol);
-int qcqpmi_cd_ring_submit(qcqpmi_ctx *member, int phase1, int64_t num_iters, double viol_tol, double tol, uint64_t seed,
-                          uint64_t first_index);
-int qcqpmi_cd_ring_collect(qcqpmi_ctx *member, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
-                           uint8_t *ran_phase2, double *f0, double *maxviol);
-int qcqpmi_cd_ring_stop(qcqpmi_ctx *owner);      /* owner = members[0] */
+int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);     /* 0 off, 1 on wherever it applies, 2 (default) auto: more tiles than CUs */
+/* (ABI 4 removed the round-3 experiments around that kernel -- qcqpmi_cd_chain, qcqpmi_cd_partition, qcqpmi_cd_ring_start /
+ * submit / collect / stop: launches that ran restarts of other contexts' populations, a CU-masked stream, one persistent
+ * spin-waiting launch for several contexts.  They needed GPU_MAX_HW_QUEUES > 4, worked on the 192-CU partition only and could
+ * stall; qcqpmi_cd_stream_run below does what they were after inside ONE self-contained launch.) */
 /* debug (after qcqpmi_debug_profile enabled profiling): tick sums (s_memtime, 100 MHz) over the workgroups of the last
- * qcqpmi_cd_stream_run launch -- [0] column build (suggest + phase 1 + gate), [1] whole launch, [2] episodes, [3] columns built */
+ * qcqpmi_cd_stream_run launch -- [0] column build (suggest + phase 1 + gate), [1] whole launch, [2] episodes, [3] columns built, [4] the normals' share of [0] */
 int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out8);
-/* debug: the 9 queue-state words of the context's population (see csrc/cd_queue.h) and hipStreamQuery of the ring's launch */
-int qcqpmi_debug_cd_ring_state(qcqpmi_ctx *ctx, int64_t *out10);
-/* statistics: restarts of this context's populations that were run by the launches of the context chained to it (total) */
-int qcqpmi_debug_cd_pulled(qcqpmi_ctx *ctx, int64_t *out);
 /* POPULATION STREAMING (round 4) -- the reference's user loop `for ...: suggest(); improve(COORD_DESCENT)` (README.md:51-57)
  * for K populations of R restarts in ONE persistent launch: a workgroup owns 16 restart slots; a slot that becomes free draws
  * the next restart index of the run and runs that restart's WHOLE step itself -- suggest(RANDOM) (qcqp.py:381-382; the keyed

@@ -67,14 +67,6 @@ PROTOTYPES = [
     ('qcqpmi_cd_stream_run', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
                                        C.c_uint64, C.c_uint64, C.c_double, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp]),
     ('qcqpmi_cd_queue', C.c_int, [C.c_void_p, C.c_int]),
-    ('qcqpmi_cd_ring_start', C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_double]),
-    ('qcqpmi_cd_ring_submit', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64]),
-    ('qcqpmi_cd_ring_collect', C.c_int, [C.c_void_p, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp]),
-    ('qcqpmi_cd_ring_stop', C.c_int, [C.c_void_p]),
-    ('qcqpmi_debug_cd_ring_state', C.c_int, [C.c_void_p, c_ip]),
-    ('qcqpmi_debug_cd_pulled', C.c_int, [C.c_void_p, c_ip]),
-    ('qcqpmi_cd_partition', C.c_int, [C.c_void_p, C.c_int]),
-    ('qcqpmi_cd_chain', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]),
     ('qcqpmi_sync', C.c_int, [C.c_void_p]),
     ('qcqpmi_debug_profile', C.c_int, [C.c_void_p, C.c_int, c_ip]),
     ('qcqpmi_debug_admm_profile', C.c_int, [C.c_void_p, c_ip]),

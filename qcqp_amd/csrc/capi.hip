@@ -12,7 +12,6 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include <set>
 
 #include "../../include/qcqp_mi.h"
 #include "kernels.hip"
@@ -175,25 +174,9 @@ struct qcqpmi_ctx {
     int last_admm_C = 0;                  // workgroups per tile of the last fused run
     long long af_prof[16] = {0};          // stage cycle counters of the last fused run (when qcqpmi_debug_profile enabled them)
     int cd_queue = 2;                     // qcqpmi_cd_queue: 0 off, 1 restart-level scheduling (cd_phase2_qs_kernel) wherever it applies,
-                                          // 2 auto: when there are more tiles than CUs, or the context is chained to another one
-    int *d_qnext = nullptr;               // [0] queue head, [1] generation of the population that is ready to be consumed
-    int qgen = 0;                         // generation of the resident population (stage 1 of a run publishes it)
-    qcqpmi_ctx *chain_nx[3] = {nullptr, nullptr, nullptr};   // qcqpmi_cd_chain: the phase-2 launch of this context may run restarts of the NEXT
-                                          // populations of these contexts (in this order) once its own queue is empty
-    qcqpmi_ctx *chained_by[3] = {nullptr, nullptr, nullptr}; // ... and the contexts whose launches may have run restarts of this one's population
-    hipEvent_t ev_p2 = nullptr;           // recorded after this context's phase-2 launch
-    bool q_prepared = false;              // the queue of the resident population has been reset and published
-    // ring mode (qcqpmi_cd_ring_*): ONE persistent slot-queue launch serves the populations of up to four contexts in turn
-    qcqpmi_ctx *ring_owner = nullptr;     // the context that holds the launch (member 0); set on every member
-    std::vector<qcqpmi_ctx *> ring_members;   // owner only
-    int *d_rctl = nullptr;                // owner only: [0] quit
-    hipStream_t ring_stream = nullptr;    // owner only: the (CU-masked) stream of the persistent launch
-    bool ring_running = false;
-    int p2_cus = 0;                       // qcqpmi_cd_partition: CUs the slot-queue launches are confined to (0: no partition)
-    hipStream_t stream_p2 = nullptr;      // ... the stream with that CU mask
-    hipEvent_t ev_prep = nullptr;         // "everything phase 2 needs has been enqueued on the main stream"
-    uint64_t chain_seed[3] = {0, 0, 0}, chain_first[3] = {0, 0, 0};   // seed / first index / size of those populations (qcqpmi_cd_chain)
-    int64_t chain_R[3] = {0, 0, 0};
+                                          // 2 auto: when there are more tiles than CUs
+    int *d_qnext = nullptr;               // [0] queue head of the slot-queue kernel
+    bool q_prepared = false;              // the queue of the resident population has been reset
     CdLife *d_life = nullptr;    // qcqpmi_cd_stream_run: parameters of the lifecycle launch
     long long *d_life_prof = nullptr;
     int64_t *d_bestK_idx = nullptr; double *d_bestK_key = nullptr, *d_bestK_x = nullptr; int64_t bestK_cap = 0;
@@ -260,8 +243,6 @@ int pop_reserve(qcqpmi_ctx *c, int64_t R) {
     int64_t Rpad = (R + 15) / 16 * 16;
     if (Rpad > c->Rcap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (qcqpmi_ctx *pb : c->chained_by) if (pb && pb->ev_p2) HIPCHK(c, hipEventSynchronize(pb->ev_p2));   // a launch may hold these buffers
-        c->qgen += 2;      // ... and no launch that expected the next generation in the old buffers will ever see it published
         free_population(c);
         int rc = 0;
         size_t xe = (size_t)Rpad * (size_t)c->n16;
@@ -433,17 +414,6 @@ int launch_eval(qcqpmi_ctx *c, bool want_F) {
     return 0;
 }
 
-// ring mode: everything a running launch needs to know about the population, then (last) its generation number
-__global__ void cd_ring_publish_kernel(int *q, int gen, int R, unsigned long long seed, unsigned long long first) {
-    q[0] = 0; q[3] = 0; q[4] = R;
-    q[5] = (int)(unsigned)(seed & 0xffffffffull); q[6] = (int)(unsigned)(seed >> 32);
-    q[7] = (int)(unsigned)(first & 0xffffffffull); q[8] = (int)(unsigned)(first >> 32);
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    __hip_atomic_store(q + 1, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ void cd_queue_publish_kernel(int *q, int gen) { q[0] = 0; __hip_atomic_store(q + 1, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // does phase 2 of the resident population go through the slot-queue kernel?
 bool cd_queue_eligible(qcqpmi_ctx *c, bool profiling) {      // the problem's shape and the context's switches allow the kernel
     if (profiling || c->force_generic || (c->dbg & 64) || !c->sep || c->maxc > 1 || c->cd_queue == 0) return false;
@@ -456,7 +426,7 @@ bool cd_queue_applies(qcqpmi_ctx *c, bool profiling) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) return false;
     if (c->cd_queue == 1) return true;
-    if (c->cd_queue == 2) return c->Rpad / 16 > cus || c->chain_nx[0] != nullptr || c->chained_by[0] != nullptr || c->chained_by[1] != nullptr || c->chained_by[2] != nullptr;
+    if (c->cd_queue == 2) return c->Rpad / 16 > cus;
     return false;
 }
 
@@ -468,9 +438,7 @@ int cd_queue_prepare(qcqpmi_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_sweeps, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, (size_t)c->Rpad * sizeof(int), c->stream));
-    c->qgen++;
-    hipLaunchKernelGGL(cd_queue_publish_kernel, dim3(1), dim3(1), 0, c->stream, c->d_qnext, c->qgen);
-    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(c->d_qnext, 0, 16 * sizeof(int), c->stream));
     c->q_prepared = true;
     return 0;
 }
@@ -478,7 +446,7 @@ int cd_queue_prepare(qcqpmi_ctx *c) {
 void cd_queue_fill_batch(qcqpmi_ctx *c, CdBatch &B, uint64_t seed, uint64_t first_index) {
     B.X = c->X; B.f0cur = c->d_f0; B.slack = c->d_mv; B.flag = c->d_flag; B.visits = c->d_visits; B.accepted = c->d_acc;
     B.sweeps = c->d_sweeps; B.status = c->d_status; B.f0out = c->d_f0; B.mvout = c->d_mv; B.R = c->R; B.seed = seed;
-    B.first_index = first_index; B.next = c->d_qnext; B.ready = nullptr; B.ready_gen = 0;
+    B.first_index = first_index; B.next = c->d_qnext;
 }
 
 template <int MAXC>
@@ -506,58 +474,21 @@ int launch_cd(qcqpmi_ctx *c, const CdArgs &a1, bool phase1, bool &used_lds, bool
         if (cs >= NBq) cs = 0;
         cs &= ~1;
         if (cd_queue_applies(c, a1.prof != nullptr) && NBq - cs <= RQ_NSIMD * RQ_MAXU && NBq >= 3) {
-            // restart-level scheduling (cd_queue.h): 16 slots per workgroup, refilled from a device-side queue -- of this
-            // population and, when the context is chained, of the next population of the other context once that is ready
+            // restart-level scheduling (cd_queue.h): 16 slots per workgroup, refilled from a device-side queue
             used_lds = true;
             int rcq;
             if (!c->q_prepared && (rcq = cd_queue_prepare(c))) return rcq;
             c->q_prepared = false;
             CdQueueArgs qa;
-            qa.P = dp; qa.nb = 1; qa.num_iters = a1.num_iters; qa.tol = a1.tol; qa.ring = 0; qa.rctl = nullptr; qa.ring_limit = 0; qa.life = nullptr; qa.life_on = 0;
-            cd_queue_fill_batch(c, qa.b[0], a1.seed, a1.first_index);
-            for (int q = 1; q < CDQ_MAXB; q++) { qa.b[q] = qa.b[0]; qa.b[q].R = 0; }
-            for (int q = 0; q < 3; q++) {
-                qcqpmi_ctx *nx = c->chain_nx[q];
-                const int64_t nR = nx ? (c->chain_R[q] > 0 ? c->chain_R[q] : nx->R) : 0;
-                if (!(nx && nx != c && nx->finalized && nx->X && nx->n == c->n && nx->device == c->device && nx->R > 0 &&
-                      cd_queue_eligible(nx, nx->profile) && (nR + 15) / 16 * 16 <= nx->Rcap)) break;     // the chain ends at the first gap
-                if (!nx->d_qnext) { if ((rcq = dev_alloc(nx, &nx->d_qnext, 16))) return fail(c, rcq, "cd chain: %s", nx->err.c_str()); HIPCHK(c, hipStreamSynchronize(nx->stream)); }
-                // the NEXT population of that context: same buffers (a context keeps them), seed / first index as the caller
-                // announced them with qcqpmi_cd_chain, generation = the one it has published already (prepared ahead) or the one
-                // its next stage 1 will publish
-                CdBatch &B = qa.b[q + 1];
-                cd_queue_fill_batch(nx, B, c->chain_seed[q], c->chain_first[q]);
-                B.R = nR;
-                B.ready = nx->d_qnext + 1;
-                B.ready_gen = nx->q_prepared ? nx->qgen : nx->qgen + 1;
-                qa.nb = q + 2;
-                bool known = false;
-                for (qcqpmi_ctx *pb : nx->chained_by) known = known || pb == c;
-                if (!known) {
-                    for (auto &pb : nx->chained_by) if (!pb) { pb = c; known = true; break; }
-                    if (!known) { qa.nb = q + 1; break; }      // more than three launches would have to be waited for: not chained
-                }
-            }
+            qa.P = dp; qa.num_iters = a1.num_iters; qa.tol = a1.tol; qa.life = nullptr; qa.life_on = 0;
+            cd_queue_fill_batch(c, qa.b, a1.seed, a1.first_index);
             int cus = 0;
             HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-            if (!c->ev_p2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_p2, hipEventDisableTiming));
-            hipStream_t ls = c->stream;
-            if (c->p2_cus > 0 && c->stream_p2) {
-                // partitioned chip: the persistent workgroups of phase 2 stay on `p2_cus` CUs (stream with a CU mask), the
-                // other CUs are always free for the kernels that prepare the next populations (phase 1, evaluation, ...)
-                if (!c->ev_prep) HIPCHK(c, hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
-                HIPCHK(c, hipEventRecord(c->ev_prep, c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->stream_p2, c->ev_prep, 0));
-                ls = c->stream_p2;
-                cus = c->p2_cus;
-            }
-            (void)hipEventRecord(c->timers[2].beg, ls);
-            hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, ls);
-            (void)hipEventRecord(c->timers[2].end, ls);
+            (void)hipEventRecord(c->timers[2].beg, c->stream);
+            hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, c->stream);
+            (void)hipEventRecord(c->timers[2].end, c->stream);
             c->timers[2].valid = true;
             if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_queue_launch: %s", hipGetErrorString(qe));
-            HIPCHK(c, hipEventRecord(c->ev_p2, ls));
-            if (ls != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_p2, 0));    // results are fetched on the main stream
             c->last_cd2_kernel = "cd_phase2_qs_kernel";
             if (used_rs) *used_rs = true;
             return 0;
@@ -761,17 +692,6 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->comm);
-    if (c->ring_running) (void)qcqpmi_cd_ring_stop(c);
-    if (c->ring_owner && c->ring_owner != c) (void)qcqpmi_cd_ring_stop(c->ring_owner);
-    if (c->ring_stream) (void)hipStreamDestroy(c->ring_stream);
-    if (c->d_rctl) (void)hipFree(c->d_rctl);
-    if (c->dn_tmp) (void)hipFree(c->dn_tmp);
-    if (c->dn_gp_pre) (void)hipFree(c->dn_gp_pre);      // (handed to prob_allocs by finalize: nullptr by then)
-    if (c->stream_p2) { (void)hipStreamSynchronize(c->stream_p2); (void)hipStreamDestroy(c->stream_p2); }
-    if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
-    if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
-    for (qcqpmi_ctx *nx : c->chain_nx) if (nx) for (auto &pb : nx->chained_by) if (pb == c) pb = nullptr;
-    for (qcqpmi_ctx *pb : c->chained_by) if (pb) for (auto &nx : pb->chain_nx) if (nx == c) nx = nullptr;
     free_population(c);
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
@@ -1485,28 +1405,9 @@ int qcqpmi_cd_run_stage(qcqpmi_ctx *c, int stage, int phase1, int64_t num_iters,
         if (stage == 2) { c->cd_stage = 2; return 0; }
     }
     c->cd_stage = 0;
-    for (qcqpmi_ctx *pb : c->chained_by) {
-        // another context's launch may have run restarts of this population: its results are complete only when that
-        // kernel is (its stores are visible once its completion has been observed)
-        if (pb && pb->ev_p2) HIPCHK(c, hipEventSynchronize(pb->ev_p2));
-    }
     std::vector<int> st, st1;
     if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
     if ((rc = cd_apply_status(c, st, st1, f0, maxviol, 0))) return rc;
-    return 0;
-}
-
-int qcqpmi_cd_chain(qcqpmi_ctx *c, int pos, qcqpmi_ctx *next, int64_t next_R, uint64_t next_seed, uint64_t next_first_index) {
-    if (!c || pos < 1 || pos > 3) return QCQPMI_EINVAL;
-    const int q = pos - 1;
-    qcqpmi_ctx *old = c->chain_nx[q];
-    c->chain_nx[q] = next;
-    if (old && old != next) {
-        bool still = false;
-        for (qcqpmi_ctx *nx : c->chain_nx) still = still || nx == old;
-        if (!still) for (auto &pb : old->chained_by) if (pb == c) pb = nullptr;
-    }
-    c->chain_R[q] = next_R; c->chain_seed[q] = next_seed; c->chain_first[q] = next_first_index;
     return 0;
 }
 
@@ -1563,11 +1464,10 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     HIPCHK(c, hipMemcpyAsync(c->d_life, &L, sizeof(L), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));       // (L lives on this stack frame)
     CdQueueArgs qa;
-    qa.P = c->dp; qa.nb = 1; qa.num_iters = num_iters; qa.tol = tol; qa.ring = 0; qa.rctl = nullptr; qa.ring_limit = 0;
+    qa.P = c->dp; qa.num_iters = num_iters; qa.tol = tol;
     qa.life = c->d_life; qa.life_on = 1;
-    cd_queue_fill_batch(c, qa.b[0], seed, first_index);
-    qa.b[0].R = K * R;
-    for (int q = 1; q < CDQ_MAXB; q++) { qa.b[q] = qa.b[0]; qa.b[q].R = 0; }
+    cd_queue_fill_batch(c, qa.b, seed, first_index);
+    qa.b.R = K * R;
     int cus = 0;
     HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     (void)hipEventRecord(c->timers[2].beg, c->stream);
@@ -1666,277 +1566,6 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 }
 
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
-
-// ---- ring mode: one persistent launch for the populations of up to four contexts --------------------------------------
-// ---- CU masks (hipExtStreamCreateWithCUMask).  Measured (tools/ubench/cumask2.hip): the bits of the mask do NOT map evenly
-// to the 8 XCDs -- "the first k bits" gives every XCD k / 8 CUs only when k is a multiple of 32 (192: 24 each, 224: 28 each;
-// 208: 25 24 25 26 24 24 25 24), and a persistent launch of k workgroups that need a CU each is dealt k / 8 workgroups per
-// XCD: with an uneven mask some of them never become resident.  Other partition sizes are therefore built bit by bit under
-// the eyes of a probe kernel that reports which CUs a masked stream really reaches.
-__global__ void cu_probe_kernel(unsigned *out, long long ticks) {
-    extern __shared__ double probe_lds[];
-    unsigned xcc, hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    if (threadIdx.x == 0) {
-        probe_lds[0] = 1.0;
-        out[2 * blockIdx.x] = xcc & 0xf; out[2 * blockIdx.x + 1] = (hw >> 8) & 0xfff;      // CU id [11:8], SH [12], SE [15:13]
-        const long long t0 = (long long)wall_clock64();
-        while ((long long)wall_clock64() - t0 < ticks) {}                                  // hold the CU: the other workgroups must go elsewhere
-    }
-}
-
-// CUs per XCD a stream with this mask reaches (256 probe workgroups of 150 KB LDS: one per CU at a time)
-static int cu_mask_probe(qcqpmi_ctx *c, const std::vector<uint32_t> &mask, unsigned *d_out, int per_xcc[8], std::set<unsigned> *ids = nullptr) {
-    hipStream_t s = nullptr;
-    if (mask.empty()) HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));      // no mask: every CU
-    else HIPCHK(c, hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
-    int khz = 0;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
-    const int wgs = 256;
-    hipError_t e = hipFuncSetAttribute((const void *)cu_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(cu_probe_kernel, dim3(wgs), dim3(64), 150 * 1024, s, d_out, (long long)khz / 2);      // 0.5 ms each
-        e = hipStreamSynchronize(s);
-    }
-    std::vector<unsigned> h((size_t)wgs * 2);
-    if (e == hipSuccess) e = hipMemcpy(h.data(), d_out, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
-    (void)hipStreamDestroy(s);
-    if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "CU mask probe: %s", hipGetErrorString(e));
-    std::set<unsigned> seen[8];
-    for (int i = 0; i < wgs; i++) seen[h[2 * i] & 7].insert(h[2 * i + 1]);
-    for (int x = 0; x < 8; x++) per_xcc[x] = (int)seen[x].size();
-    if (ids) for (int x = 0; x < 8; x++) ids[x] = seen[x];
-    return 0;
-}
-
-// a mask that reaches exactly cus / 8 CUs of every XCD (cus a multiple of 8)
-static int cu_mask_balanced(qcqpmi_ctx *c, int cus_total, int cus, std::vector<uint32_t> &mask) {
-    const int words = (cus_total + 31) / 32, target = cus / 8;
-    mask.assign((size_t)words, 0u);
-    if (cus % 8 != 0 || target < 1) return fail(c, QCQPMI_EINVAL, "CU partition of %d CUs: not a multiple of 8", cus);
-    const int base = cus / 32 * 32;
-    for (int i = 0; i < base; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
-    unsigned *d_out = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_out, 512 * sizeof(unsigned)));
-    int per[8], rc = 0;
-    // a precaution: every shader array (HW_ID: SE [15:13], SH [12]) keeps a CU outside the partition, in case workgroups of the
-    // other streams are dealt to the arrays in turn.  (It is NOT what makes partitions other than 192 / 224 stall: masks built
-    // under this rule stall as well.)
-    std::set<unsigned> all[8], in[8];
-    if ((rc = cu_mask_probe(c, std::vector<uint32_t>(), d_out, per, all))) { (void)hipFree(d_out); return rc; }
-    auto arrays_ok = [&](const std::set<unsigned> (&m)[8]) {
-        for (int x = 0; x < 8; x++) {
-            int tot[16] = {0}, used[16] = {0};
-            for (unsigned id : all[x]) tot[(id >> 4) & 15]++;
-            for (unsigned id : m[x]) used[(id >> 4) & 15]++;
-            for (int a = 0; a < 16; a++) if (tot[a] > 0 && used[a] >= tot[a]) return false;
-        }
-        return true;
-    };
-    if (cus == base) {
-        // whole words are even on the devices measured; checked all the same (which CUs are fused off differs from chip to chip)
-        rc = cu_mask_probe(c, mask, d_out, per, in);
-        (void)hipFree(d_out);
-        if (rc) return rc;
-        if (!arrays_ok(in)) return fail(c, QCQPMI_EUNSUPPORTED, "the first %d bits of the CU mask take every CU of a shader array on this device", cus);
-        for (int x = 0; x < 8; x++)
-            if (per[x] != target)
-                return fail(c, QCQPMI_EUNSUPPORTED, "the first %d bits of the CU mask reach %d %d %d %d %d %d %d %d CUs of the XCDs on this device, "
-                            "not %d each", cus, per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7], target);
-        return 0;
-    }
-    bool done = false;
-    for (int bit = base; bit < cus_total && !done && !rc; bit++) {
-        mask[(size_t)bit / 32] |= 1u << (bit % 32);
-        if ((rc = cu_mask_probe(c, mask, d_out, per, in))) break;
-        bool over = !arrays_ok(in), full = true;
-        for (int x = 0; x < 8; x++) { over = over || per[x] > target; full = full && per[x] == target; }
-        if (over) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
-        done = full && !over;
-    }
-    (void)hipFree(d_out);
-    if (rc) return rc;
-    if (!done) return fail(c, QCQPMI_EUNSUPPORTED, "no CU mask with %d CUs on every XCD found", target);
-    return 0;
-}
-
-int qcqpmi_cd_ring_start(qcqpmi_ctx **ctxs, int count, int phase2_cus, int64_t num_iters, double tol) {
-    if (!ctxs || count < 2 || count > CDQ_MAXB || !ctxs[0]) return QCQPMI_EINVAL;
-    qcqpmi_ctx *o = ctxs[0];
-    if (o->ring_running || o->ring_owner) return fail(o, QCQPMI_ESTATE, "cd_ring_start: a ring is already running on this context");
-    HIPCHK(o, hipSetDevice(o->device));
-    int cus = 0;
-    HIPCHK(o, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, o->device));
-    if (phase2_cus <= 0 || phase2_cus > cus) phase2_cus = cus;
-    for (int i = 0; i < count; i++) {
-        qcqpmi_ctx *c = ctxs[i];
-        if (!c || !c->finalized || c->n != o->n || c->device != o->device || !c->X || c->R != o->R || c->ring_owner ||
-            !cd_queue_eligible(c, false) || c->R <= 0)
-            return fail(o, QCQPMI_EINVAL, "cd_ring_start: member %d is not a context of the same problem with a resident population of the "
-                        "same size, or its problem does not take the slot-queue kernel", i);
-    }
-    if (!(tol > 0.0) || num_iters < 0) return fail(o, QCQPMI_EINVAL, "cd_ring_start: bad num_iters / tol");
-    int rc;
-    if (!o->d_rctl && (rc = dev_alloc(o, &o->d_rctl, 4))) return rc;
-    HIPCHK(o, hipMemsetAsync(o->d_rctl, 0, 4 * sizeof(int), o->stream));
-    CdQueueArgs qa;
-    qa.P = o->dp; qa.nb = count; qa.num_iters = num_iters; qa.tol = tol; qa.ring = 1; qa.rctl = o->d_rctl; qa.life = nullptr; qa.life_on = 0;
-    {
-        int khz = 0;
-        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, o->device) != hipSuccess || khz <= 0) khz = 100000;
-        qa.ring_limit = (long long)khz * 1000ll * 600ll;      // ten minutes of the wall clock: a forgotten ring does not hold the GPU forever
-    }
-    for (int i = 0; i < CDQ_MAXB; i++) {
-        qcqpmi_ctx *c = ctxs[i < count ? i : 0];
-        if (i < count) {
-            if (!c->d_qnext && (rc = dev_alloc(c, &c->d_qnext, 16))) return fail(o, rc, "cd_ring_start: %s", c->err.c_str());
-            HIPCHK(o, hipMemsetAsync(c->d_qnext, 0, 16 * sizeof(int), c->stream));
-            HIPCHK(o, hipStreamSynchronize(c->stream));
-            c->qgen = 0;
-        }
-        cd_queue_fill_batch(c, qa.b[i], 0, 0);
-    }
-    HIPCHK(o, hipStreamSynchronize(o->stream));
-    if (o->ring_stream) { (void)hipStreamDestroy(o->ring_stream); o->ring_stream = nullptr; }
-    if (phase2_cus < cus) {
-        // Partitions of whole mask words (192, 224 CUs) are the ones that work: with others -- also with a mask built bit by bit to
-        // reach the same number of CUs on every XCD (cu_mask_balanced, verified by the probe) -- the run stalls after a few
-        // populations or crawls (profiles/r03_queue_chain_ring.md); not understood yet, hence refused unless asked for.
-        if (phase2_cus % 32 != 0 && !getenv("QCQPMI_RING_ANY_PARTITION"))
-            return fail(o, QCQPMI_EUNSUPPORTED, "cd_ring_start: a partition of %d CUs is not a multiple of 32 (only whole words of the CU mask behave: "
-                        "192 or 224 of 256)", phase2_cus);
-        std::vector<uint32_t> mask;
-        if ((rc = cu_mask_balanced(o, cus, phase2_cus, mask))) return rc;      // the same number of CUs on every XCD
-        HIPCHK(o, hipExtStreamCreateWithCUMask(&o->ring_stream, (uint32_t)mask.size(), mask.data()));
-    } else {
-        HIPCHK(o, hipStreamCreateWithFlags(&o->ring_stream, hipStreamNonBlocking));
-    }
-    int cs = (o->dbg & 128) ? ((o->dbg >> 8) & 7) : 4;
-    (void)hipEventRecord(o->timers[2].beg, o->ring_stream);
-    hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, phase2_cus, o->ring_stream);
-    if (qe != hipSuccess) return fail(o, QCQPMI_EHIP, "cd_ring_start: %s", hipGetErrorString(qe));
-    (void)hipEventRecord(o->timers[2].end, o->ring_stream);
-    o->timers[2].valid = true;
-    o->ring_members.assign(ctxs, ctxs + count);
-    for (int i = 0; i < count; i++) { ctxs[i]->ring_owner = o; ctxs[i]->last_cd2_kernel = "cd_phase2_qs_kernel"; }
-    o->ring_running = true;
-    return 0;
-}
-
-// stage 1 of a run (suggest is the caller's; phase 1, evaluation, gate) on the member's own stream, then the population is
-// handed to the persistent launch
-int qcqpmi_cd_ring_submit(qcqpmi_ctx *c, int phase1, int64_t num_iters, double viol_tol, double tol, uint64_t seed, uint64_t first_index) {
-    int rc = check_ready(c, true);
-    if (rc) return rc;
-    if (!c->ring_owner || !c->ring_owner->ring_running) return fail(c, QCQPMI_ESTATE, "cd_ring_submit: the context is not a member of a running ring");
-    c->cd_stage = 0;
-    const int keep = c->cd_queue;
-    c->cd_queue = 0;                       // (stage 1 must not publish in the chained way)
-    rc = qcqpmi_cd_run_stage(c, 1, phase1, num_iters, viol_tol, tol, seed, first_index, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    c->cd_queue = keep;
-    if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_visits, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_sweeps, 0, (size_t)c->Rpad * sizeof(int64_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_status, 0, (size_t)c->Rpad * sizeof(int), c->stream));
-    c->qgen++;
-    hipLaunchKernelGGL(cd_ring_publish_kernel, dim3(1), dim3(1), 0, c->stream, c->d_qnext, c->qgen, (int)c->R,
-                       (unsigned long long)seed, (unsigned long long)first_index);
-    HIPCHK(c, hipGetLastError());
-    c->cd_stage = 2;                       // "phase 2 is under way"
-    return 0;
-}
-
-// waits until every restart of the member's population is done, then fetches the results like stage 3
-int qcqpmi_cd_ring_collect(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
-                           uint8_t *ran_phase2, double *f0, double *maxviol) {
-    int rc = check_ready(c, true);
-    if (rc) return rc;
-    if (!c->ring_owner || c->cd_stage != 2) return fail(c, QCQPMI_ESTATE, "cd_ring_collect: nothing submitted");
-    HIPCHK(c, hipSetDevice(c->device));
-    // Wait for the population's `done` counter.  The wait is bounded by the LAUNCH, not by a number of polls (a large population
-    // with slow restarts, or a GPU shared with other members, may legitimately take long): as long as the persistent launch
-    // runs it is working on submitted populations -- it leaves by the quit word or by its own wall-clock limit (ten minutes,
-    // cd_ring_start); once it has ended the counter cannot move any more and an incomplete population is an error.
-    int done = 0;
-    bool ended = false;
-    for (int64_t spin = 0;; spin++) {
-        HIPCHK(c, hipMemcpyAsync(&done, c->d_qnext + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (done >= (int)c->R) break;
-        if (ended) return fail(c, QCQPMI_EHIP, "cd_ring_collect: the ring's launch ended with the population incomplete (%d of %lld restarts done)", done, (long long)c->R);
-        if (spin > 2000) {      // ~ 20 ms of busy polling, then back off
-            qcqpmi_ctx *o = c->ring_owner;
-            ended = o->ring_stream && hipStreamQuery(o->ring_stream) != hipErrorNotReady;    // one more look at the counter, then fail
-            if (!ended) usleep(200);
-        }
-    }
-    c->cd_stage = 0;
-    c->evaluated = true;                   // d_f0 / d_mv hold the values of the final points
-    std::vector<int> st, st1;
-    if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
-    if ((rc = cd_apply_status(c, st, st1, f0, maxviol, 0))) return rc;
-    return 0;
-}
-
-int qcqpmi_cd_ring_stop(qcqpmi_ctx *o) {
-    if (!o) return QCQPMI_EINVAL;
-    if (!o->ring_running) return 0;
-    HIPCHK(o, hipSetDevice(o->device));
-    const int one = 1;
-    HIPCHK(o, hipMemcpyAsync(o->d_rctl, &one, sizeof(int), hipMemcpyHostToDevice, o->stream));
-    HIPCHK(o, hipStreamSynchronize(o->stream));
-    HIPCHK(o, hipStreamSynchronize(o->ring_stream));
-    for (qcqpmi_ctx *m_ : o->ring_members) m_->ring_owner = nullptr;
-    o->ring_members.clear();
-    o->ring_running = false;
-    return 0;
-}
-
-int qcqpmi_debug_cd_ring_state(qcqpmi_ctx *c, int64_t *out10) {
-    if (!c || !out10) return QCQPMI_EINVAL;
-    for (int k = 0; k < 10; k++) out10[k] = -1;
-    int q[9] = {0};
-    if (c->d_qnext) {
-        hipStream_t side = nullptr;
-        HIPCHK(c, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        HIPCHK(c, hipMemcpyAsync(q, c->d_qnext, sizeof(q), hipMemcpyDeviceToHost, side));
-        HIPCHK(c, hipStreamSynchronize(side));
-        (void)hipStreamDestroy(side);
-        for (int k = 0; k < 9; k++) out10[k] = q[k];
-    }
-    qcqpmi_ctx *o = c->ring_owner;
-    if (o && o->ring_stream) out10[9] = (int64_t)hipStreamQuery(o->ring_stream);     // 0 = the launch has ended, 600 = still running
-    return 0;
-}
-
-int qcqpmi_debug_cd_pulled(qcqpmi_ctx *c, int64_t *out) {
-    if (!c || !out) return QCQPMI_EINVAL;
-    *out = 0;
-    if (!c->d_qnext) return 0;
-    int v = 0;
-    HIPCHK(c, hipMemcpy(&v, c->d_qnext + 2, sizeof(int), hipMemcpyDeviceToHost));
-    *out = v;
-    return 0;
-}
-
-int qcqpmi_cd_partition(qcqpmi_ctx *c, int phase2_cus) {
-    if (!c) return QCQPMI_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
-    int cus = 0;
-    HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    if (phase2_cus < 0 || phase2_cus > cus) return fail(c, QCQPMI_EINVAL, "cd_partition: %d CUs of %d", phase2_cus, cus);
-    if (c->stream_p2) { HIPCHK(c, hipStreamSynchronize(c->stream_p2)); (void)hipStreamDestroy(c->stream_p2); c->stream_p2 = nullptr; }
-    c->p2_cus = 0;
-    if (phase2_cus == 0 || phase2_cus == cus) return 0;
-    // the bits of the mask are dealt round-robin to the XCDs (measured: tools/ubench/cumask.hip): the first k bits = k / 8 CUs of each
-    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
-    for (int i = 0; i < phase2_cus; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
-    HIPCHK(c, hipExtStreamCreateWithCUMask(&c->stream_p2, (uint32_t)mask.size(), mask.data()));
-    c->p2_cus = phase2_cus;
-    return 0;
-}
 
 int qcqpmi_cd_queue(qcqpmi_ctx *c, int mode) {
     if (!c || mode < 0 || mode > 2) return QCQPMI_EINVAL;

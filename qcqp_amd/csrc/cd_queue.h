@@ -4,10 +4,8 @@
 // cd_phase2_q_kernel binds 16 restarts to a workgroup for the whole launch: the workgroup runs until its slowest restart
 // has converged (lanes of converged restarts keep multiplying), and the launch until the slowest workgroup has.  Here a
 // workgroup owns 16 SLOTS: a restart that has converged is written out at the next sweep boundary and its slot takes the
-// next restart from a device-side queue -- of this population or, once that one is exhausted, of the NEXT population
-// (the one a second context has prepared meanwhile: suggest, phase 1, evaluation, gate), so the matrix pipes keep
-// working on live columns across the step boundary.  Per restart the arithmetic is that of cd_phase2_q_kernel bit for bit
-// (a column's products depend on that column only).
+// next restart from a device-side queue, so the matrix pipes keep working on live columns.  Per restart the arithmetic is
+// that of cd_phase2_q_kernel bit for bit (a column's products depend on that column only).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,27 +13,19 @@
 
 namespace qcqpmi {
 
-struct CdBatch {                 // one population = the restarts of one improve(COORD_DESCENT) call
+struct CdBatch {                 // the restarts a launch works on: one population, or (lifecycle mode) all populations of a run
     double *X;                   // tile-major [tile][n16][16], in / out
-    const double *f0cur;         // [Rpad] objective at phase-2 start
-    const double *slack;         // [Rpad] max violation at phase-2 start (the fixed slack of phase 2, qcqp.py:157)
-    const uint8_t *flag;         // [Rpad] passed the gate of improve_coord_descent (qcqp.py:189)
+    const double *f0cur;         // [Rpad] objective at phase-2 start               (not read in lifecycle mode)
+    const double *slack;         // [Rpad] max violation at phase-2 start (the fixed slack of phase 2, qcqp.py:157)   (ditto)
+    const uint8_t *flag;         // [Rpad] passed the gate of improve_coord_descent (qcqp.py:189)                    (ditto)
     int64_t *visits, *accepted, *sweeps;
     int *status;
-    double *f0out, *mvout;       // tracked objective / max violation of the final point, written for the restarts that ran
+    double *f0out, *mvout;       // objective / max violation of the final point, written for the restarts that ran
     int64_t R;
     uint64_t seed, first_index;
-    int *next;                   // queue head: next restart index to hand out (zeroed before the population is offered)
-    const int *ready;            // nullptr: always; else the population may be consumed once *ready == ready_gen
-    int ready_gen;               // generation number the owner of that population publishes when it has prepared it
+    int *next;                   // queue head: next restart index to hand out (zeroed before the launch)
 };
 
-constexpr int CDQ_MAXB = 8;      // populations a launch can see (chained launches: its own and the next three; ring: the members)
-
-// Ring mode: the queue state of a population lives in 16 device ints of its context (`next` points at them):
-//   [0] queue head  [1] generation published  [2] restarts run ahead (statistics)  [3] restarts done  [4] R
-//   [5,6] seed  [7,8] first global index       (the fields of CdBatch with the same names are ignored)
-// Population number j of a run (j = 0, 1, ...) lives in entry j % nb with generation j / nb + 1.
 // Lifecycle mode (round 4): the launch runs a restart's WHOLE improve step -- suggest(RANDOM) (keyed normals), phase 1,
 // the gate of improve_coord_descent, phase 2, objective and max violation of the result -- for a queue of Rtotal restarts
 // that belong to Rtotal / Rpop populations of Rpop restarts each (population p: seed + p seed_stride, global restart
@@ -43,7 +33,7 @@ constexpr int CDQ_MAXB = 8;      // populations a launch can see (chained launch
 // that becomes free draws the next restart index and builds the column itself.
 struct CdLife {
     int on;
-    int generate;                // 1: x0 = keyed normals (suggest RANDOM, qcqp.py:381-382); 0: the columns of b[0].X
+    int generate;                // 1: x0 = keyed normals (suggest RANDOM, qcqp.py:381-382); 0: the columns of b.X
     int phase1;                  // run phase 1 (qcqp.py:186-187)
     int64_t Rtotal, Rpop;
     uint64_t seed, seed_stride, first_index, first_stride;
@@ -52,27 +42,23 @@ struct CdLife {
     int *status1;                // [Rtotal] phase-1 status
     uint8_t *ran2;               // [Rtotal] passed the gate (qcqp.py:189)
     long long *prof;             // optional [8]: ticks (s_memtime) summed over the workgroups -- 0 column build, 1 whole launch, 2 episodes,
-                                 // 3 columns built, 4 write-out; nullptr: off
+                                 // 3 columns built, 4 the normals' share of 0; nullptr: off
 };
 
 struct CdQueueArgs {
     DevProblem P;
-    CdBatch b[CDQ_MAXB];         // b[0]: the population this launch belongs to; b[1..nb-1]: the next ones (run ahead), in order
-    int nb;
+    CdBatch b;
     int64_t num_iters;
     double tol;
-    int ring;                    // 1: ONE persistent launch serves the populations of nb contexts in turn until *rctl != 0
-    int *rctl;                   // [0] quit
-    long long ring_limit;        // safety: the launch ends after this many ticks of wall_clock64() whatever happens
-    const CdLife *life;          // lifecycle mode: parameters in DEVICE memory (b[0] holds the outputs of all Rtotal restarts; nb = 1, no
-                                 // ring); nullptr: off.  (By value they cost scalar registers for the whole kernel -- the multiplying
-                                 // waves sit exactly at the register limit and spill when the spilled scalars take two more VGPRs.)
+    const CdLife *life;          // lifecycle mode: parameters in DEVICE memory (b holds the outputs of all Rtotal restarts); nullptr: off.
+                                 // (By value they cost scalar registers for the whole kernel -- the multiplying waves sit exactly at the
+                                 // register limit and spill when the spilled scalars take two more VGPRs.)
     int life_on;
 };
 
 // LDS bytes of the kernel for this problem (0: does not fit / not eligible)
 size_t cd_queue_lds_bytes(const DevProblem &P);
-// launches ceil(R0 / 16) workgroups at most `max_wgs`; cs = blocks of the contraction the chain wave multiplies (0, 2, 4, 6)
-int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st);     // ring mode: exactly max_wgs workgroups
+// launches ceil(R / 16) workgroups at most `max_wgs`; cs = blocks of the contraction the chain wave multiplies (0, 2, 4, 6)
+int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st);
 
 }  // namespace qcqpmi

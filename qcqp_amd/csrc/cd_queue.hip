@@ -3,9 +3,12 @@
 // DESIGN.md section 4.1) wrapped into EPISODES.  A workgroup owns 16 slots of its X tile in LDS; an episode runs the role
 // code from a sweep boundary until, at a later sweep boundary, some slot's restart is done (converged, qcqp.py:172-176, or at
 // the sweep limit) and the device-side queue still has restarts -- then the finished columns are written out (point,
-// tracked objective, max violation, counters), the free slots take the next restarts (of this population, or of the next
-// one once that is ready: cd_queue.h), and the next episode starts; restarts that are not done simply continue (their
-// state lives in the chain wave's registers and in the tile).
+// tracked objective, max violation, counters), the free slots take the next restarts of the queue, and the next episode
+// starts; restarts that are not done simply continue (their state lives in the chain wave's registers and in the tile).
+// Lifecycle mode (round 4, cd_queue.h): the queue runs over the restarts of SEVERAL populations and a slot builds its restart
+// itself -- normals, phase 1, gate -- before phase 2.  (Rounds 3's chained launches and ring mode -- one persistent launch on
+// a CU-masked stream serving the populations of several contexts -- were removed in round 4: the lifecycle mode does what
+// they were after without a CU partition, extra hardware queues or a second stream; DESIGN.md section 4.1c keeps the record.)
 //
 // Determinism.  A restart's values must not depend on where the episode boundaries fall (they depend on the other slots).
 // Every product of the kernel is therefore summed in ONE association: the multiplying waves always leave out the two
@@ -36,10 +39,8 @@ namespace {
 __device__ inline int qs_load_int(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline double qs_load_d(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// A pointer that was read from the descriptor table in LDS is GLOBAL memory, but the compiler cannot know: it emits FLAT
-// loads / stores / atomics for everything reached through it (31 of them; they count against the LDS counter as well, and
-// the roles of this kernel synchronise through LDS words) -- the chained variant was 30 % slower than the single-population
-// one for that alone (12.9 against 9.8 ms at 16384 restarts).  Hence descriptors with pointers typed as global memory.
+// pointers typed as global memory: a generic pointer makes the compiler emit FLAT loads / stores / atomics, which count against
+// the LDS counter as well -- and the roles of this kernel synchronise through LDS words (measured in round 3: 30 % slower)
 #define QG __attribute__((address_space(1)))
 struct CdBatchG {
     QG double *X;
@@ -51,8 +52,6 @@ struct CdBatchG {
     int64_t R;
     uint64_t seed, first_index;
     QG int *next;
-    QG const int *ready;
-    int ready_gen;
 };
 template <class T>
 __device__ __attribute__((always_inline)) inline QG T *qs_g(T *p) { return (QG T *)p; }
@@ -60,18 +59,14 @@ __device__ __attribute__((always_inline)) inline CdBatchG qs_batch(const CdBatch
     CdBatchG b;
     b.X = qs_g(t.X); b.f0cur = qs_g(t.f0cur); b.slack = qs_g(t.slack); b.flag = qs_g(t.flag);
     b.visits = qs_g(t.visits); b.accepted = qs_g(t.accepted); b.sweeps = qs_g(t.sweeps); b.status = qs_g(t.status);
-    b.f0out = qs_g(t.f0out); b.mvout = qs_g(t.mvout); b.next = qs_g(t.next); b.ready = qs_g(t.ready);
-    b.R = t.R; b.seed = t.seed; b.first_index = t.first_index; b.ready_gen = t.ready_gen;
+    b.f0out = qs_g(t.f0out); b.mvout = qs_g(t.mvout); b.next = qs_g(t.next);
+    b.R = t.R; b.seed = t.seed; b.first_index = t.first_index;
     return b;
 }
 __device__ inline int qs_load_int(QG const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline double qs_load_d(QG const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline int qs_add(QG int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// CS: blocks of the contraction the chain wave multiplies itself (0..RQ_CSMAX)
-// MULTI = false: ONE population and no ring -- the descriptor is the kernel argument itself, the chain / ring branches are
-// compiled out.  (With the four descriptors in LDS and the ring branches in place the single-population launch was 30 %
-// slower: 12.9 instead of 9.8 ms at 16384 restarts; measured late in round 3, tools/queue_rate.py.)
 // order-preserving map double -> u64 and back (LDS integer atomics as max-reductions over the threads)
 __device__ inline unsigned long long qs_key(double x) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(x);
@@ -119,15 +114,10 @@ __device__ __attribute__((noinline)) double qs_p1_visit(double p, double q, doub
     return x;
 }
 
-template <int CS, int QM>      // QM: 0 one population, 1 chained populations (descriptor table), 2 ring, 3 lifecycle (cd_queue.h)
+// CS: blocks of the contraction the chain wave multiplies itself (0..RQ_CSMAX); LIFE: lifecycle mode (cd_queue.h)
+template <int CS, bool LIFE>
 __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
-    constexpr bool MULTI = QM == 1 || QM == 2;
-    constexpr bool LIFE = QM == 3;
-    // the compiler sees constants where the other modes read the arguments
-    CdQueueArgs a = a0;
-    a.ring = (QM == 2) ? 1 : 0;
-    if (!MULTI) a.nb = 1;
-#define QB(i) (MULTI ? Bt[i] : a0.b[0])
+    const CdQueueArgs &a = a0;
     constexpr int MAXC = 1;
     constexpr int CSU = CS > 0 ? CS : 1;
     extern __shared__ double smem[];
@@ -159,15 +149,13 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
     long long *oacc = (long long *)sp; sp += 16;
     long long *oswp = (long long *)sp; sp += 16;
     int *sid = (int *)sp; sp += 8;                 // restart held by a slot (-1: none)
-    int *sbt = (int *)sp; sp += 8;                 // ... and the population it belongs to (0 / 1)
     int *snew = (int *)sp; sp += 8;                // slot refilled before this episode
     int *sfin = (int *)sp; sp += 8;                // slot's restart finished in this episode
     int *ost = (int *)sp; sp += 8;
     int *ctl = (int *)sp; sp += 8;                 // [0] occupied slots
     long long *cst = (long long *)sp; sp += 64 * 10; // the chain wave's per-lane state between episodes: [field][lane]
-    CdBatch *Bt = (CdBatch *)sp; sp += (CDQ_MAXB * sizeof(CdBatch) + 7) / 8;
-    unsigned long long *sseed = (unsigned long long *)sp; sp += 16;     // ring mode: seed / first global index of the slot's population
-    unsigned long long *sfirst = (unsigned long long *)sp; sp += 16;   // the populations this launch may draw from (dynamic indexing: LDS, not kernel arguments)
+    unsigned long long *sseed = (unsigned long long *)sp; sp += 16;     // seed / first global index (minus the slot's queue index) of the slot's population
+    unsigned long long *sfirst = (unsigned long long *)sp; sp += 16;
     // lifecycle mode: phase 1 of the restarts just taken -- per slot: max-violation key (reduction), "a coordinate moved",
     // finished, sweeps, status; passed the gate
     unsigned long long *p1key = (unsigned long long *)sp; sp += 16;
@@ -186,9 +174,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
 #pragma unroll
         for (int f = 0; f < 10; f++) cst[f * 64 + tid0] = (f == 4) ? 1 : 0;
     }
-    if (tid0 < 16) { sid[tid0] = -1; sbt[tid0] = 0; sfin[tid0] = 0; }
-    if (tid0 == 0) { if (MULTI) for (int q = 0; q < CDQ_MAXB; q++) Bt[q] = a0.b[q]; ctl[1] = 0; ctl[2] = 0; }
-    const long long ring_t0 = a.ring ? (long long)wall_clock64() : 0;
+    if (tid0 < 16) { sid[tid0] = -1; sfin[tid0] = 0; }
     const long long life_t0 = (LIFE && tid0 == 0) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     __syncthreads();
     const int64_t gmax = (int64_t)1 << 40;         // the roles end through RQ_STOP
@@ -202,67 +188,38 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
         asm volatile("" : "+s"(lifep));
         const int lane = tid & 63, r = lane >> 2, gq = lane & 3;
         // ================================================================ refill: free slots take the next restarts
-        if (tid == 0) {
-            ctl[0] = 0;
-            // ring mode: leave when the host asks to, or after the safety limit (a.ring_limit ticks of the 100 MHz wall clock: ten minutes, cd_ring_start)
-            ctl[3] = !a.ring ? 0 : ((long long)wall_clock64() - ring_t0 > a.ring_limit) ? 2 : (qs_load_int(a.rctl) != 0 ? 1 : 0);
-        }
+        if (tid == 0) ctl[0] = 0;
         __syncthreads();
         if (tid < 16) {
-            int id = sid[tid], bt = sbt[tid], nw = 0;
-            if (id < 0 && a.ring) {
-                // ring mode: this workgroup's cursor j walks the populations of the run in order (entry j % nb, generation
-                // j / nb + 1); it moves on when a queue is exhausted and stops at the first population not published yet
-                int j = ctl[1];
-                for (;;) {
-                    const int e = j % a.nb;
-                    QG int *qe = qs_g(QB(e).next);
-                    const int want = j / a.nb + 1, gen = qs_load_int(qe + 1);
-                    if (gen < want) break;
-                    if (gen > want) { j++; continue; }              // that population was complete long ago (entry reused)
-                    const int idx = qs_add(qe, 1);
-                    if (idx >= qs_load_int(qe + 4)) { j++; continue; }
-                    if (__hip_atomic_load(qs_g(QB(e).flag) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        id = idx; bt = e; nw = 1;
-                        sseed[tid] = (unsigned long long)(unsigned)qs_load_int(qe + 5) | ((unsigned long long)(unsigned)qs_load_int(qe + 6) << 32);
-                        sfirst[tid] = (unsigned long long)(unsigned)qs_load_int(qe + 7) | ((unsigned long long)(unsigned)qs_load_int(qe + 8) << 32);
-                        break;
-                    }
-                    qs_add(qe + 3, 1);                            // did not pass the gate (qcqp.py:189): nothing to run, done
-                }
-                atomicMax(&ctl[2], j);
-            } else if (id < 0 && LIFE) {
+            int id = sid[tid], nw = 0;
+            if (id < 0 && LIFE) {
                 // lifecycle mode: the queue is a counter over all restarts of the run; the column is built below
                 QG const CdLife *lf = qs_g(lifep);
-                const int idx = qs_add(qs_g(a0.b[0].next), 1);
+                const int idx = qs_add(qs_g(a0.b.next), 1);
                 if (idx < (int)lf->Rtotal) {
-                    id = idx; bt = 0; nw = 1;
+                    id = idx; nw = 1;
                     const uint64_t pop = (uint64_t)idx / (uint64_t)lf->Rpop, rho = (uint64_t)idx % (uint64_t)lf->Rpop;
                     sseed[tid] = lf->seed + pop * lf->seed_stride;
                     sfirst[tid] = lf->first_index + pop * lf->first_stride + rho - (uint64_t)idx;    // + id = the global restart index
                 }
             } else if (id < 0) {
-                for (int q = 0; q < a.nb && id < 0; q++) {
-                    const CdBatchG B = qs_batch(QB(q));
-                    if (B.ready && qs_load_int(B.ready) != B.ready_gen) break;     // not published yet (nor are the ones after it)
-                    for (;;) {
-                        const int idx = qs_add(B.next, 1);      // (runs past R by at most 16 per workgroup and episode: harmless)
-                        if (idx >= (int)B.R) break;
-                        if (__hip_atomic_load(B.flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            id = idx; bt = q; nw = 1;
-                            sseed[tid] = B.seed; sfirst[tid] = B.first_index;
-                            if (q >= 1) qs_add(B.next + 2, 1);      // statistics: restarts of the next population run ahead by this launch
-                            break;
-                        }
+                const CdBatchG B = qs_batch(a0.b);
+                for (;;) {
+                    const int idx = qs_add(B.next, 1);      // (runs past R by at most 16 per workgroup and episode: harmless)
+                    if (idx >= (int)B.R) break;
+                    if (B.flag[idx]) {                      // passed the gate of improve_coord_descent (qcqp.py:189)
+                        id = idx; nw = 1;
+                        sseed[tid] = B.seed; sfirst[tid] = B.first_index;
+                        break;
                     }
                 }
             }
-            sid[tid] = id; sbt[tid] = bt; snew[tid] = nw;
+            sid[tid] = id; snew[tid] = nw;
             if (LIFE) { if (nw) { p1fin[tid] = 0; p1sw[tid] = 0; p1st[tid] = 0; gatep[tid] = 0; } }
             if (nw && !LIFE) {
-                const CdBatchG B = qs_batch(QB(bt));
-                slk[tid] = qs_load_d(B.slack + id);
-                f0new[tid] = qs_load_d(B.f0cur + id);
+                const CdBatchG B = qs_batch(a0.b);
+                slk[tid] = B.slack[id];
+                f0new[tid] = B.f0cur[id];
                 FeasSet<MAXC> C;
                 compute_set<MAXC>(P, P.krep[0], slk[tid], C);
                 store_set<MAXC>(TC, tid, C);
@@ -277,16 +234,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
         }
         if (tid < 16) *(volatile rq_lds_int *)(sy + tid) = (tid >= RQ_PARTS && tid < RQ_PARTS + 3) ? -1 : 0;   // words of the even-product waves start odd
         __syncthreads();
-        if (tid == 0 && ctl[2] > ctl[1]) ctl[1] = ctl[2];
-        if (ctl[3] == 2) break;                    // safety limit of a persistent launch: leave whatever is in flight
-        if (ctl[0] == 0) {
-            if (!a.ring) break;                    // nothing left anywhere: done
-            // ring mode: idle until a population is published, the host asks to quit, or the safety limit passes
-            if (ctl[3]) break;
-            __builtin_amdgcn_s_sleep(127);
-            __syncthreads();
-            continue;
-        }
+        if (ctl[0] == 0) break;                    // nothing left anywhere: done
         if (LIFE) {
             // ---- lifecycle mode: build the columns of the restarts just taken -- suggest(RANDOM) (qcqp.py:381-382: keyed
             // normals, the stream of randn_tiles_kernel), phase 1 (qcqp.py:101-149 through p1_sep_visit: the moves of
@@ -312,7 +260,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                         Xs[(j + 1) * 16 + c] = xo;
                     }
                 } else {
-                    QG const double *src = qs_g(a0.b[0].X) + ((int64_t)(sid[c] >> 4) * n16) * 16 + (sid[c] & 15);
+                    QG const double *src = qs_g(a0.b.X) + ((int64_t)(sid[c] >> 4) * n16) * 16 + (sid[c] & 15);
                     for (int64_t j = tid; j < n16; j += 512) Xs[j * 16 + c] = src[j * 16];
                 }
             }
@@ -388,16 +336,14 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
             const int col = tid & 15;
             const int id = sid[col];
             if (snew[col]) {
-                // eight loads in flight per thread; the own population was complete before this launch (plain loads), the
-                // next one was written by kernels of another stream while this one was running (sc1 loads)
-                const bool nxt = a.ring || sbt[col] != 0;
-                QG const double *src = qs_g(QB(sbt[col]).X) + ((int64_t)(id >> 4) * n16) * 16 + (id & 15);
+                // eight loads in flight per thread
+                QG const double *src = qs_g(a0.b.X) + ((int64_t)(id >> 4) * n16) * 16 + (id & 15);
                 for (int64_t j0 = tid >> 4; j0 < n16; j0 += 32 * 8) {
                     double pv[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const int64_t j = j0 + 32 * u;
-                        pv[u] = (j < n16) ? (nxt ? qs_load_d(src + j * 16) : src[j * 16]) : 0.0;
+                        pv[u] = (j < n16) ? src[j * 16] : 0.0;
                     }
 #pragma unroll
                     for (int u = 0; u < 8; u++) { const int64_t j = j0 + 32 * u; if (j < n16) Xs[j * 16 + col] = pv[u]; }
@@ -784,9 +730,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                         S.fcur = rq_quad_sum(fpart);
                         double fa = LIFE ? rq_quad_sum(facc) : 0.0;
                         double *Gsc = fixp;
-                        const int bsel = sbt[r];
                         const uint64_t dseed = sseed[r], dfirst = sfirst[r];
-                        (void)bsel;
 #pragma unroll
                         for (int v = 0; v < 4; v++) Gsc[(4 * v + gq) * 16 + r] = g0[v];
                         for (int c = 0; c < 16; c++) {
@@ -819,7 +763,6 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                 if (LIFE && frz && b == NB - 1) { frz = false; done = true; }      // the frozen sweep is complete
                 const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv || frz);
                 if (livem == 0ull) break;
-                if (b == NB - 1 && a.ring && (long long)wall_clock64() - ring_t0 > a.ring_limit) break;
                 if (b == NB - 1) {
                     // sweep boundary: slots whose restart is done (converged, or at the sweep limit) can take a new restart --
                     // end the episode if the queue has one
@@ -827,24 +770,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                     const unsigned long long finm = __builtin_amdgcn_ballot_w64(fin);
                     if (finm == ~0ull) break;
                     if (finm != 0ull) {
-                        bool more = LIFE && qs_load_int(qs_g(a0.b[0].next)) < (int)qs_g(lifep)->Rtotal;
-                        if (a.ring) {
-                            for (int j = ctl[1], tries = 0; tries < 2 && !more; j++, tries++) {
-                                QG int *qe = qs_g(QB(j % a.nb).next);
-                                const int want = j / a.nb + 1, gen = qs_load_int(qe + 1);
-                                if (gen < want) break;
-                                more = gen == want && qs_load_int(qe) < qs_load_int(qe + 4);
-                            }
-                        }
-                        if (!a.ring && !LIFE) {
-                            // own population from the kernel arguments (scalar registers), the others from the table
-                            more = (!a0.b[0].ready || qs_load_int(a0.b[0].ready) == a0.b[0].ready_gen) && qs_load_int(a0.b[0].next) < (int)a0.b[0].R;
-                            for (int q = 1; q < a.nb && !more; q++) {
-                                const CdBatchG B = qs_batch(QB(q));
-                                if (B.ready && qs_load_int(B.ready) != B.ready_gen) break;
-                                more = qs_load_int(B.next) < (int)B.R;
-                            }
-                        }
+                        const bool more = qs_load_int(qs_g(a0.b.next)) < (LIFE ? (int)qs_g(lifep)->Rtotal : (int)a0.b.R);
                         if (more) break;
                     }
                 }
@@ -899,11 +825,10 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
             const int col = tid & 15, slot = tid >> 4;
             double v = -QM_INF;
             if (sfin[col]) {
-                QG double *dst = qs_g(QB(sbt[col]).X) + ((int64_t)(sid[col] >> 4) * n16) * 16 + (sid[col] & 15);
+                QG double *dst = qs_g(a0.b.X) + ((int64_t)(sid[col] >> 4) * n16) * 16 + (sid[col] & 15);
                 for (int64_t i = slot; i < n16; i += 32) {
                     const double x = Xs[i * 16 + col];
-                    if (a.ring) __hip_atomic_store(dst + i * 16, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // read by other kernels while this one runs
-                    else dst[i * 16] = x;
+                    dst[i * 16] = x;
                     if (i < P.n) {
                         const double f = (cp * x + cq) * x + cr;
                         const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
@@ -913,23 +838,13 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
             }
             double *red = part2;                 // 512 doubles of the partial-tile area, free between episodes
             red[tid] = v;
-            if (a.ring) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the columns are in memory before `done` counts them
             __syncthreads();
             if (tid < 16 && sfin[tid]) {
                 double m = -QM_INF;
                 for (int s2 = 0; s2 < 32; s2++) { const double w = red[s2 * 16 + tid]; m = w > m ? w : m; }
-                const CdBatchG B = qs_batch(QB(sbt[tid]));
+                const CdBatchG B = qs_batch(a0.b);
                 const int id = sid[tid];
-                if (a.ring) {
-                    __hip_atomic_store((QG long long *)B.visits + id, ovis[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store((QG long long *)B.accepted + id, oacc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store((QG long long *)B.sweeps + id, oswp[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(B.status + id, ost[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (B.f0out) __hip_atomic_store(B.f0out + id, of0[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (B.mvout) __hip_atomic_store(B.mvout + id, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    qs_add(B.next + 3, 1);                              // one more restart of that population is complete
-                } else {
+                {
                     B.visits[id] = ovis[tid]; B.accepted[id] = oacc[tid]; B.sweeps[id] = oswp[tid]; B.status[id] = ost[tid];
                     if (B.f0out) B.f0out[id] = of0[tid];
                     if (B.mvout) B.mvout[id] = m;
@@ -950,12 +865,11 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
 
 }  // namespace
 
-#undef QB
 
 size_t cd_queue_lds_bytes(const DevProblem &P) {
     const int NB = (int)P.NB;
     if (P.n % 16 != 0 || NB < 3) return 0;
-    size_t bytes = ((size_t)RQ_LDS_COMMON + 8 + 16 * 5 + 8 * 6 + 64 * 10 + (CDQ_MAXB * sizeof(CdBatch) + 7) / 8 + 32 + 16 + 8 * 5 + (size_t)P.n16 * 16) * sizeof(double);
+    size_t bytes = ((size_t)RQ_LDS_COMMON + 8 + 16 * 5 + 8 * 6 + 64 * 10 + 32 + 16 + 8 * 5 + (size_t)P.n16 * 16) * sizeof(double);
     if (bytes < RQ_LDS_MIN + 1024) bytes = RQ_LDS_MIN + 1024;
     return bytes <= 160 * 1024 ? bytes : 0;
 }
@@ -968,16 +882,12 @@ int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st) {
     if (cs >= NB) cs = 0;
     cs &= ~1;
     if (NB - cs > RQ_NSIMD * RQ_MAXU) return (int)hipErrorInvalidValue;
-    int qm = a.life_on ? 3 : a.ring ? 2 : (a.nb > 1 ? 1 : 0);
-    if (const char *e = getenv("QCQPMI_QS_MODE")) { const int v = atoi(e); if (!a.ring && !a.life_on && v >= qm && v <= 1) qm = v; }     // experiments: the chained variant on one population
-    auto k = qm == 3 ? (cs == 0 ? cd_phase2_qs_kernel<0, 3> : cs == 2 ? cd_phase2_qs_kernel<2, 3> : cs == 4 ? cd_phase2_qs_kernel<4, 3> : cd_phase2_qs_kernel<6, 3>)
-           : qm == 2 ? (cs == 0 ? cd_phase2_qs_kernel<0, 2> : cs == 2 ? cd_phase2_qs_kernel<2, 2> : cs == 4 ? cd_phase2_qs_kernel<4, 2> : cd_phase2_qs_kernel<6, 2>)
-           : qm == 1 ? (cs == 0 ? cd_phase2_qs_kernel<0, 1> : cs == 2 ? cd_phase2_qs_kernel<2, 1> : cs == 4 ? cd_phase2_qs_kernel<4, 1> : cd_phase2_qs_kernel<6, 1>)
-                     : (cs == 0 ? cd_phase2_qs_kernel<0, 0> : cs == 2 ? cd_phase2_qs_kernel<2, 0> : cs == 4 ? cd_phase2_qs_kernel<4, 0> : cd_phase2_qs_kernel<6, 0>);
+    auto k = a.life_on ? (cs == 0 ? cd_phase2_qs_kernel<0, true> : cs == 2 ? cd_phase2_qs_kernel<2, true> : cs == 4 ? cd_phase2_qs_kernel<4, true> : cd_phase2_qs_kernel<6, true>)
+                       : (cs == 0 ? cd_phase2_qs_kernel<0, false> : cs == 2 ? cd_phase2_qs_kernel<2, false> : cs == 4 ? cd_phase2_qs_kernel<4, false> : cd_phase2_qs_kernel<6, false>);
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    int64_t wgs = (a.b[0].R + 15) / 16;     // lifecycle mode: b[0].R = all restarts of the run
-    if (wgs > max_wgs || a.ring) wgs = max_wgs;
+    int64_t wgs = (a.b.R + 15) / 16;     // lifecycle mode: b.R = all restarts of the run
+    if (wgs > max_wgs) wgs = max_wgs;
     if (wgs < 1) wgs = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3(512), lds, st, a);
     return (int)hipGetLastError();

@@ -378,54 +378,6 @@ class Engine(object):
         a device-side queue (cd_phase2_qs_kernel)."""
         self._chk(self.L.qcqpmi_cd_queue(self.h, int(mode)))
 
-    # ring mode: one persistent phase-2 launch for the populations of several engines (qcqpmi_cd_ring_*)
-    @staticmethod
-    def ring_start(engines, phase2_cus=0, num_iters=1000, tol=1e-4):
-        """Start the persistent slot-queue launch for `engines` (2..8, same problem, resident populations of one size, each
-        having run one ordinary cd_run before).  engines[0] owns the launch."""
-        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
-        rc = engines[0].L.qcqpmi_cd_ring_start(arr, len(engines), int(phase2_cus), int(num_iters), float(tol))
-        engines[0]._chk(rc)
-
-    def ring_submit(self, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=0, first_index=0):
-        """Phase 1 + evaluation + gate of the resident population, then hand it to the persistent launch (asynchronous)."""
-        self._chk(self.L.qcqpmi_cd_ring_submit(self.h, int(bool(phase1)), int(num_iters), float(viol_tol), float(tol), int(seed),
-                                               int(first_index)))
-
-    def ring_collect(self):
-        """Wait until the submitted population is complete; the dictionary of cd_run."""
-        R = self.pop_size
-        out = dict(sweeps1=np.zeros(R, dtype=np.int64), sweeps2=np.zeros(R, dtype=np.int64),
-                   visits2=np.zeros(R, dtype=np.int64), accepted2=np.zeros(R, dtype=np.int64),
-                   ran_phase2=np.zeros(R, dtype=np.uint8), f0=np.empty(R), maxviol=np.empty(R))
-        self._chk(self.L.qcqpmi_cd_ring_collect(self.h, _ip(out['sweeps1']), _ip(out['sweeps2']), _ip(out['visits2']),
-                                                _ip(out['accepted2']), _bp(out['ran_phase2']), _dp(out['f0']), _dp(out['maxviol'])))
-        st1 = np.zeros(R, dtype=np.int32)
-        st2 = np.zeros(R, dtype=np.int32)
-        self._chk(self.L.qcqpmi_cd_status(self.h, st1.ctypes.data_as(C.POINTER(C.c_int)), st2.ctypes.data_as(C.POINTER(C.c_int))))
-        out['status1'], out['status2'] = st1, st2
-        return out
-
-    def ring_stop(self):
-        self._chk(self.L.qcqpmi_cd_ring_stop(self.h))
-
-    def cd_pulled(self):
-        """Restarts of this engine's populations run ahead by the launches of the engine chained to it (running total)."""
-        v = np.zeros(1, dtype=np.int64)
-        self._chk(self.L.qcqpmi_debug_cd_pulled(self.h, _ip(v)))
-        return int(v[0])
-
-    def cd_partition(self, phase2_cus):
-        """Confine the slot-queue launches of this engine to `phase2_cus` CUs (0 = whole chip); see qcqpmi_cd_partition."""
-        self._chk(self.L.qcqpmi_cd_partition(self.h, int(phase2_cus)))
-
-    def cd_chain(self, nxt, next_R=0, next_seed=0, next_first_index=0, pos=1):
-        """The phase-2 launch of this engine may run restarts of the NEXT population of engine `nxt` (same problem, same GPU) once
-        the queues before it are empty; pos = 1 the population after this engine's own, 2 / 3 the ones after that
-        (qcqpmi_cd_chain).  nxt=None ends the chain at pos."""
-        self._chk(self.L.qcqpmi_cd_chain(self.h, int(pos), nxt.h if nxt is not None else None, int(next_R), int(next_seed),
-                                         int(next_first_index)))
-
     def cd_reference_order(self, enable=True):
         """Coupled constraints: coordinate descent in the reference's summation order (slow, value-for-value comparable with
         the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""

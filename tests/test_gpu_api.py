@@ -466,17 +466,35 @@ def test_circle_packing_two_variables(orc):
     for r in range(R2):
         assert abs(q2.population_f[r] + po2.eval(0, Y[:, r])) <= 1e-9 * (1 + abs(q2.population_f[r]))
         assert abs(q2.population_v[r] - po2.max_violation(Y[:, r])) <= 1e-9 * (1 + q2.population_v[r])
-    q2.engine.upload(Y0)
-    q2._resident = False
-    q2.engine.cd_reference_order(True)
-    out = q2.engine.cd_run(phase1=True, num_iters=3, seed=6)
-    Yr = q2.engine.download()
-    assert q2.engine.last_cd_kernel() == 'cd_general_kernel'
-    for r in (0, R2 - 1):
+    # ... and value for value, teacher-forced: the oracle's own states through the unit step of the default path
+    # (qcqpmi_cd_dense_block_step, one coordinate visit per step; see tests/test_gpu_scale.py for the statement)
+    Rt = 8
+    runs = []
+    for r in range(Rt):
         rng = orc.Rng(orc.RNG_KEYED, 6)
         rng.set_restart(r)
-        xo, s1, s2 = po2.improve_cd(Y0[:, r], num_iters=3, rng=rng)
-        assert np.max(np.abs(Yr[:, r] - xo)) <= 1e-9 * (1 + np.max(np.abs(xo))), r
+        runs.append(po2.improve_cd_traced(Y0[:, r], num_iters=3, rng=rng))
+    n2 = 2 * N2 + 1
+    slack2 = np.array([0.0 if u[5] is None else u[5] for u in runs])
+    cur = Y0[:, :Rt].copy()
+    worst, cnt = 0.0, 0
+    for phase, ti in ((1, 3), (2, 4)):
+        trs = [u[ti] for u in runs]
+        for v0 in range(max(len(t) for t in trs)):
+            t, i = divmod(v0, n2)
+            active = [r for r in range(Rt) if len(trs[r]) > v0]
+            if not active:
+                continue
+            q2.engine.upload(cur)
+            q2.engine.cd_dense_block_step(phase, t, i // 16, slack=slack2 if phase == 2 else None, seed=6, first_index=0,
+                                          coords=(i % 16, i % 16 + 1))
+            X1 = q2.engine.download()
+            for r in active:
+                worst = max(worst, abs(X1[i, r] - trs[r][v0]) / (1 + np.max(np.abs(cur[:, r]))))
+                cur[i, r] = trs[r][v0]
+                cnt += 1
+    print('\ncircle packing N = 40 through the default dense path, teacher-forced: %d visits, worst deviation from the oracle %.1e' % (cnt, worst))
+    assert cnt >= 2 * n2 * Rt // 2 and worst < 1e-6
 
 
 def rel_eq_forms(form, funcs):

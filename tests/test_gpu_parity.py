@@ -729,83 +729,3 @@ def test_cd_queue_kernel_vs_tile_bound(eng_mod, orc):
         x, s1, s2 = prob.improve_cd(X0[:, r], rng=rng)
         assert rel(Xq[:, r], x) < 1e-9, r
         assert oq['visits2'][r] == s2[1] and oq['accepted2'][r] == s2[2]
-
-
-@pytest.mark.parametrize('NC,LA,DL', [(4, 1, 1), (6, 2, 2)])    # a context is reused after LA + DL + 2 steps
-def test_cd_chained_contexts_match_serial_runs(eng_mod, NC, LA, DL):
-    """qcqpmi_cd_chain: contexts in a ring, the phase-2 launch of step k may run restarts of the next LA steps (prepared
-    ahead in the next contexts) once the queues before them are empty -- the way bench.py runs its steps; results are
-    fetched DL steps after the launch.  Every step's results (points, counters, objective, max violation, best restart)
-    must equal those of the same step run alone on a fresh engine with the tile-bound kernel: per restart the scheduling
-    changes nothing."""
-    from qcqp_amd import problems
-    n, R, steps, seed, first = 256, 700, 9, 31, 11
-    funcs, _, _ = problems.boolean_least_squares(n, 64, seed=2)
-    ref = []
-    e0 = make(eng_mod, funcs)
-    e0.cd_queue(0)
-    for k in range(steps):
-        e0.randn(R, seed=seed + k, first_index=first)
-        o = e0.cd_run(seed=seed + k, first_index=first)
-        ref.append((e0.download(), o, e0.select_best(1e-4)[:3]))
-    engs = [make(eng_mod, funcs) for _ in range(NC)]
-    for e in engs:
-        e.cd_queue(1)
-    got = {}
-
-    def prepare(e, k):
-        e.randn(R, seed=seed + k, first_index=first)
-        e.cd_begin(phase1=True, seed=seed + k, first_index=first)
-
-    def finish(j):
-        e = engs[j % NC]
-        o = e.cd_fetch()
-        got[j] = (e.download(), o, e.select_best(1e-4)[:3], e.last_cd_kernel())
-    for j in range(min(LA + 1, steps)):
-        prepare(engs[j % NC], j)
-    for k in range(steps):
-        cur = engs[k % NC]
-        for p_ in range(1, LA + 1):
-            cur.cd_chain(engs[(k + p_) % NC] if k + p_ < steps else None, R, seed + k + p_, first, pos=p_)
-        cur.cd_phase2()
-        if k + LA + 1 < steps:
-            prepare(engs[(k + LA + 1) % NC], k + LA + 1)
-        if k >= DL:
-            finish(k - DL)
-    for j in range(max(steps - DL, 0), steps):
-        finish(j)
-    pulled = sum(e.cd_pulled() for e in engs)
-    print('\nchained contexts (%d, depth %d): %d restarts of %d were run ahead by earlier launches' % (NC, LA, pulled, steps * R))
-    for k in range(steps):
-        X, o, b, name = got[k]
-        rX, ro, rb = ref[k]
-        assert name == 'cd_phase2_qs_kernel', (k, name)
-        assert rel(X, rX) < 1e-12, k
-        for key in ('sweeps1', 'sweeps2', 'visits2', 'accepted2', 'ran_phase2', 'status1', 'status2'):
-            assert np.array_equal(o[key], ro[key]), (k, key)
-        assert rel(o['f0'], ro['f0']) < 1e-12 and np.array_equal(o['maxviol'], ro['maxviol']), k
-        assert b[0] == rb[0] and abs(b[1] - rb[1]) <= 1e-12 * (1 + abs(rb[1])), k
-
-
-def test_cd_ring_scheme_equals_serial_runs():
-    """The scheme `python bench.py` reports on one GPU: ONE persistent cd_phase2_qs_kernel launch on 192 CUs serves the populations of
-    four contexts in turn (qcqpmi_cd_ring_start / submit / collect / stop).  Run in a child process -- the HIP
-    runtime must be started with GPU_MAX_HW_QUEUES > 4, which cannot be changed in this process any more -- with a time limit:
-    the first steps must equal the same steps made one after the other with the tile-bound kernel (points to 1e-12, counters
-    identical, the same best restart: coord_descent_phase2, qcqp.py:152-178, does not depend on the scheduling), and the run must
-    end (the launch leaves on the host's request)."""
-    import json
-    import subprocess
-    import sys
-    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'ring_bench.py')
-    env = dict(os.environ)
-    env['GPU_MAX_HW_QUEUES'] = '16'
-    pr = subprocess.run([sys.executable, tool, '4096', '16', '4', '192', '4'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
-    lines = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
-    if pr.returncode != 0 and b'CU mask reach' in pr.stderr:
-        pytest.skip('this device offers no even 192-CU partition: ' + pr.stderr.decode().strip().splitlines()[-1][-200:])
-    assert pr.returncode == 0 and lines, pr.stderr.decode()[-500:]
-    rb = json.loads(lines[-1])
-    assert rb['steps_compared'] == 4 and rb['first_steps_equal_serial_tile_bound_kernel'] is True, rb
-    assert rb['best']['maxviol'] < 1e-2 and rb['value'] > 0
-    print('\nring scheme: %.2f ms per step (16 steps after 4 warm-up steps), %.3f of the fp64 peak' % (rb['ms_per_step'], rb['frac']))
