@@ -310,6 +310,43 @@ def secondary_records(device, sdr_full=False):
         del e
     except Exception as ex:
         recs.append({'config': 'configs[4]', 'error': repr(ex)})
+    # configs[4] at FULL size: n = 4096, m = 1024, 137.6 GB of matrices generated on the device, 512 restarts = the share of one
+    # GPU of eight; evaluation of all 1025 functions + phase 1 + gate + phase 2 with 2 sweeps per phase (about 5 s with the generation)
+    try:
+        n, m, R = 4096, 1024, 512
+        t0 = time.perf_counter()
+        form = problems.dense_indefinite_generated(n, m, seed=7)
+        e = Engine(form, device=device)
+        e.sync()
+        t_gen = time.perf_counter() - t0
+        e.upload(0.1 * np.random.RandomState(0).randn(n, R))
+        e.eval()
+        ev_ms = e.kernel_ms(Engine.KERNEL_EVAL)
+        t0 = time.perf_counter()
+        out = e.cd_run(phase1=True, num_iters=2, seed=1)
+        e.sync()
+        dt = time.perf_counter() - t0
+        fl = 2.0 * (m + 1) * n * n
+        s1, s2 = float(out['sweeps1'].sum()), float(out['visits2'].sum()) / n
+        ms1, ms2 = e.kernel_ms(Engine.KERNEL_CD1), e.kernel_ms(Engine.KERNEL_CD2)
+        recs.append({'config': 'BASELINE.json configs[4] at FULL size: dense indefinite QCQP n = 4096, m = 1024 (137.6 GB of fp64 matrices generated '
+                               'on the device in %.1f s), 512 restarts (the share of one GPU of eight), COORD_DESCENT with 2 sweeps per phase' % t_gen,
+                     'metric': 'restarts x coord-sweeps / s (phase 1 + phase 2)', 'value': (s1 + s2) / dt, 'unit': 'restart-sweeps/s',
+                     'wall_s': dt, 'kernel': e.last_cd_kernel(), 'feasible': int((out['maxviol'] < 1e-2).sum()), 'restarts': R,
+                     'evaluation': {'kernel_ms': ev_ms, 'achieved': fl * R / 1e12 / (ev_ms / 1e3), 'frac': fl * R / 1e12 / (ev_ms / 1e3) / FP64_PEAK_TFLOPS,
+                                    'note': 'all 1025 quadratic forms of 512 candidates (dense_products_kernel<1>); one pass over the matrices from HBM '
+                                            'would take 17.2 ms'},
+                     'roofline': {'bound': 'mfma', 'kernel': 'dense_products_kernel<0> + ' + e.last_cd_kernel(),
+                                  'achieved': fl * s2 / 1e12 / (ms2 / 1e3) if ms2 > 0 else None, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': fl * s2 / 1e12 / (ms2 / 1e3) / FP64_PEAK_TFLOPS if ms2 > 0 else None,
+                                  'frac_phase1': fl * s1 / 1e12 / (ms1 / 1e3) / FP64_PEAK_TFLOPS if ms1 > 0 else None,
+                                  'algorithmic_flops_per_restart_sweep': fl,
+                                  'timing': 'HIP events around the sweep loops of phase 2 (frac) and phase 1 (frac_phase1): block products on the '
+                                            'matrix cores + chain kernels; the chip sustains 47 TFLOP/s = 0.60 of the data-sheet peak on pure fp64 '
+                                            'MFMA loops of this length (profiles/r01_fp64_mfma_sustained.md)'}})
+        del e
+    except Exception as ex:
+        recs.append({'config': 'configs[4] at full size', 'error': repr(ex)[:300]})
     if sdr_full:
         try:
             n, m = 4096, 1024
