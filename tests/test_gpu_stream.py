@@ -163,3 +163,38 @@ def test_cd_stream_run_refuses_other_families(eng_mod):
     e = make(eng_mod, funcs)
     with pytest.raises(eng_mod.EngineError, match='lifecycle'):
         e.cd_stream_run(2, 32)
+
+
+@pytest.mark.parametrize('K,R,iters,p1', [(3, 1, 1000, True),       # single-restart populations (the reference's own use)
+                                           (1, 5, 1000, True),       # fewer restarts than slots of one workgroup
+                                           (2, 33, 0, True),         # num_iters = 0: no sweep of either phase
+                                           (2, 40, 50, False)])      # random starts without phase 1: nothing passes the gate
+def test_cd_stream_run_edge_shapes(eng_mod, K, R, iters, p1):
+    """Degenerate shapes of a streamed run against the serial path: populations of one restart, fewer restarts than a workgroup has
+    slots, num_iters = 0 (qcqp.py:110, 160: no sweep at all -- the result is the start, evaluated), phase1 = False on random starts
+    (qcqp.py:186-189: the gate keeps every restart out of phase 2; objective and max violation of the untouched start come from the
+    kernel's frozen sweep)."""
+    from qcqp_amd import problems
+    n = 48
+    funcs, _, _ = problems.boolean_least_squares(n, 16, seed=4)
+    e = make(eng_mod, funcs)
+    es = make(eng_mod, funcs)
+    o = es.cd_stream_run(K, R, phase1=p1, num_iters=iters, seed=21, seed_stride=5, first_index=3, first_stride=1000)
+    X = es.download()
+    f0e, mve = es.eval()
+    assert rel(o['f0'], f0e) < 1e-11 and np.max(np.abs(o['maxviol'] - mve)) < 1e-12
+    for p in range(K):
+        sd, fi = 21 + 5 * p, 3 + 1000 * p
+        e.randn(R, seed=sd, first_index=fi)
+        X0 = e.download()
+        outr = e.cd_run(phase1=p1, num_iters=iters, seed=sd, first_index=fi)
+        Xr = e.download()
+        sl = slice(p * R, (p + 1) * R)
+        assert rel(X[:, sl], Xr) < 1e-12, p
+        for key in COUNTERS:
+            assert np.array_equal(o[key][sl], outr[key]), (p, key)
+        assert rel(o['f0'][sl], outr['f0']) < 1e-11
+        if iters == 0 or not p1:
+            assert np.array_equal(X[:, sl], X0) and not o['sweeps2'][sl].any()
+        idx = e.select_best(1e-4)[0]
+        assert o['best_index'][p] == idx
