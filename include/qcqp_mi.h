@@ -266,7 +266,7 @@ int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);     /* 0 off, 1 on wherever it a
  * spin-waiting launch for several contexts.  They needed GPU_MAX_HW_QUEUES > 4, worked on the 192-CU partition only and could
  * stall; qcqpmi_cd_stream_run below does what they were after inside ONE self-contained launch.) */
 /* debug (after qcqpmi_debug_profile enabled profiling): tick sums (s_memtime, 100 MHz) over the workgroups of the last
- * qcqpmi_cd_stream_run launch -- [0] column build (suggest + phase 1 + gate), [1] whole launch, [2] episodes, [3] columns built, [4] the normals' share of [0] */
+ * qcqpmi_cd_stream_run launch -- [0] column build (suggest + phase 1 + gate), [1] whole launch, [2] episodes, [3] columns built, [4] the normals' share of [0], [5] the roles of the episodes (the rest: write-out, queue, refill) */
 int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out8);
 /* POPULATION STREAMING (round 4) -- the reference's user loop `for ...: suggest(); improve(COORD_DESCENT)` (README.md:51-57)
  * for K populations of R restarts in ONE persistent launch: a workgroup owns 16 restart slots; a slot that becomes free draws
@@ -340,8 +340,9 @@ int qcqpmi_comm_select_best(qcqpmi_ctx *ctx, double tol, int64_t index_offset,
                             int64_t *best_global_index, double *best_f0, double *best_maxviol,
                             double *best_x);
 int qcqpmi_comm_barrier(qcqpmi_ctx *ctx);
-/* in-place all-reduce of up to 4 host doubles; op 0 = max, 1 = sum (bench.py: max-over-ranks
- * step time, sum-over-ranks work counters) */
+/* in-place all-reduce of host doubles (RCCL all-reduce of a device copy); op 0 = max, 1 = sum (bench.py: max-over-ranks
+ * step time, sum-over-ranks work counters; the exchange of a streamed run: the table of the local winners' keys of all
+ * populations, then the table of the winners' points -- qcqp_amd.dist.global_best_of_populations) */
 int qcqpmi_comm_allreduce(qcqpmi_ctx *ctx, double *values, int64_t count, int op);
 
 #ifdef __cplusplus

@@ -156,7 +156,8 @@ struct qcqpmi_ctx {
     // comm
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    double *d_comm = nullptr;
+    double *d_comm = nullptr, *d_comm_big = nullptr;
+    int64_t comm_big_cap = 0;
     long long *d_prof = nullptr;
     int cd_stage = 0;                   // qcqpmi_cd_run_stage: last stage completed of a split run
     int64_t Xi_cap = 0;                 // doubles reserved for the standard normals of pop_sdr_sample
@@ -695,7 +696,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     free_population(c);
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
-    void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm,   // d_gP is in prob_allocs
+    void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm, c->d_comm_big,   // d_gP is in prob_allocs
                     c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key, c->d_bestK_x};
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -1671,13 +1672,23 @@ int qcqpmi_comm_barrier(qcqpmi_ctx *c) {
 }
 
 int qcqpmi_comm_allreduce(qcqpmi_ctx *c, double *values, int64_t count, int op) {
-    if (!c || !values || count < 1 || count > 4 || op < 0 || op > 1) return QCQPMI_EINVAL;
+    if (!c || !values || count < 1 || count > ((int64_t)1 << 28) || op < 0 || op > 1) return QCQPMI_EINVAL;
     if (!c->comm) return fail(c, QCQPMI_ESTATE, "comm_init has not been called");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->d_comm, values, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(c, rccl()->AllReduce(c->d_comm, c->d_comm, (size_t)count, ncclDouble, op == 0 ? ncclMax : ncclSum,
-                                 c->comm, c->stream));
-    HIPCHK(c, hipMemcpyAsync(values, c->d_comm, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    double *buf = c->d_comm;
+    if (count > 4) {      // the exchange of a streamed run (keys of all populations, then the winners' points): a buffer of its own
+        if (count > c->comm_big_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_comm_big) (void)hipFree(c->d_comm_big);
+            c->d_comm_big = nullptr; c->comm_big_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_comm_big, (size_t)count * sizeof(double)));
+            c->comm_big_cap = count;
+        }
+        buf = c->d_comm_big;
+    }
+    HIPCHK(c, hipMemcpyAsync(buf, values, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, rccl()->AllReduce(buf, buf, (size_t)count, ncclDouble, op == 0 ? ncclMax : ncclSum, c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(values, buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -42,7 +42,7 @@ struct CdLife {
     int *status1;                // [Rtotal] phase-1 status
     uint8_t *ran2;               // [Rtotal] passed the gate (qcqp.py:189)
     long long *prof;             // optional [8]: ticks (s_memtime) summed over the workgroups -- 0 column build, 1 whole launch, 2 episodes,
-                                 // 3 columns built, 4 the normals' share of 0; nullptr: off
+                                 // 3 columns built, 4 the normals' share of 0, 5 the roles (episodes proper); nullptr: off
 };
 
 struct CdQueueArgs {

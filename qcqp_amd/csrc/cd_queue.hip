@@ -372,6 +372,7 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
             }
         }
         __syncthreads();
+        if (LIFE && tid == 0 && qs_g(lifep)->prof) *(long long *)(ctl + 6) = (long long)__builtin_amdgcn_s_memtime();     // (stashed in LDS: not a register of the chain wave)
 
         // ================================================================ episode: the roles of cd_phase2_q_kernel
         if (wave == 4) {
@@ -815,6 +816,8 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
         }
 
         __syncthreads();
+        if (LIFE && tid == 0 && qs_g(lifep)->prof)
+            atomicAdd((unsigned long long *)qs_g(lifep)->prof + 5, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - *(long long *)(ctl + 6)));
         // ================================================================ write out the slots that finished
         {
             // max violation of the final points, same expression as eval_kernel: (p x + q) x + r of the one constraint

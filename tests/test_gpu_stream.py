@@ -198,3 +198,31 @@ def test_cd_stream_run_edge_shapes(eng_mod, K, R, iters, p1):
             assert np.array_equal(X[:, sl], X0) and not o['sweeps2'][sl].any()
         idx = e.select_best(1e-4)[0]
         assert o['best_index'][p] == idx
+
+
+def test_streamed_run_exchange_over_rccl_one_rank(eng_mod):
+    """The exchange of a streamed run through the library's RCCL communicator (one rank: the only size a one-GPU box offers --
+    the N-rank logic is the CPU test test_global_best_of_populations_two_ranks): dist.global_best_of_populations with
+    Engine.comm_allreduce as its all-reduce returns the local winners unchanged, and qcqpmi_comm_allreduce moves tables far
+    beyond the four scalars it was limited to (keys of all populations, K x n points)."""
+    from qcqp_amd import dist, problems
+    funcs, _, _ = problems.boolean_least_squares(64, 16, seed=7)
+    e = make(eng_mod, funcs)
+    dist.init_rccl(e, 0, 1)
+    K, R = 6, 50
+    o = e.cd_stream_run(K, R, seed=3, seed_stride=1)
+    big = np.arange(20000, dtype=np.float64)
+    assert np.array_equal(e.comm_allreduce(big.copy(), 'sum'), big) and np.array_equal(e.comm_allreduce(big.copy(), 'max'), big)
+    calls = []
+
+    def allreduce(a):
+        calls.append(a.size)
+        return e.comm_allreduce(a, 'sum')
+    # world = 1 skips the exchange; force the two all-reduces through RCCL by calling them the way a rank of a larger job does
+    keys = np.zeros((1, K, 3))
+    keys[0, :, 0], keys[0, :, 1], keys[0, :, 2] = o['best_f0'], o['best_maxviol'], o['best_index']
+    kk = allreduce(keys.ravel().copy()).reshape(1, K, 3)
+    xx = allreduce(o['best_x'].ravel().copy()).reshape(K, -1)
+    assert calls == [K * 3, K * 64] and np.array_equal(kk, keys) and np.array_equal(xx, o['best_x'])
+    ks, X = dist.global_best_of_populations(allreduce, 0, 1, o['best_f0'], o['best_maxviol'], o['best_index'], o['best_x'])
+    assert [k[0] for k in ks] == list(o['best_index']) and np.array_equal(X, o['best_x'])

@@ -44,8 +44,8 @@ def main():
     pr = np.zeros(8, dtype=np.int64)
     es.L.qcqpmi_debug_life_profile(es.h, pr.ctypes.data_as(C.POINTER(C.c_int64)))
     es.L.qcqpmi_debug_profile(es.h, ((128 | (cs << 8)) << 4) if cs >= 0 else 0, None)
-    print('profile: column build %.1f %% of the workgroups\' time (normals %.1f %%); %d episodes, %d columns' % (
-        100.0 * pr[0] / max(pr[1], 1), 100.0 * pr[4] / max(pr[1], 1), pr[2], pr[3]))
+    print('profile: column build %.1f %% of the workgroups\' time (normals %.1f %%), roles %.1f %%, write-out / queue / idle at the end %.1f %%; %d episodes, %d columns' % (
+        100.0 * pr[0] / max(pr[1], 1), 100.0 * pr[4] / max(pr[1], 1), 100.0 * pr[5] / max(pr[1], 1), 100.0 * (pr[1] - pr[0] - pr[5]) / max(pr[1], 1), pr[2], pr[3]))
     X = es.download()
     print('kernels:', ref[0][3], '/', es.last_cd_kernel())
     worst = 0.0
