@@ -502,3 +502,122 @@ def test_global_best_of_populations_two_ranks():
     # one rank: no exchange at all
     ks, Xs = dist.global_best_of_populations(None, 0, 1, f0[0], mv[0], gi[0], xs[0])
     assert [k[0] for k in ks] == list(gi[0]) and np.array_equal(Xs, xs[0])
+
+
+BENCH_WORKER = r'''
+import json, os, sys, types
+sys.path.insert(0, %(repo)r)
+import numpy as np
+from qcqp_amd import dist
+import qcqp_amd.engine as engine_mod
+
+BOOT = {}
+
+
+class FakeEngine(object):
+    """Stands in for qcqp_amd.engine.Engine on a box without a GPU: deterministic synthetic results per (rank, step, restart),
+    the collectives over the job's file rendezvous -- everything bench.py does AROUND the kernels runs for real."""
+    KERNEL_EVAL, KERNEL_CD1, KERNEL_CD2, KERNEL_SDR, KERNEL_ADMM = 0, 1, 2, 3, 4
+
+    def __init__(self, form, device=0):
+        self.n, self.device = form.n, device
+        self.calls = []
+
+    def comm_init(self, rank, world, uid):
+        pass
+
+    def comm_unique_id(self):
+        return np.zeros(128, dtype=np.uint8)
+
+    def cd_stream_run(self, K, R, seed=0, seed_stride=1, first_index=0, first_stride=0, **kw):
+        self.calls.append((K, R, seed, first_index))
+        T = K * R
+        rs = np.random.RandomState(seed %% 100000 + 7 * first_index)
+        o = dict(sweeps1=np.ones(T, dtype=np.int64), visits2=np.full(T, 10 * self.n, dtype=np.int64), f0=rs.rand(T) + 5.0,
+                 maxviol=np.zeros(T))
+        o['best_index'] = np.array([int(np.argmin(o['f0'][p * R:(p + 1) * R])) for p in range(K)], dtype=np.int64)
+        o['best_f0'] = np.array([o['f0'][p * R + o['best_index'][p]] for p in range(K)])
+        o['best_maxviol'] = np.zeros(K)
+        o['best_x'] = np.tile(o['best_f0'][:, None], (1, self.n))
+        return o
+
+    def kernel_ms(self, which):
+        return 1.0
+
+    def last_cd_kernel(self):
+        return 'cd_phase2_qs_kernel<lifecycle>'
+
+    def sync(self):
+        pass
+
+    def comm_allreduce(self, values, op='max'):
+        v = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)))
+        parts = BOOT['b'].allgather([float(a) for a in v])
+        out = np.max(np.array(parts), axis=0) if op == 'max' else np.sum(np.array(parts), axis=0)
+        v[...] = out
+        return v
+
+    def comm_barrier(self):
+        BOOT['b'].barrier()
+
+
+def fake_init_rccl(engine, rank, world, bootstrap=None):
+    if 'b' not in BOOT:
+        BOOT['b'] = dist.FileRendezvous(rank, world)
+    return BOOT['b']
+
+
+engine_mod.Engine = FakeEngine
+dist.init_rccl = fake_init_rccl
+sys.argv = [os.path.abspath(__file__), '--gpus', '2', '--steps', '3',      # (the self-spawned rank 1 re-runs THIS script)
+             '--warmup', '1', '--n', '32', '--m-rows', '8', '--restarts', '16',
+            '--no-secondary', '--no-cpu-baseline']
+import bench
+sys.exit(bench.main())
+'''
+
+
+@pytest.mark.parametrize('launch', ['self_spawn', 'launcher'])
+def test_bench_two_ranks_control_flow(tmp_path, launch):
+    """bench.py --gpus 2 with a FAKE engine (no GPU here): the self-spawn of rank 1 -- or two processes started the way the
+    driver's `python -m torch.distributed.run --nproc-per-node 2` starts them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment) --, the scheme decision taken identically on both ranks (one all-reduce), the streamed run per rank with the
+    rank's own global restart indices, the exchange of a streamed run over the ranks (dist.global_best_of_populations through
+    the engine's all-reduce), the max / sum reductions of the timing and work counters, ONE JSON line on rank 0 -- everything
+    around the kernels runs for real; the collectives travel over the job's file rendezvous instead of RCCL."""
+    import json
+    import subprocess
+    script = tmp_path / 'bench_worker.py'
+    script.write_text(BENCH_WORKER % dict(repo=REPO))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'QCQP_AMD_RDZV')}
+    if launch == 'self_spawn':
+        pr = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=str(tmp_path))
+        assert pr.returncode == 0, pr.stderr.decode()[-2000:]
+        out = pr.stdout.decode()
+    else:
+        procs = []
+        for r in range(2):
+            e2 = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29%03d' % (os.getpid() % 1000),
+                      TORCHELASTIC_RUN_ID='t%d' % os.getpid())
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=e2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(tmp_path)))
+        outs = [p_.communicate(timeout=300) for p_ in procs]
+        assert all(p_.returncode == 0 for p_ in procs), [o_[1].decode()[-1500:] for o_ in outs]
+        assert not [l for l in outs[1][0].decode().splitlines() if l.startswith('{')]      # only rank 0 prints the line
+        out = outs[0][0].decode()
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['config']['scheme'] == 'stream' and d['scaling'] == 'weak'
+    # both ranks ran 3 steps of 16 restarts with 10 sweeps each: the whole-job value counts both
+    assert abs(d['value'] * d['timed_region_s'] - 2 * 3 * 16 * 10) < 1e-6
+    assert d['phase2_sweeps_per_restart'] == 10.0
+    # the best point of the job: the smaller of the two ranks' winners, with its GLOBAL restart index (rank 1 owns 16..31)
+    best = None
+    for rank in range(2):
+        rs = np.random.RandomState((2024 % 100000) + 7 * (16 * rank))
+        f = rs.rand(3 * 16) + 5.0
+        for p in range(3):
+            i = int(np.argmin(f[p * 16:(p + 1) * 16]))
+            cand = (float(f[p * 16 + i]), 16 * rank + i, p)
+            best = cand if best is None or cand[0] < best[0] else best
+    assert abs(d['best']['objective'] - best[0]) < 1e-12 and d['best']['global_restart_index'] == best[1] and d['best']['step'] == best[2]
