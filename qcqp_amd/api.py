@@ -272,6 +272,10 @@ class QCQP(object):
             self.engine.cd_reference_order(bool(kwargs.get('reference_order', False)))
             first_index = int(kwargs.get('first_index', 0))
             batches = getattr(self, '_batches', None) if self._resident_batches() else None
+            if batches is None and self.engine.pop_size >= 8192 and not kwargs.get('reference_order', False):
+                # one large population: more restarts than the chip has slots -- the lifecycle launch (phase 1, gate, phase 2
+                # and the evaluation inside one kernel) beats the separate launches from about two generations on; same restarts
+                batches = (1, self.engine.pop_size, first_index)
             out = None
             if batches is not None:
                 # population streaming: K batches of R restarts in ONE persistent launch (qcqpmi_cd_stream_run); families the
@@ -287,7 +291,7 @@ class QCQP(object):
             if out is None:
                 out = self.engine.cd_run(phase1=phase1, num_iters=num_iters, viol_tol=viol_tol, tol=tol,
                                          seed=seed, first_index=first_index)
-            if batches is not None:
+            if batches is not None and getattr(self, '_batches', None) is not None and self._resident_batches():
                 from .dist import select_best_host
                 Kb, Rb, _ = batches
                 self.batch_results = []

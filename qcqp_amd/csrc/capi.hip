@@ -1448,7 +1448,7 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
     if (cs >= NBq) cs = 0;
     cs &= ~1;
-    if (NBq - cs > RQ_NSIMD * RQ_MAXU || NBq < 3) return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: n = %lld outside the slot-queue kernel's range", (long long)c->n);
+    if (NBq - cs > RQ_NSIMD * RQ_MAXU || NBq < 3) return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: n = %lld outside the range of the lifecycle kernel (n <= 1024, at least 3 blocks of 16)", (long long)c->n);
     if (!c->d_qnext && (rc = dev_alloc(c, &c->d_qnext, 16))) return rc;
     if (!c->d_life) HIPCHK(c, hipMalloc((void **)&c->d_life, sizeof(CdLife)));
     HIPCHK(c, hipMemsetAsync(c->d_qnext, 0, 16 * sizeof(int), c->stream));

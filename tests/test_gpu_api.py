@@ -507,3 +507,26 @@ def rel_eq_forms(form, funcs):
         if not (np.array_equal(Pf, np.asarray(P)) and np.array_equal(np.ravel(f.qarray), np.ravel(q)) and f.r == r and f.relop == relop):
             return False
     return True
+
+
+def test_large_population_takes_the_lifecycle_launch():
+    """improve(COORD_DESCENT) on ONE population of 8192 restarts (two generations of the chip's 4096 slots) runs as a lifecycle
+    launch (phase 1, gate, phase 2, evaluation in one kernel) -- the same restarts as the separate launches: equal points and
+    (f, v), checked against the engine's serial path on the same starts."""
+    from qcqp_amd import QCQP, COORD_DESCENT, RANDOM, problems
+    from qcqp_amd.form import QCQPForm
+    funcs, _, _ = problems.boolean_least_squares(128, 40, seed=8)
+    form = QCQPForm.from_arrays(funcs)
+    q = QCQP(form)
+    q.suggest(RANDOM, num_samples=8192, seed=4)
+    X0 = q.population()
+    f, v = q.improve(COORD_DESCENT, seed=9)
+    assert q.engine.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
+    X = q.population()
+    q2 = QCQP(form)
+    q2.engine.upload(X0)
+    out = q2.engine.cd_run(phase1=True, seed=9)
+    assert q2.engine.last_cd_kernel() != 'cd_phase2_qs_kernel<lifecycle>'
+    assert np.max(np.abs(X - q2.engine.download())) < 1e-12
+    idx, fb, vb, xb = q2.engine.select_best(1e-4)
+    assert q.best_index == idx and abs(f - fb) <= 1e-11 * (1 + abs(fb)) and abs(v - vb) <= 1e-12
