@@ -235,6 +235,20 @@ def test_population_best_vs_oracle(eng_mod, orc, family):
     # ---- the fast (MFMA) path against that counterpart: a distribution statement (see the docstring)
     qg, qo = np.percentile(f0, [25, 50, 75]), np.percentile(fo, [25, 50, 75])
     assert np.all(np.abs(qg - qo) <= 0.05 * (qo[2] - qo[0]) + 0.02 * np.abs(qo)), (qg, qo)
+    # the yardstick for `off`: how many of the ORACLE's restarts leave the oracle's own trajectory when x0 moves by one ulp
+    # (the reference's arithmetic under the smallest possible input change; see tests/test_host_cpu.py and
+    # profiles/r04_reference_sensitivity.md for the same experiment with /root/reference)
+    Rs = min(R, 96)
+    dref = np.zeros(Rs)
+    for r in range(Rs):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(first + r)
+        xp = prob.improve_cd(np.nextafter(X0[:, r], np.inf), num_iters=iters, rng=rng)[0]
+        dref[r] = np.max(np.abs(xp - Xo[:, r])) / (1 + np.max(np.abs(Xo[:, r])))
+    off_ref = float(np.mean(dref > 1e-6))
+    print('%s: the oracle against itself under one ulp of x0: %.1f %% of %d restarts leave the trajectory (1e-6); the MFMA path against the '
+          'oracle: %.1f %%' % (family, 100 * off_ref, Rs, 100 * off))
+    assert off <= off_ref + 0.25, (off, off_ref)      # the fast path leaves the oracle no more often than the oracle leaves itself
     if family.startswith('dense'):
         assert off < 0.75, off
         assert ig == io, (ig, io)
