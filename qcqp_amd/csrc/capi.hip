@@ -1440,7 +1440,11 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     if (!generate && c->R != K * R) return fail(c, QCQPMI_EINVAL, "cd_stream_run: the resident population has %lld points, K R = %lld", (long long)c->R, (long long)(K * R));
     HIPCHK(c, hipSetDevice(c->device));
     if (generate && (rc = pop_reserve(c, K * R))) return rc;
-    if (!cd_queue_eligible(c, false))
+    const int queue_switch = c->cd_queue;
+    c->cd_queue = 2;                                   // (qcqpmi_cd_queue chooses the phase-2 kernel of qcqpmi_cd_run; it does not apply here)
+    const bool eligible = cd_queue_eligible(c, false);
+    c->cd_queue = queue_switch;
+    if (!eligible)
         return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernel needs the Boolean family (one mirrored equality class on a positive "
                     "diagonal, n a multiple of 16, n <= 1024): use qcqpmi_cd_run per population");
     const int NBq = (int)(c->n16 / 16);

@@ -107,6 +107,82 @@ __device__ inline void p1_sep_visit_core(int mf, const double (&cp)[MAXC], const
         }
 }
 
+// The same visit for the constraint class the pipelined kernels are built for -- ONE constraint p x^2 + r == 0 on the
+// coordinate, p > 1e-4, no linear term ("band": |f| <= s is a <= |x| <= b) -- with the generic machinery of onevar.h resolved
+// by hand: feasible_intervals' two intervals_le calls + their pairwise intersection, feasible_set_single's merge / drop rules
+// and onevar_minimise's zero-objective branch, each expression the one the generic code evaluates on the same values in the
+// same order (the lifecycle kernel runs this one, cd_phase1_sep_kernel the generic one: the GPU tests compare the two bit for
+// bit on millions of visits).  q is passed although it is zero: the generic expressions contain it.
+__device__ inline void p1_band_visit(double p, double q, double r, int64_t i, double &xi, double tol, double viol_tol, uint64_t seed,
+                                     uint64_t grestart, int64_t t, P1Visit &V) {
+    V.visited = true; V.moved = false; V.status = 0;
+    const double viol = fabs(xi * (p * xi + q) + r);
+    double new_xi = xi, new_viol = viol;
+    double ss = -tol, es = viol - viol_tol, sp = 0.0;
+    uint32_t it = 0, itp = 0;
+    bool pending = false;
+    while (es - ss > tol) {
+        const double s = (ss + es) / 2.0;
+        const uint32_t itb = it++;
+        const double D1 = 0.0 - 4.0 * p * (r - s);
+        const double D2 = 0.0 - 4.0 * (-p) * (-r - s);
+        const bool nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
+        if (!nonempty) { ss = s; continue; }
+        sp = s; itp = itb; pending = true;
+        new_viol = s; es = s;
+    }
+    if (pending) {
+        // feasible_intervals(p, q, r, ==, sp): A = {f - s <= 0} (convex: at most one interval), B = {-f - s <= 0} (concave: two rays, or the line)
+        const double r1 = r - sp, r2 = -r - sp;
+        const double rsA = r1 - 0.0, rsB = r2 - 0.0;
+        const double DA = q * q - 4.0 * p * rsA;
+        const bool hasA = DA >= 0.0;
+        const double rDA = sqrt(hasA ? DA : 0.0);
+        const double alo = (-q - rDA) / (2.0 * p), ahi = (-q + rDA) / (2.0 * p);
+        const double pB = -p, qB = -q;
+        const double DB = qB * qB - 4.0 * pB * rsB;
+        const bool twoB = DB >= 0.0;
+        const double rDB = sqrt(twoB ? DB : 0.0);
+        const double bhi0 = twoB ? (-qB + rDB) / (2.0 * pB) : QM_INF;       // B = (-inf, bhi0] u [blo1, +inf), or the whole line
+        const double blo1 = (-qB - rDB) / (2.0 * pB);
+        // pairwise intersections in the reference's (i, j) order: (A, first piece of B), (A, second piece of B)
+        const double l0 = alo > -QM_INF ? alo : -QM_INF, h0 = ahi < bhi0 ? ahi : bhi0;
+        const bool ok0 = hasA && l0 <= h0;
+        const double l1 = alo > blo1 ? alo : blo1, h1 = ahi < QM_INF ? ahi : QM_INF;
+        const bool ok1 = hasA && twoB && l1 <= h1;
+        int n = (ok0 ? 1 : 0) + (ok1 ? 1 : 0);
+        double lo0 = ok0 ? l0 : (ok1 ? l1 : 0.0), hi0 = ok0 ? h0 : (ok1 ? h1 : 0.0);
+        double lo1 = (ok0 && ok1) ? l1 : 0.0, hi1 = (ok0 && ok1) ? h1 : 0.0;
+        // feasible_set_single: identical intervals vanish, touching ones merge, zero-width ones and ones that end at +inf are dropped
+        if (n == 2 && lo0 == lo1 && hi0 == hi1) n = 0;
+        else if (n == 2 && hi0 == lo1) { hi0 = hi1; n = 1; }
+        else if (n == 2 && hi1 == lo0) { lo0 = lo1; n = 1; }
+        const bool k0 = n >= 1 && lo0 != hi0 && hi0 != QM_INF;
+        const bool k1 = n >= 2 && lo1 != hi1 && hi1 != QM_INF;
+        if (k0 && k1 && lo1 < lo0) {
+            double tt;
+            tt = lo0; lo0 = lo1; lo1 = tt;
+            tt = hi0; hi0 = hi1; hi1 = tt;
+        }
+        const int cn = (k0 ? 1 : 0) + (k1 ? 1 : 0);
+        const double c0lo = k0 ? lo0 : lo1, c0hi = k0 ? hi0 : hi1;      // first kept interval; the second one is (lo1, hi1) when both are kept
+        // onevar_minimise with the objective identically zero: a uniform point of a random interval (utilities.py:266-267)
+        int got = 0;
+        double xn = xi;
+        if (cn > 0) {
+            const U4 rnd = cd_draw(seed, grestart, (uint32_t)i, (uint32_t)t, itp);
+            const int c = draw_choice(rnd, cn);
+            const double lo = (c == 1) ? lo1 : c0lo, hi = (c == 1) ? hi1 : c0hi;
+            if (__builtin_isinf(lo) || __builtin_isinf(hi)) got = -1;
+            else { xn = draw_uniform(rnd, lo, hi); got = 1; }
+        }
+        if (got == 1) new_xi = xn;
+        else { new_viol = viol; if (got < 0) V.status = got; }
+    }
+    if (new_viol < viol) { xi = new_xi; V.moved = true; }
+    V.vafter = fabs((p * xi + q) * xi + r);
+}
+
 template <int MAXC>
 __device__ inline void p1_sep_visit(const DevProblem &P, int64_t i, double &xi, double tol, double viol_tol, uint64_t seed,
                                     uint64_t grestart, int64_t t, P1Visit &V) {

@@ -105,10 +105,14 @@ __device__ __attribute__((noinline)) double qs_keyed_normal_pair(uint64_t seed, 
 __device__ __attribute__((noinline)) double qs_p1_visit(double p, double q, double r, int relop, int64_t i, double x, double tol,
                                                         double viol_tol, uint64_t seed, uint64_t restart, int64_t t, int *flags,
                                                         double *vafter) {
-    const double cp[1] = {p}, cq[1] = {q}, cr[1] = {r};
-    const int crel[1] = {relop};
     P1Visit V;
-    p1_sep_visit_core<1>(1, cp, cq, cr, crel, i, x, tol, viol_tol, seed, restart, t, V);
+    if (q == 0.0 && relop == RELOP_EQ && p > 1e-4) {
+        p1_band_visit(p, q, r, i, x, tol, viol_tol, seed, restart, t, V);      // the class of the headline family, resolved by hand
+    } else {
+        const double cp[1] = {p}, cq[1] = {q}, cr[1] = {r};
+        const int crel[1] = {relop};
+        p1_sep_visit_core<1>(1, cp, cq, cr, crel, i, x, tol, viol_tol, seed, restart, t, V);
+    }
     *flags = (V.moved ? 1 : 0) | ((-V.status) << 8);
     *vafter = V.vafter;
     return x;
