@@ -261,11 +261,6 @@ const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *ctx);
  * next restart from a device-side queue (cd_phase2_qs_kernel, csrc/cd_queue.hip).  Per restart the same arithmetic; results
  * do not depend on the scheduling (every product is summed in one association).  qcqpmi_last_cd_kernel names the kernel. */
 int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);     /* 0 off, 1 on wherever it applies, 2 (default) auto: more tiles than CUs */
-/* Kernel behind qcqpmi_cd_stream_run: 1 (default) cd_wave_kernel -- one wavefront per restart, the gradient P0 x + q/2 kept
- * in registers and updated by one row of P0 per accepted move (one product on the matrix cores per restart instead of one
- * per sweep); 0 the slot-queue kernel cd_phase2_qs_kernel (a product per block of 16 coordinates and sweep).  Same visits,
- * same decisions (qcqp.py:152-178); the two differ by the rounding of the gradient (accumulated vs summed afresh). */
-int qcqpmi_cd_stream_kernel(qcqpmi_ctx *ctx, int mode);
 /* (ABI 4 removed the round-3 experiments around that kernel -- qcqpmi_cd_chain, qcqpmi_cd_partition, qcqpmi_cd_ring_start /
  * submit / collect / stop: launches that ran restarts of other contexts' populations, a CU-masked stream, one persistent
  * spin-waiting launch for several contexts.  They needed GPU_MAX_HW_QUEUES > 4, worked on the 192-CU partition only and could

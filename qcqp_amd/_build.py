@@ -19,7 +19,6 @@ UNITS = {
                  'cd_phase2.h', 'cd_phase2_rs.h', 'cd_phase2_q.h', 'admm.h', 'admm_fused.h', 'cd_queue.h', 'gemm_pk.h', 'cd_general.h', 'cd_dense.h', 'cd_dense_mw.h',
                  'sdr_solve.h'],
     'admm_fused.hip': ['admm_fused.hip', 'admm_fused.h', 'onevar.h', 'philox.h'],
-    'cd_wave.hip': ['cd_wave.hip', 'cd_queue.h', 'cd_phase1_sep.h', 'cd_phase2.h', 'kernels.h', 'onevar.h', 'philox.h'],
     'cd_queue.hip': ['cd_queue.hip', 'cd_queue.h', 'cd_phase2_q.h', 'cd_phase2_rs.h', 'cd_phase2.h', 'kernels.h', 'onevar.h', 'philox.h'],
 }
 SOURCES = sorted(set(sum(UNITS.values(), [])))

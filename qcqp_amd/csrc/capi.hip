@@ -174,7 +174,6 @@ struct qcqpmi_ctx {
     const char *last_admm_kernel = "";    // "admm_fused_kernel" / "admm_multi_launch"
     int last_admm_C = 0;                  // workgroups per tile of the last fused run
     long long af_prof[16] = {0};          // stage cycle counters of the last fused run (when qcqpmi_debug_profile enabled them)
-    int cd_stream_kernel = 1;             // qcqpmi_cd_stream_kernel: 1 wave-per-restart kernel with the incremental gradient (cd_wave_kernel), 0 slot-queue kernel
     int cd_queue = 2;                     // qcqpmi_cd_queue: 0 off, 1 restart-level scheduling (cd_phase2_qs_kernel) wherever it applies,
                                           // 2 auto: when there are more tiles than CUs
     int *d_qnext = nullptr;               // [0] queue head of the slot-queue kernel
@@ -1441,22 +1440,19 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     if (!generate && c->R != K * R) return fail(c, QCQPMI_EINVAL, "cd_stream_run: the resident population has %lld points, K R = %lld", (long long)c->R, (long long)(K * R));
     HIPCHK(c, hipSetDevice(c->device));
     if (generate && (rc = pop_reserve(c, K * R))) return rc;
-    // the Boolean family: one mirrored equality class on a positive diagonal (the class the pipelined kernels are built for)
-    const bool family = !c->force_generic && !(c->dbg & 64) && c->sep && c->maxc <= 1 && c->K == 1 && c->objclass == 1 && c->symcls && c->n % 16 == 0;
-    const bool wave_kernel = family && c->cd_stream_kernel == 1 && cd_wave_lds_bytes(c->dp) != 0;
     const int queue_switch = c->cd_queue;
     c->cd_queue = 2;                                   // (qcqpmi_cd_queue chooses the phase-2 kernel of qcqpmi_cd_run; it does not apply here)
-    const bool eligible = wave_kernel || cd_queue_eligible(c, false);
+    const bool eligible = cd_queue_eligible(c, false);
     c->cd_queue = queue_switch;
     if (!eligible)
-        return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernels need the Boolean family (one mirrored equality class on a positive "
+        return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernel needs the Boolean family (one mirrored equality class on a positive "
                     "diagonal, n a multiple of 16, n <= 1024): use qcqpmi_cd_run per population");
     const int NBq = (int)(c->n16 / 16);
     int cs = (c->dbg & 128) ? ((c->dbg >> 8) & 7) : 4;
     cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
     if (cs >= NBq) cs = 0;
     cs &= ~1;
-    if (!wave_kernel && (NBq - cs > RQ_NSIMD * RQ_MAXU || NBq < 3)) return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: n = %lld outside the range of the slot-queue kernel (n <= 1024, at least 3 blocks of 16)", (long long)c->n);
+    if (NBq - cs > RQ_NSIMD * RQ_MAXU || NBq < 3) return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: n = %lld outside the range of the lifecycle kernel (n <= 1024, at least 3 blocks of 16)", (long long)c->n);
     if (!c->d_qnext && (rc = dev_alloc(c, &c->d_qnext, 16))) return rc;
     if (!c->d_life) HIPCHK(c, hipMalloc((void **)&c->d_life, sizeof(CdLife)));
     HIPCHK(c, hipMemsetAsync(c->d_qnext, 0, 16 * sizeof(int), c->stream));
@@ -1480,11 +1476,11 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     int cus = 0;
     HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     (void)hipEventRecord(c->timers[2].beg, c->stream);
-    hipError_t qe = wave_kernel ? (hipError_t)cd_wave_launch(qa, c->stream) : (hipError_t)cd_queue_launch(qa, cs, cus, c->stream);
+    hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, c->stream);
     (void)hipEventRecord(c->timers[2].end, c->stream);
     c->timers[2].valid = true;
     if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_stream_run: %s", hipGetErrorString(qe));
-    c->last_cd2_kernel = wave_kernel ? "cd_wave_kernel" : "cd_phase2_qs_kernel<lifecycle>";
+    c->last_cd2_kernel = "cd_phase2_qs_kernel<lifecycle>";
     c->cd_stage = 0;
     c->evaluated = true;                   // d_f0 / d_mv hold the values of the final points
     std::vector<int> st, st1;
@@ -1579,12 +1575,6 @@ const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel
 int qcqpmi_cd_queue(qcqpmi_ctx *c, int mode) {
     if (!c || mode < 0 || mode > 2) return QCQPMI_EINVAL;
     c->cd_queue = mode;
-    return 0;
-}
-
-int qcqpmi_cd_stream_kernel(qcqpmi_ctx *c, int mode) {
-    if (!c || mode < 0 || mode > 1) return QCQPMI_EINVAL;
-    c->cd_stream_kernel = mode;
     return 0;
 }
 

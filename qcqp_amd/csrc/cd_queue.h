@@ -61,11 +61,4 @@ size_t cd_queue_lds_bytes(const DevProblem &P);
 // launches ceil(R / 16) workgroups at most `max_wgs`; cs = blocks of the contraction the chain wave multiplies (0, 2, 4, 6)
 int cd_queue_launch(const CdQueueArgs &a, int cs, int max_wgs, hipStream_t st);
 
-// cd_wave_kernel (cd_wave.hip): the same lifecycle run (a.life, a.b as in lifecycle mode) with one wavefront per restart and
-// an incremental gradient -- one product on the matrix cores per restart, then one row of P0 per move.
-// LDS bytes (0: n not a multiple of 16 or beyond 1024)
-size_t cd_wave_lds_bytes(const DevProblem &P);
-// launches ceil(a.b.R / 16) workgroups of 16 waves
-int cd_wave_launch(const CdQueueArgs &a, hipStream_t st);
-
 }  // namespace qcqpmi

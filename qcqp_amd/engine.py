@@ -378,12 +378,6 @@ class Engine(object):
         a device-side queue (cd_phase2_qs_kernel)."""
         self._chk(self.L.qcqpmi_cd_queue(self.h, int(mode)))
 
-    def cd_stream_kernel(self, mode=1):
-        """Kernel behind cd_stream_run: 1 (default) = cd_wave_kernel (one wavefront per restart, incremental gradient: one
-        product on the matrix cores per restart, one row of P0 per accepted move), 0 = the slot-queue kernel
-        cd_phase2_qs_kernel (a product per block and sweep)."""
-        self._chk(self.L.qcqpmi_cd_stream_kernel(self.h, int(mode)))
-
     def cd_reference_order(self, enable=True):
         """Coupled constraints: coordinate descent in the reference's summation order (slow, value-for-value comparable with
         the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Lifecycle (population-streaming) run against K serial suggest(RANDOM) + improve(COORD_DESCENT) calls: points, counters,
-objective, best restart; and its rate.  Usage: python tools/stream_check.py [n] [R] [K] [num_iters] [cs] [stream kernel]"""
+objective, best restart; and its rate.  Usage: python tools/stream_check.py [n] [R] [K] [num_iters]"""
 import sys
 import time
 
@@ -18,7 +18,6 @@ def main():
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     iters = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
     cs = int(sys.argv[5]) if len(sys.argv) > 5 else -1      # experiments: blocks of the contraction the chain wave multiplies (default 4)
-    sk = int(sys.argv[6]) if len(sys.argv) > 6 else 1       # 1: cd_wave_kernel (default), 0: slot-queue kernel
     funcs, _, _ = problems.boolean_least_squares(n, max(4, n // 4), seed=1)
     form = QCQPForm.from_arrays(funcs)
     e = Engine(form)
@@ -29,7 +28,6 @@ def main():
         out = e.cd_run(phase1=True, num_iters=iters, seed=seed0 + p, first_index=first0 + p * fstride)
         ref.append((e.download(), out, e.select_best(), e.last_cd_kernel()))
     es = Engine(form)
-    es.cd_stream_kernel(sk)
     if cs >= 0:
         es.L.qcqpmi_debug_profile(es.h, (128 | (cs << 8)) << 4, None)
     for rep in range(3):
