@@ -1475,7 +1475,6 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     qa.b.R = K * R;
     int cus = 0;
     HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    if (getenv("QCQPMI_MAX_WGS")) cus = atoi(getenv("QCQPMI_MAX_WGS"));   // EXPERIMENT
     (void)hipEventRecord(c->timers[2].beg, c->stream);
     hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, c->stream);
     (void)hipEventRecord(c->timers[2].end, c->stream);
