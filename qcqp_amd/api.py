@@ -18,7 +18,7 @@ import logging
 import numpy as np
 
 from . import settings as s
-from .engine import Engine, EngineError
+from .engine import E_UNSUPPORTED, Engine, EngineError
 from .form import QCQPForm
 
 # module logger (the reference configures the ROOT logger at import, qcqp.py:39, and logs per iteration; this engine
@@ -285,7 +285,7 @@ class QCQP(object):
                     out = self.engine.cd_stream_run(Kb, Rb, generate=False, phase1=phase1, num_iters=num_iters, viol_tol=viol_tol,
                                                     tol=tol, seed=seed, seed_stride=0, first_index=first_index, first_stride=Rb)
                 except EngineError as ex:
-                    if 'lifecycle' not in str(ex):
+                    if ex.code != E_UNSUPPORTED:     # (QCQPMI_EUNSUPPORTED: not the family of the lifecycle kernel)
                         raise
                     log.info('coord_descent: %s', ex)
             if out is None:

@@ -9,7 +9,15 @@ from .form import RELOP_CODE
 
 
 class EngineError(Exception):
-    pass
+    """An entry point of libqcqp_mi.so returned an error; `code` is the QCQPMI_E* value (include/qcqp_mi.h)."""
+    code = 0
+
+    def __init__(self, message, code=0):
+        Exception.__init__(self, message)
+        self.code = int(code)
+
+
+E_UNSUPPORTED = -4     # QCQPMI_EUNSUPPORTED
 
 
 def _dp(a):
@@ -51,7 +59,7 @@ class Engine(object):
     # ------------------------------------------------------------------ plumbing
     def _chk(self, rc):
         if rc:
-            raise EngineError(self.L.qcqpmi_last_error(self.h).decode())
+            raise EngineError(self.L.qcqpmi_last_error(self.h).decode(), rc)
 
     def close(self):
         if getattr(self, 'h', None):
