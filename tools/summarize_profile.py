@@ -101,7 +101,7 @@ if os.path.exists(bj) and os.path.getsize(bj):
     out['bench_under_profiler'] = json.load(open(bj))
 hdr = ['# rocprofv3 summary %s' % tag, '',
        'Command: `python bench.py --scheme stream --steps 20 --warmup 20 --no-cpu-baseline --no-secondary` (tools/profile_round.sh):',
-       'two launches of `cd_phase2_qs_kernel<4, 3>` (the lifecycle mode of the slot-queue kernel), each = 20 steps of 4096 restarts --',
+       'two launches of `cd_phase2_qs_kernel<4, true>` (the lifecycle mode of the slot-queue kernel), each = 20 steps of 4096 restarts --',
        'suggest, phase 1, gate, phase 2, objective of 81920 restarts inside the launch.',
        'Pass 1 `--kernel-trace --stats`; passes 2-4 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc TCC_HIT_sum TCC_MISS_sum`',
        '(separate runs, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled (gfx950 reports half the bytes of',
