@@ -701,6 +701,7 @@ def main():
 
     launch_ms = None
     if scheme == 'stream':
+        eng.cd_stream_reserve(K, R)      # buffers of the K timed steps (the warm-up ran W steps): no allocation inside the timed region
         eng.sync()
         eng.comm_barrier()
         t0 = time.perf_counter()

@@ -287,6 +287,10 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *ctx, int64_t K, int64_t R, int generate, in
                          double select_tol, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
                          uint8_t *ran_phase2, double *f0, double *maxviol, int64_t *best_index, double *best_f0,
                          double *best_maxviol, double *best_x);
+/* Device and pinned-host buffers for a qcqpmi_cd_stream_run(K, R) to come (population, per-restart outputs, per-population
+ * winners): allocation only, so that a timed or latency-sensitive run does not start with hipMalloc / hipHostMalloc.  A
+ * resident population smaller than K R points is dropped (like any reallocation of the population). */
+int qcqpmi_cd_stream_reserve(qcqpmi_ctx *ctx, int64_t K, int64_t R);
 /* Coordinate descent for constraints that couple coordinates IN THE REFERENCE'S SUMMATION ORDER (test / diagnostic mode, any
  * n): every one-variable coefficient (t2, t1, t0) of get_onevar_func (utilities.py:99-105) is formed by row-sequential sums
  * like the reference's CSR products -- t0 = f_k(z) afresh per coordinate, O((m+1) n^2) per coordinate visit -- so that

@@ -64,6 +64,7 @@ PROTOTYPES = [
     ('qcqpmi_last_cd_kernel', C.c_char_p, [C.c_void_p]),
     ('qcqpmi_cd_reference_order', C.c_int, [C.c_void_p, C.c_int]),
     ('qcqpmi_cd_dense_block_step', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint64, c_dp]),
+    ('qcqpmi_cd_stream_reserve', C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
     ('qcqpmi_cd_stream_run', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
                                        C.c_uint64, C.c_uint64, C.c_double, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp]),
     ('qcqpmi_cd_queue', C.c_int, [C.c_void_p, C.c_int]),

@@ -304,9 +304,9 @@ int pin_reserve(qcqpmi_ctx *c, size_t bytes) {
     return 0;
 }
 
-int fetch_cd_outputs(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
-                     uint8_t *ran_phase2, double *f0, double *maxviol, std::vector<int> &st, std::vector<int> &st1) {
-    const int64_t R = c->R, bytes = 57 * R;
+// staging buffers (device + pinned host) of fetch_cd_outputs for R restarts
+int cd_outputs_reserve(qcqpmi_ctx *c, int64_t R) {
+    const int64_t bytes = 57 * R;
     if (bytes > c->out_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->d_out) (void)hipFree(c->d_out);
@@ -316,6 +316,29 @@ int fetch_cd_outputs(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, int64_t 
         HIPCHK(c, hipHostMalloc((void **)&c->h_out, (size_t)bytes, hipHostMallocDefault));
         c->out_cap = bytes;
     }
+    return 0;
+}
+
+// device buffers of the per-population winners of a streamed run (K populations)
+int cd_bestK_reserve(qcqpmi_ctx *c, int64_t K) {
+    if (K > c->bestK_cap) {
+        if (c->d_bestK_idx) (void)hipFree(c->d_bestK_idx);
+        if (c->d_bestK_key) (void)hipFree(c->d_bestK_key);
+        if (c->d_bestK_x) (void)hipFree(c->d_bestK_x);
+        c->d_bestK_idx = nullptr; c->d_bestK_key = nullptr; c->d_bestK_x = nullptr;
+        HIPCHK(c, hipMalloc((void **)&c->d_bestK_idx, (size_t)K * 2 * sizeof(int64_t)));
+        HIPCHK(c, hipMalloc((void **)&c->d_bestK_key, (size_t)K * 2 * sizeof(double)));
+        HIPCHK(c, hipMalloc((void **)&c->d_bestK_x, (size_t)K * c->n * sizeof(double)));
+        c->bestK_cap = K;
+    }
+    return 0;
+}
+
+int fetch_cd_outputs(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
+                     uint8_t *ran_phase2, double *f0, double *maxviol, std::vector<int> &st, std::vector<int> &st1) {
+    const int64_t R = c->R, bytes = 57 * R;
+    int rco = cd_outputs_reserve(c, R);
+    if (rco) return rco;
     hipLaunchKernelGGL(pack_cd_outputs_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream, c->d_out, R,
                        (const int64_t *)c->d_sweeps1, (const int64_t *)c->d_sweeps, (const int64_t *)c->d_visits,
                        (const int64_t *)c->d_acc, (const double *)c->d_f0, (const double *)c->d_mv,
@@ -1488,16 +1511,7 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     if ((rc = cd_apply_status(c, st, st1, f0, maxviol, 0))) return rc;
     if (best_index || best_f0 || best_maxviol || best_x) {
         // the best restart of every population (QCQPForm.better folded over it, ties -> lowest index)
-        if (K > c->bestK_cap) {
-            if (c->d_bestK_idx) (void)hipFree(c->d_bestK_idx);
-            if (c->d_bestK_key) (void)hipFree(c->d_bestK_key);
-            if (c->d_bestK_x) (void)hipFree(c->d_bestK_x);
-            c->d_bestK_idx = nullptr; c->d_bestK_key = nullptr; c->d_bestK_x = nullptr;
-            HIPCHK(c, hipMalloc((void **)&c->d_bestK_idx, (size_t)K * 2 * sizeof(int64_t)));
-            HIPCHK(c, hipMalloc((void **)&c->d_bestK_key, (size_t)K * 2 * sizeof(double)));
-            HIPCHK(c, hipMalloc((void **)&c->d_bestK_x, (size_t)K * c->n * sizeof(double)));
-            c->bestK_cap = K;
-        }
+        if ((rc = cd_bestK_reserve(c, K))) return rc;
         // one workgroup per population, then one gather of the winners' columns: three launches and three copies whatever K
         hipLaunchKernelGGL(select_best_kernel, dim3((unsigned)K), dim3(1024), 0, c->stream, (const double *)c->d_f0, (const double *)c->d_mv,
                            R, select_tol, c->d_bestK_idx, c->d_bestK_key);
@@ -1519,6 +1533,19 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
             if (best_maxviol) best_maxviol[p] = key[(size_t)2 * p + 1];
         }
     }
+    return 0;
+}
+
+int qcqpmi_cd_stream_reserve(qcqpmi_ctx *c, int64_t K, int64_t R) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (K < 1 || R < 1 || K * R >= (1LL << 30)) return fail(c, QCQPMI_EINVAL, "cd_stream_reserve: bad K / R");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (K * R > c->Rcap) { if ((rc = pop_reserve(c, K * R))) return rc; }       // (a resident population of that size or more stays)
+    if ((rc = cd_outputs_reserve(c, K * R))) return rc;
+    if ((rc = cd_bestK_reserve(c, K))) return rc;
+    if (!c->d_qnext && (rc = dev_alloc(c, &c->d_qnext, 16))) return rc;
+    if (!c->d_life) HIPCHK(c, hipMalloc((void **)&c->d_life, sizeof(CdLife)));
     return 0;
 }
 

@@ -166,6 +166,10 @@ class Engine(object):
         out['status1'], out['status2'] = st1, st2     # != 0: the reference would raise on this restart (f0 = inf)
         return out
 
+    def cd_stream_reserve(self, K, R):
+        """Allocate what cd_stream_run(K, R) needs (population, output staging, winners) ahead of time."""
+        self._chk(self.L.qcqpmi_cd_stream_reserve(self.h, int(K), int(R)))
+
     def cd_stream_run(self, K, R, generate=True, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=0, seed_stride=1,
                       first_index=0, first_stride=0, select_tol=1e-4, want_best_x=True):
         """K populations of R restarts -- suggest(RANDOM) + improve(COORD_DESCENT) + best point each -- in ONE persistent launch

@@ -44,6 +44,8 @@ def test_cd_stream_run_equals_serial_runs(eng_mod, orc, n, m_rows, R, K, iters):
     e = make(eng_mod, funcs)
     es = make(eng_mod, funcs)
     seed0, sstride, first0, fstride = 500, 3, 11, 70000
+    if K > 1:
+        es.cd_stream_reserve(K, R)          # buffers ahead of the run (qcqpmi_cd_stream_reserve): allocation only, same results
     o = es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=sstride, first_index=first0, first_stride=fstride)
     assert es.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
     assert es.pop_size == K * R

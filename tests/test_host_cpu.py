@@ -529,6 +529,9 @@ class FakeEngine(object):
     def comm_unique_id(self):
         return np.zeros(128, dtype=np.uint8)
 
+    def cd_stream_reserve(self, K, R):
+        pass
+
     def cd_stream_run(self, K, R, seed=0, seed_stride=1, first_index=0, first_stride=0, **kw):
         self.calls.append((K, R, seed, first_index))
         T = K * R
