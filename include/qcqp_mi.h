@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QCQPMI_ABI_VERSION 4
+#define QCQPMI_ABI_VERSION 5
 
 enum {
     QCQPMI_OK = 0,
@@ -265,9 +265,14 @@ int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);     /* 0 off, 1 on wherever it a
  * submit / collect / stop: launches that ran restarts of other contexts' populations, a CU-masked stream, one persistent
  * spin-waiting launch for several contexts.  They needed GPU_MAX_HW_QUEUES > 4, worked on the 192-CU partition only and could
  * stall; qcqpmi_cd_stream_run below does what they were after inside ONE self-contained launch.) */
-/* debug (after qcqpmi_debug_profile enabled profiling): tick sums (s_memtime, 100 MHz) over the workgroups of the last
- * qcqpmi_cd_stream_run launch -- [0] column build (suggest + phase 1 + gate), [1] whole launch, [2] episodes, [3] columns built, [4] the normals' share of [0], [5] the roles of the episodes (the rest: write-out, queue, refill) */
-int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out8);
+/* debug (after qcqpmi_debug_profile enabled profiling): tick sums (s_memtime) over the workgroups of the last
+ * qcqpmi_cd_stream_run launch, SIXTEEN entries (ABI 5; 8 before) -- [0] column build (suggest + phase 1 + gate), [1] whole launch,
+ * [2] episodes, [3] columns built, [4] the normals' share of [0], [5] the roles of the episodes (the rest: write-out, queue,
+ * refill); cd_life_kernel only: [6] workgroups whose waves covered the four SIMDs evenly, [8] the chain waves' wait for
+ * partial tiles, [9] / [10] multiplying wave 0's waits for a commit / for its slot, [11] block intervals, [12] blocks with a
+ * near-tie replay, [13] / [14] / [15] / [7] the chain's stages: sum of the partial tiles + requests, the 16 steps, block end +
+ * commit, fix-up + own share + staging */
+int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out16);
 /* POPULATION STREAMING (round 4) -- the reference's user loop `for ...: suggest(); improve(COORD_DESCENT)` (README.md:51-57)
  * for K populations of R restarts in ONE persistent launch: a workgroup owns 16 restart slots; a slot that becomes free draws
  * the next restart index of the run and runs that restart's WHOLE step itself -- suggest(RANDOM) (qcqp.py:381-382; the keyed
@@ -280,8 +285,18 @@ int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out8);
  * relative).  generate = 0: the K R resident points (qcqpmi_pop_upload) are the starts instead of normals.  Outputs: per-restart
  * arrays of K R entries (population-major; may be NULL) as in qcqpmi_cd_run, and per population the best restart (index within
  * the population, QCQPForm.better ordering with bucket width select_tol), its objective, max violation and point (K x n).
- * The K R final points stay resident (qcqpmi_pop_download).  Boolean family only (the headline kernel's: one mirrored equality
- * class on a positive diagonal, n a multiple of 16, n <= 1024): QCQPMI_EUNSUPPORTED otherwise. */
+ * The K R final points stay resident (qcqpmi_pop_download).
+ * Round 5 (ABI 5): the launch is cd_life_kernel (csrc/cd_life.hip) -- four-wave workgroups, two per CU, the X tile in a private
+ * global tile instead of LDS -- and takes every problem with separable constraints of ONE class, one constraint per coordinate
+ * (Boolean / MAXCUT x_i^2 == 1, box and disc x_i^2 <= c, one-sided and linear single-coordinate constraints), a diagonal of P0
+ * that is positive everywhere or ZERO everywhere (MAXCUT: qcqp.py:152-178 with a linear scalar objective), any 48 <= n <= 2048
+ * (n need not be a multiple of 16; 1024 < n <= 2048 runs eight-wave workgroups).  QCQPMI_EUNSUPPORTED otherwise (several
+ * classes, several constraints per coordinate, mixed diagonal signs, coupled constraints): use qcqpmi_cd_run per population;
+ * a refused call leaves the resident population untouched.  K R < 2^30 (restart tickets are 32-bit; QCQPMI_EINVAL beyond).
+ * Near-ties: a restart whose decision is within rounding of a tie is replayed in the reference's arithmetic like in
+ * qcqpmi_cd_run; for a positive diagonal the replay sees the objective RELATIVE to the start of phase 2 (the constant of its
+ * scalar objective differs from the reference's by f0 at that start: candidates closer than one ulp of f0 may resolve
+ * differently; exact ties do not), for a zero diagonal the absolute objective (evaluated by an extra frozen sweep). */
 int qcqpmi_cd_stream_run(qcqpmi_ctx *ctx, int64_t K, int64_t R, int generate, int phase1, int64_t num_iters, double viol_tol,
                          double tol, uint64_t seed, uint64_t seed_stride, uint64_t first_index, uint64_t first_stride,
                          double select_tol, int64_t *sweeps1, int64_t *sweeps2, int64_t *visits2, int64_t *accepted2,
@@ -291,6 +306,10 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *ctx, int64_t K, int64_t R, int generate, in
  * winners): allocation only, so that a timed or latency-sensitive run does not start with hipMalloc / hipHostMalloc.  A
  * resident population smaller than K R points is dropped (like any reallocation of the population). */
 int qcqpmi_cd_stream_reserve(qcqpmi_ctx *ctx, int64_t K, int64_t R);
+/* Which lifecycle kernel qcqpmi_cd_stream_run launches: 2 (default) cd_life_kernel wherever it applies, else the round-4 kernel;
+ * 1: the round-4 kernel only (cd_phase2_qs_kernel<lifecycle>: Boolean family, n a multiple of 16, n <= 1024) -- kept as the
+ * cross-check of the new one (tests/test_gpu_life.py). */
+int qcqpmi_cd_life_version(qcqpmi_ctx *ctx, int version);
 /* Coordinate descent for constraints that couple coordinates IN THE REFERENCE'S SUMMATION ORDER (test / diagnostic mode, any
  * n): every one-variable coefficient (t2, t1, t0) of get_onevar_func (utilities.py:99-105) is formed by row-sequential sums
  * like the reference's CSR products -- t0 = f_k(z) afresh per coordinate, O((m+1) n^2) per coordinate visit -- so that

@@ -3,6 +3,7 @@
 Several translation units, compiled in parallel and only when one of their sources changed (the big one takes two
 minutes): objects under qcqp_amd/_obj/ (git-ignored), linked into qcqp_amd/libqcqp_mi.so."""
 import os
+import re
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
 
@@ -13,14 +14,31 @@ OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(HERE, 'libqcqp_mi.so')
 HEADER = os.path.join(REPO, 'include', 'qcqp_mi.h')
 
-# translation unit -> everything it includes (rebuilt when any of these is newer than its object)
-UNITS = {
-    'capi.hip': ['capi.hip', 'capi_admm.inc', 'capi_units.inc', 'capi_dense.inc', 'kernels.hip', 'kernels.h', 'onevar.h', 'philox.h',
-                 'cd_phase2.h', 'cd_phase2_rs.h', 'cd_phase2_q.h', 'admm.h', 'admm_fused.h', 'cd_queue.h', 'gemm_pk.h', 'cd_general.h', 'cd_dense.h', 'cd_dense_mw.h',
-                 'sdr_solve.h'],
-    'admm_fused.hip': ['admm_fused.hip', 'admm_fused.h', 'onevar.h', 'philox.h'],
-    'cd_queue.hip': ['cd_queue.hip', 'cd_queue.h', 'cd_phase2_q.h', 'cd_phase2_rs.h', 'cd_phase2.h', 'kernels.h', 'onevar.h', 'philox.h'],
-}
+# translation units; what each one includes is found by scanning its `#include "..."` lines recursively (round 4 shipped a
+# hand-kept list that missed a header: an edit to it rebuilt nothing)
+TRANSLATION_UNITS = ['capi.hip', 'admm_fused.hip', 'cd_queue.hip', 'cd_life.hip']
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _scan(path, seen):
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return
+    seen.add(path)
+    with open(path) as f:
+        text = f.read()
+    for inc in _INC.findall(text):
+        _scan(os.path.join(os.path.dirname(path), inc), seen)
+
+
+def unit_sources(unit):
+    """Absolute paths of every file the translation unit is built from (itself, headers, .inc files, the C ABI header)."""
+    seen = set()
+    _scan(os.path.join(SRC, unit), seen)
+    return sorted(seen)
+
+
+UNITS = {u: [os.path.relpath(p, SRC) for p in unit_sources(u)] for u in TRANSLATION_UNITS}
 SOURCES = sorted(set(sum(UNITS.values(), [])))
 
 
@@ -36,7 +54,7 @@ def _stale(target, deps):
 
 
 def _unit_deps(unit):
-    return [os.path.join(SRC, s) for s in UNITS[unit]] + [HEADER]
+    return unit_sources(unit) + [HEADER]
 
 
 def needs_build():

@@ -18,6 +18,7 @@
 #include "admm.h"
 #include "admm_fused.h"
 #include "cd_queue.h"
+#include "cd_life.h"
 #include "gemm_pk.h"
 #include "cd_general.h"
 #include "cd_dense.h"
@@ -179,6 +180,13 @@ struct qcqpmi_ctx {
     int *d_qnext = nullptr;               // [0] queue head of the slot-queue kernel
     bool q_prepared = false;              // the queue of the resident population has been reset
     CdLife *d_life = nullptr;    // qcqpmi_cd_stream_run: parameters of the lifecycle launch
+    // second-generation lifecycle kernel (cd_life.h): the workgroups' X tiles, the staged diagonal blocks, the watchdog word
+    int Kreal = 0;               // constraint classes among the REAL coordinates (the padded ones of n16 carry no constraint)
+    double fbound = 0.0;         // sum |P0| + sum |q0| + |r0|
+    double *l2_scratch = nullptr; size_t l2_scratch_cap = 0;
+    double *l2_D = nullptr, *l2_S = nullptr;
+    int *l2_abort = nullptr;
+    int life_version = 2;        // qcqpmi_cd_life_version: 2 = cd_life_kernel where it applies, 1 = cd_phase2_qs_kernel<lifecycle> only
     long long *d_life_prof = nullptr;
     int64_t *d_bestK_idx = nullptr; double *d_bestK_key = nullptr, *d_bestK_x = nullptr; int64_t bestK_cap = 0;
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
@@ -720,7 +728,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm, c->d_comm_big,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key, c->d_bestK_x};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key, c->d_bestK_x, c->l2_scratch, c->l2_D, c->l2_S, c->l2_abort};
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -906,6 +914,12 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
                 allzero = allzero && d == 0.0;
             }
             c->objclass = allpos ? 1 : (allzero ? 2 : 0);
+            double fb = fabs(h.r);
+            for (int64_t i = 0; i < n; i++) {
+                fb += fabs(q[(size_t)i]);
+                for (int64_t j = 0; j < n; j++) fb += fabs(P[(size_t)i * n16 + j]);
+            }
+            c->fbound = fb;
         }
         double *ap = nullptr;
         if ((rc = dev_alloc(c, &ap, (size_t)n16 * n16, false))) return rc;
@@ -991,6 +1005,12 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
             }
             dp.K = (int)krep.size();
             c->K = dp.K;
+            {
+                std::vector<char> seen(krep.size(), 0);
+                int kr = 0;
+                for (int64_t i = 0; i < n; i++) if (!seen[(size_t)cls[i]]) { seen[(size_t)cls[i]] = 1; kr++; }
+                c->Kreal = kr;
+            }
             c->symcls = false;
             if (dp.K == 1 && maxc == 1) {
                 const int e0 = cptr[krep[0]];
@@ -1452,6 +1472,26 @@ int qcqpmi_cd_dense_block_step(qcqpmi_ctx *c, int phase, int64_t sweep, int64_t 
     return cd_dense_block_step(c, phase, sweep, block, coord_lo, coord_hi, viol_tol, tol, seed, first_index, slack);
 }
 
+// buffers of cd_life_kernel: the workgroups' X tiles, the staged diagonal blocks (packed once per problem), the watchdog word
+static int cd_life2_reserve(qcqpmi_ctx *c, int nmw, int cus) {
+    int rc;
+    const size_t need = (size_t)cd_life2_max_wgs(nmw, cus) * (size_t)c->n16 * 16;
+    if (need > c->l2_scratch_cap) {
+        if (c->l2_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0; }
+        if ((rc = dev_alloc(c, &c->l2_scratch, need))) return rc;
+        c->l2_scratch_cap = need;
+    }
+    if (!c->l2_abort && (rc = dev_alloc(c, &c->l2_abort, 4))) return rc;
+    if (!c->l2_D) {
+        const size_t NB = (size_t)(c->n16 / 16);
+        if ((rc = dev_alloc(c, &c->l2_D, NB * 256))) return rc;
+        if ((rc = dev_alloc(c, &c->l2_S, NB * 48))) return rc;
+        hipError_t e = (hipError_t)cd_life2_pack(c->dp, c->l2_D, c->l2_S, c->stream);
+        if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_life2_pack: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
 // ---- lifecycle run: K populations of R restarts through ONE persistent slot-queue launch (cd_queue.h, CdLife)
 int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int phase1, int64_t num_iters, double viol_tol, double tol,
                          uint64_t seed, uint64_t seed_stride, uint64_t first_index, uint64_t first_stride, double select_tol,
@@ -1462,20 +1502,27 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     if (K < 1 || R < 1 || num_iters < 0 || !(tol > 0.0) || K * R >= (1LL << 30)) return fail(c, QCQPMI_EINVAL, "cd_stream_run: bad K / R / num_iters / tol");
     if (!generate && c->R != K * R) return fail(c, QCQPMI_EINVAL, "cd_stream_run: the resident population has %lld points, K R = %lld", (long long)c->R, (long long)(K * R));
     HIPCHK(c, hipSetDevice(c->device));
+    // ---- which kernel (decided BEFORE the resident population is touched: a refused call leaves the context as it was)
+    int nmw = 0, cs2 = 0, kind = 0;
+    const bool use2 = c->life_version >= 2 && !c->force_generic && !(c->dbg & 64) && c->sep &&
+                      cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, &nmw, &cs2, &kind);
+    int cs = 0;
+    if (!use2) {
+        const int queue_switch = c->cd_queue;
+        c->cd_queue = 2;                                   // (qcqpmi_cd_queue chooses the phase-2 kernel of qcqpmi_cd_run; it does not apply here)
+        const bool eligible = cd_queue_eligible(c, false);
+        c->cd_queue = queue_switch;
+        if (!eligible)
+            return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernels need separable constraints of ONE class with one constraint per "
+                        "coordinate, a diagonal of P0 that is positive everywhere or zero everywhere, and 48 <= n <= 2048: use qcqpmi_cd_run per population");
+        const int NBq = (int)(c->n16 / 16);
+        cs = (c->dbg & 128) ? ((c->dbg >> 8) & 7) : 4;
+        cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
+        if (cs >= NBq) cs = 0;
+        cs &= ~1;
+        if (NBq - cs > RQ_NSIMD * RQ_MAXU || NBq < 3) return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: n = %lld outside the range of cd_phase2_qs_kernel (n <= 1024, at least 3 blocks of 16)", (long long)c->n);
+    }
     if (generate && (rc = pop_reserve(c, K * R))) return rc;
-    const int queue_switch = c->cd_queue;
-    c->cd_queue = 2;                                   // (qcqpmi_cd_queue chooses the phase-2 kernel of qcqpmi_cd_run; it does not apply here)
-    const bool eligible = cd_queue_eligible(c, false);
-    c->cd_queue = queue_switch;
-    if (!eligible)
-        return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernel needs the Boolean family (one mirrored equality class on a positive "
-                    "diagonal, n a multiple of 16, n <= 1024): use qcqpmi_cd_run per population");
-    const int NBq = (int)(c->n16 / 16);
-    int cs = (c->dbg & 128) ? ((c->dbg >> 8) & 7) : 4;
-    cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
-    if (cs >= NBq) cs = 0;
-    cs &= ~1;
-    if (NBq - cs > RQ_NSIMD * RQ_MAXU || NBq < 3) return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: n = %lld outside the range of the lifecycle kernel (n <= 1024, at least 3 blocks of 16)", (long long)c->n);
     if (!c->d_qnext && (rc = dev_alloc(c, &c->d_qnext, 16))) return rc;
     if (!c->d_life) HIPCHK(c, hipMalloc((void **)&c->d_life, sizeof(CdLife)));
     HIPCHK(c, hipMemsetAsync(c->d_qnext, 0, 16 * sizeof(int), c->stream));
@@ -1485,25 +1532,53 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     L.sweeps1 = c->d_sweeps1; L.status1 = c->d_status1; L.ran2 = c->d_flag;
     L.prof = nullptr;
     if (c->profile) {      // qcqpmi_debug_profile: tick sums of the launch (qcqpmi_debug_life_profile)
-        if (!c->d_life_prof) HIPCHK(c, hipMalloc((void **)&c->d_life_prof, 8 * sizeof(long long)));
-        HIPCHK(c, hipMemsetAsync(c->d_life_prof, 0, 8 * sizeof(long long), c->stream));
+        if (!c->d_life_prof) HIPCHK(c, hipMalloc((void **)&c->d_life_prof, 16 * sizeof(long long)));
+        HIPCHK(c, hipMemsetAsync(c->d_life_prof, 0, 16 * sizeof(long long), c->stream));
         L.prof = c->d_life_prof;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_life, &L, sizeof(L), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));       // (L lives on this stack frame)
-    CdQueueArgs qa;
-    qa.P = c->dp; qa.num_iters = num_iters; qa.tol = tol;
-    qa.life = c->d_life; qa.life_on = 1;
-    cd_queue_fill_batch(c, qa.b, seed, first_index);
-    qa.b.R = K * R;
     int cus = 0;
     HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    (void)hipEventRecord(c->timers[2].beg, c->stream);
-    hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, c->stream);
-    (void)hipEventRecord(c->timers[2].end, c->stream);
-    c->timers[2].valid = true;
-    if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_stream_run: %s", hipGetErrorString(qe));
-    c->last_cd2_kernel = "cd_phase2_qs_kernel<lifecycle>";
+    if (use2) {
+        if ((rc = cd_life2_reserve(c, nmw, cus))) return rc;
+        int64_t wgs = (K * R + 15) / 16;
+        const int maxw = cd_life2_max_wgs(nmw, cus);
+        if (wgs > maxw) wgs = maxw;
+        if (c->dbg & 1024) { const int lim = (c->dbg >> 12) & 1023; if (lim > 0 && wgs > lim) wgs = lim; }     // debug knob: workgroups of the launch
+        CdLife2Args qa;
+        qa.P = c->dp; qa.num_iters = num_iters; qa.tol = tol; qa.life = c->d_life;
+        cd_queue_fill_batch(c, qa.b, seed, first_index);
+        qa.b.R = K * R;
+        qa.scratch = c->l2_scratch; qa.Dpack = c->l2_D; qa.Spack = c->l2_S; qa.abort = c->l2_abort; qa.fbound = c->fbound;
+        if (c->dbg & 128) { const int k2 = (c->dbg >> 8) & 7; if (nmw == 3 && (k2 == 0 || k2 == 2 || k2 == 4) && k2 < (int)(c->n16 / 16)) cs2 = k2; }
+        (void)hipEventRecord(c->timers[2].beg, c->stream);
+        hipError_t qe = (hipError_t)cd_life2_launch(qa, nmw, cs2, kind, (int)wgs, c->stream);
+        (void)hipEventRecord(c->timers[2].end, c->stream);
+        c->timers[2].valid = true;
+        if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_stream_run: %s", hipGetErrorString(qe));
+        c->last_cd2_kernel = cd_life2_name(nmw, kind);
+        int ab = 0;
+        HIPCHK(c, hipMemcpyAsync(&ab, c->l2_abort, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (ab) {
+            HIPCHK(c, hipMemsetAsync(c->l2_abort, 0, sizeof(int), c->stream));
+            c->R = 0;
+            return fail(c, QCQPMI_EHIP, "cd_stream_run: a wait inside cd_life_kernel ran into its watchdog (internal error; no results)");
+        }
+    } else {
+        CdQueueArgs qa;
+        qa.P = c->dp; qa.num_iters = num_iters; qa.tol = tol;
+        qa.life = c->d_life; qa.life_on = 1;
+        cd_queue_fill_batch(c, qa.b, seed, first_index);
+        qa.b.R = K * R;
+        (void)hipEventRecord(c->timers[2].beg, c->stream);
+        hipError_t qe = (hipError_t)cd_queue_launch(qa, cs, cus, c->stream);
+        (void)hipEventRecord(c->timers[2].end, c->stream);
+        c->timers[2].valid = true;
+        if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_stream_run: %s", hipGetErrorString(qe));
+        c->last_cd2_kernel = "cd_phase2_qs_kernel<lifecycle>";
+    }
     c->cd_stage = 0;
     c->evaluated = true;                   // d_f0 / d_mv hold the values of the final points
     std::vector<int> st, st1;
@@ -1546,16 +1621,21 @@ int qcqpmi_cd_stream_reserve(qcqpmi_ctx *c, int64_t K, int64_t R) {
     if ((rc = cd_bestK_reserve(c, K))) return rc;
     if (!c->d_qnext && (rc = dev_alloc(c, &c->d_qnext, 16))) return rc;
     if (!c->d_life) HIPCHK(c, hipMalloc((void **)&c->d_life, sizeof(CdLife)));
+    {
+        int nmw = 0, cs2 = 0, kind = 0, cus = 0;
+        HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        if (c->life_version >= 2 && c->sep && cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, &nmw, &cs2, &kind) && (rc = cd_life2_reserve(c, nmw, cus))) return rc;
+    }
     return 0;
 }
 
-int qcqpmi_debug_life_profile(qcqpmi_ctx *c, int64_t *out8) {
-    if (!c || !out8) return QCQPMI_EINVAL;
-    for (int k = 0; k < 8; k++) out8[k] = 0;
+int qcqpmi_debug_life_profile(qcqpmi_ctx *c, int64_t *out16) {
+    if (!c || !out16) return QCQPMI_EINVAL;
+    for (int k = 0; k < 16; k++) out16[k] = 0;
     if (!c->d_life_prof) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out8, c->d_life_prof, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out16, c->d_life_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1598,6 +1678,12 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 }
 
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
+
+int qcqpmi_cd_life_version(qcqpmi_ctx *c, int version) {
+    if (!c || version < 1 || version > 2) return QCQPMI_EINVAL;
+    c->life_version = version;
+    return 0;
+}
 
 int qcqpmi_cd_queue(qcqpmi_ctx *c, int mode) {
     if (!c || mode < 0 || mode > 2) return QCQPMI_EINVAL;

@@ -1,0 +1,1142 @@
+// cd_life_kernel -- improve_coord_descent (qcqp.py:181-192) for a queue of restarts inside one persistent launch, second
+// generation (round 5).  What it computes, restart by restart, is what cd_phase2_qs_kernel<CS, LIFE = true> (cd_queue.hip)
+// computes -- suggest(RANDOM) / resident start, phase 1 through cd_phase1_sep.h, gate, the blocked Gauss-Seidel phase 2 of
+// cd_phase2_q.h with its near-tie replay in the reference's arithmetic, the objective from the converged window -- and the
+// EPISODE structure is the same (16 slots per workgroup; at a sweep boundary finished slots are written out and refilled from
+// the queue; products are always summed in one association so that results do not depend on the episode boundaries).
+// What is new is the layout of the work on the chip (cd_life.h): four-wave workgroups, two per CU, roles by hardware SIMD,
+// the X tile in a private global tile with a ring of the four blocks committed last in LDS, every multiplying wave
+// computes EVERY product over its own blocks of the contraction, the chain wave stages its own small operands; plus the
+// generalisations: n not a multiple of 16, 1024 < n <= 2048 with six multiplying waves, step kinds for single classes
+// with up to two intervals and for a zero diagonal.
+#include "cd_life.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "onevar.h"
+#include "cd_phase1_sep.h"
+
+namespace qcqpmi {
+typedef double v4d __attribute__((ext_vector_type(4)));
+template <typename XPtr>
+__device__ inline v4d block_rows_times_X(const double *__restrict__ Ab, XPtr Xs, int kk0, int kk1, int lane, v4d acc) {
+    const int xoff = (lane >> 4) * 16 + (lane & 15);
+    for (int kk = kk0; kk < kk1; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[(int64_t)kk * 64 + lane], Xs[kk * 64 + xoff], acc, 0, 0, 0);
+    return acc;
+}
+}  // namespace qcqpmi
+
+#include "cd_phase2_q.h"      // rq_quad_*, RqOwn, rq_block / rq_slot, the LDS flag protocol, RQ_PFU / RQ_RND / RQ_PERS / RQ_MAXU
+
+namespace qcqpmi {
+namespace {
+
+#define LG __attribute__((address_space(1)))
+template <class T>
+__device__ __attribute__((always_inline)) inline LG T *l2_g(T *p) { return (LG T *)p; }
+__device__ inline int l2_load_int(LG const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int l2_add(LG int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ inline unsigned long long l2_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ inline double l2_unkey(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__device__ inline double l2_wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+
+// the scalar code of a restart's start -- same expressions as cd_queue.hip (which has to CALL them: inlined they spilled the
+// product loop of its multiplying waves; here the roles are functions of their own and the kernel body is free to inline)
+__device__ __attribute__((always_inline)) inline double l2_keyed_normal_pair(uint64_t seed, uint64_t restart, uint64_t elem, double *odd) {
+    const U4 o = philox4x32_10((uint32_t)(elem >> 1), (uint32_t)(elem >> 33), 0xA5A50000u, (uint32_t)restart, (uint32_t)seed,
+                               (uint32_t)(seed >> 32) ^ (uint32_t)(restart >> 32));
+    const double u1 = (((double)(o.x >> 5) * 67108864.0 + (double)(o.y >> 6)) + 0.5) / 9007199254740992.0;
+    const double u2 = u53(o.z, o.w);
+    const double rad = sqrt(-2.0 * log(u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
+    *odd = rad * sin(ang);
+    return rad * cos(ang);
+}
+__device__ __attribute__((always_inline)) inline double l2_p1_visit(double p, double q, double r, int relop, int64_t i, double x, double tol,
+                                                        double viol_tol, uint64_t seed, uint64_t restart, int64_t t, int *flags,
+                                                        double *vafter) {
+    P1Visit V;
+    if (q == 0.0 && relop == RELOP_EQ && p > 1e-4) {
+        p1_band_visit(p, q, r, i, x, tol, viol_tol, seed, restart, t, V);
+    } else {
+        const double cp[1] = {p}, cq[1] = {q}, cr[1] = {r};
+        const int crel[1] = {relop};
+        p1_sep_visit_core<1>(1, cp, cq, cr, crel, i, x, tol, viol_tol, seed, restart, t, V);
+    }
+    *flags = (V.moved ? 1 : 0) | ((-V.status) << 8);
+    *vafter = V.vafter;
+    return x;
+}
+constexpr int L2_WD = 1 << 21;        // polls before a wait gives up (a wait is a few hundred polls at most)
+enum { L2_ABORT = 3 };                // sync word: a watchdog fired in this workgroup
+
+// blocks of the contraction owned by multiplying wave m of NMW (the chain wave keeps the last CS blocks)
+__device__ __attribute__((always_inline)) inline RqOwn l2_own(int NB, int CS, int m, int NMW) {
+    RqOwn o;
+    const int rest = NB - CS;
+    o.NB = NB;
+    if (m < 0) { o.first = rest; o.stride = 1; o.nu = CS; }
+    else { o.first = m; o.stride = NMW; o.nu = m < rest ? (rest - m + NMW - 1) / NMW : 0; }
+    return o;
+}
+
+// chain share: A fragments (pair-packed) of the owned blocks for block row bn -> registers
+template <int NU>
+__device__ __attribute__((always_inline)) inline void l2_load_A(v2d_ (&ar)[2 * NU], LG const double *Apack2, int KS, const RqOwn &o, int lane, int bn) {
+#pragma unroll
+    for (int U = 0; U < NU; U++) {
+        LG const v2d_ *ap = (LG const v2d_ *)Apack2 + ((int64_t)bn * (KS / 2) + 2 * rq_block(o, U)) * 64;
+        ar[2 * U] = ap[(unsigned)lane];
+        ar[2 * U + 1] = ap[64u + (unsigned)lane];
+    }
+}
+template <int NU>
+__device__ __attribute__((always_inline)) inline v4d_ l2_product(v2d_ (&ar)[2 * NU], const double (&bq)[4 * NU], LG const double *Apack2, int KS,
+                                                                 const RqOwn &o, int lane, int hs, int hs2, int bn2, v4d_ acc0) {
+    v4d_ acc = acc0, acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = acc1, acc3 = acc1;
+#pragma unroll
+    for (int U = 0; U < NU; U++) {
+        if (U < o.nu && U != hs && U != hs2) {   // wave-uniform
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U][0], bq[4 * U], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U][1], bq[4 * U + 1], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U + 1][0], bq[4 * U + 2], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[2 * U + 1][1], bq[4 * U + 3], acc3, 0, 0, 0);
+        }
+        {
+            LG const v2d_ *ap = (LG const v2d_ *)Apack2 + ((int64_t)bn2 * (KS / 2) + 2 * rq_block(o, U)) * 64;
+            ar[2 * U] = ap[(unsigned)lane];
+            ar[2 * U + 1] = ap[64u + (unsigned)lane];
+        }
+    }
+    return (acc + acc1) + (acc2 + acc3);
+}
+
+// ---- dynamic LDS of a workgroup (doubles), the same view in the kernel and in the role functions:
+//   part2   2 NMW 256   partial G tiles (one per multiplying wave), [v][4 r + g], by product parity
+//   fixp    256         the chain wave's own plane (fix-up + its share)
+//   gtile   256         G + q/2 of the block as the chain found it, [c][r]: the generic path's tile
+//   DU2     2 x 256     strictly upper triangle of the diagonal block, by interval parity
+//   sc2     2 x 48      per parity: q0 / 2 [16], 1 / P0[i,i] [16], P0[i,i] [16]
+//   ring    4 x 256     the four blocks committed last, [j][r] (= MFMA B layout k-step by k-step)
+//   cshare  CS x 256    the blocks of the chain wave's own share of the contraction, same layout
+//   slot tables (slack, feasible set, restart id, new / finished flags, outputs), sy: the synchronisation words,
+//   cst: the chain wave's per-lane state between episodes [field][lane], phase-1 words, simdof, par
+#define L2_LDS_VIEW \
+    extern __shared__ double smem[]; \
+    double *sp = smem; \
+    double *part2 = sp; sp += 2 * NMW * 256; \
+    double *fixp = sp; sp += 256; \
+    double *gtile = sp; sp += 256; \
+    double *DU2 = sp; sp += 2 * 256; \
+    double *sc2 = sp; sp += 2 * 48; \
+    double *ring = sp; sp += 4 * 256; \
+    double *cshare = sp; sp += CSU * 256; \
+    double *slk = sp; sp += 16; \
+    SetTable<MAXC> TC; \
+    TC.slots = 16; \
+    TC.lo = sp; sp += 2 * 16; \
+    TC.hi = sp; sp += 2 * 16; \
+    TC.n = (int *)sp; sp += 8; \
+    TC.slow = (int *)sp; sp += 8; \
+    rq_lds_int *sy = (rq_lds_int *)(int *)sp; sp += 8; \
+    double *of0 = sp; sp += 16; \
+    long long *ovis = (long long *)sp; sp += 16; \
+    long long *oacc = (long long *)sp; sp += 16; \
+    long long *oswp = (long long *)sp; sp += 16; \
+    int *sid = (int *)sp; sp += 8; \
+    int *snew = (int *)sp; sp += 8; \
+    int *sfin = (int *)sp; sp += 8; \
+    int *ost = (int *)sp; sp += 8; \
+    int *ctl = (int *)sp; sp += 8; \
+    long long *cst = (long long *)sp; sp += 64 * 10; \
+    unsigned long long *sseed = (unsigned long long *)sp; sp += 16; \
+    unsigned long long *sfirst = (unsigned long long *)sp; sp += 16; \
+    unsigned long long *p1key = (unsigned long long *)sp; sp += 16; \
+    int *p1upd = (int *)sp; sp += 8; \
+    int *p1fin = (int *)sp; sp += 8; \
+    int *p1sw = (int *)sp; sp += 8; \
+    int *p1st = (int *)sp; sp += 8; \
+    int *gatep = (int *)sp; sp += 8; \
+    int *simdof = (int *)sp; sp += 8; \
+    L2Par *par = (L2Par *)sp; sp += 32;
+
+// parameters the role functions need, in LDS: arguments of a real function call travel in vector registers, i.e. the callee
+// would have to treat NB, the base pointers, ... as lane-dependent (waterfall loops around every buffer descriptor);
+// read from LDS and made wave-uniform explicitly they are scalars again
+struct L2Par {
+    const double *Apack, *Apack2, *Dpack, *Spack;
+    double *Xg;
+    int *next;
+    unsigned long long *prof;
+    long long num_iters, n16;
+    double tol, r0, fbound;
+    int NB, KS, n, nlast, Rtotal, pad_;
+};
+__device__ __attribute__((always_inline)) inline int l2_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __attribute__((always_inline)) inline long long l2_uni(long long v) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (long long)(unsigned)lo;
+}
+__device__ __attribute__((always_inline)) inline double l2_uni(double v) { return __longlong_as_double(l2_uni(__double_as_longlong(v))); }
+template <class T>
+__device__ __attribute__((always_inline)) inline T *l2_uni(T *p) { return (T *)(uintptr_t)l2_uni((long long)(uintptr_t)p); }
+
+// =========================================================================== multiplying role (a real function: its
+// register allocation -- 160 registers of persistent B operands, the A ring, two accumulators -- is its own; inlined into the
+// kernel beside the chain role the two fought over the 256 registers and over the scalar file, and the product loop spilled
+// whenever anything else in the kernel changed)
+template <int NMW, int CS>
+__device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
+    constexpr int MAXC = 1;
+    constexpr int CSU = CS > 0 ? CS : 1;
+    L2_LDS_VIEW
+    (void)fixp; (void)gtile; (void)DU2; (void)sc2; (void)cshare; (void)slk; (void)TC; (void)of0; (void)ovis; (void)oacc; (void)oswp; (void)sid; (void)snew;
+    (void)sfin; (void)ost; (void)ctl; (void)cst; (void)sseed; (void)sfirst; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof;
+    const int lane = threadIdx.x & 63;
+    const int m = l2_uni(m_in);
+    const double *pApack2 = l2_uni(par->Apack2);
+    double *pXg = l2_uni(par->Xg);
+    unsigned long long *pprof = l2_uni(par->prof);
+    const int NB = l2_uni(par->NB), KS = l2_uni(par->KS);
+    const int64_t n16 = l2_uni(par->n16);
+    const int64_t gmax = (int64_t)1 << 40;         // the role ends through RQ_STOP
+    // =========================================================================== multiplying role
+    // Wave m owns the blocks m, m + NMW, ... of the contraction (unit u = block m + NMW u) and computes EVERY product
+    // (product i = block row i mod NB, consumed by the chain in interval i) over them:
+    //   B operands: PERSISTENT in registers (4 per unit), loaded from the global tile at the start of the episode; a
+    //   product re-reads only the block committed three intervals ago (out of the LDS ring) -- the other two blocks
+    //   rewritten since are the "holes" the chain supplies itself;
+    //   A fragments of block row `row`: buffer loads, descriptor = P.Apack2, scalar offset = row KS 512 + block 2048,
+    //   vector offset = lane 16, through a ring of RQ_PFU units refilled in place.
+    const RqOwn own = l2_own(NB, CS, m, NMW);
+    v2d_ arP[2 * RQ_PFU];
+    const unsigned vlane = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(pApack2), 0, NB * KS * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(pXg, 0, (int)(n16 * 128), 0x00020000);
+    const int rowstride = KS * 512;
+    typedef unsigned rq_u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned rq_u2 __attribute__((ext_vector_type(2)));
+    #define L2_LDA(dst, soff, vo) { const rq_u4 t0_ = __builtin_amdgcn_raw_buffer_load_b128(arsrc, (vo), (soff), 0);           \
+                            const rq_u4 t1_ = __builtin_amdgcn_raw_buffer_load_b128(arsrc, (vo) + 1024u, (soff), 0);   \
+                            (dst)[0] = __builtin_bit_cast(v2d_, t0_); (dst)[1] = __builtin_bit_cast(v2d_, t1_); }
+    double bq[4 * RQ_PERS];
+    {
+        const unsigned vl8 = (unsigned)lane * 8u;
+    #pragma unroll
+        for (int u = 0; u < RQ_PERS; u++)
+    #pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const rq_u2 t_ = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, vl8, (m + NMW * u) * 2048 + q * 512, 0);
+                bq[4 * u + q] = __builtin_bit_cast(double, t_);
+            }
+    }
+    typedef __attribute__((address_space(3))) const double rq_lds_cd;
+    rq_lds_cd *rbase = (rq_lds_cd *)(ring + lane);
+    asm volatile("" : "+v"(rbase));
+    int row = 0;
+    #pragma unroll
+    for (int U = 0; U < RQ_PFU; U++) L2_LDA(arP + 2 * U, row * rowstride + (m + NMW * U) * 2048, vlane)
+    int spins = 0;
+    const bool prof_on = pprof != nullptr && m == 0;
+    long long pw_commit = 0, pw_cons = 0;
+    for (int64_t i = 0; i < gmax; i++) {
+        const int row2 = (row + 1 == NB) ? 0 : row + 1;
+        // ALWAYS two holes, also for the first products of an episode (the chain supplies them from the tile as if the
+        // sweep before had just ended): every product is summed in the same association wherever episodes begin
+        const int h1 = row == 0 ? NB - 1 : row - 1;
+        const int h2 = h1 == 0 ? NB - 1 : h1 - 1;
+        const int r1 = (i >= 3) ? (h2 == 0 ? NB - 1 : h2 - 1) : -1;      // committed in interval i - 3: its operands are stale
+        unsigned skip = ~0u << own.nu, fresh = 0u;
+        if (h1 % NMW == m && h1 < NB - CS) skip |= 1u << (h1 / NMW);
+        if (h2 % NMW == m && h2 < NB - CS) skip |= 1u << (h2 / NMW);
+        if (r1 >= 0 && r1 % NMW == m && r1 < NB - CS) fresh |= 1u << (r1 / NMW);
+        const int so1 = row * rowstride + m * 2048, so2 = row2 * rowstride + m * 2048;
+        bool stop = false;
+        if (i >= 3) {
+            // every block except the two holes must be final: the latest one was committed in interval i - 3
+            const long long tw0 = prof_on ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            for (;;) {
+                const rq_i4 s4 = rq_sync_read(sy);
+                if (s4[RQ_STOP]) { stop = true; break; }
+                if (s4[RQ_COMMIT] >= (int)i - 2) break;
+                if (++spins > L2_WD) { stop = true; rq_sync_write(sy, L2_ABORT, 1, lane); rq_sync_write(sy, RQ_STOP, 1, lane); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (stop) break;
+            spins = 0;
+            if (prof_on) pw_commit += (long long)__builtin_amdgcn_s_memtime() - tw0;
+            if (fresh) {
+                rq_lds_cd *rp = rbase + (int)((i - 3) & 3) * 256;
+    #pragma unroll
+                for (int u = 0; u < RQ_PERS; u++)
+                    if ((fresh >> u) & 1u) {   // wave-uniform
+    #pragma unroll
+                        for (int q = 0; q < 4; q++) bq[4 * u + q] = rp[q * 64];
+                    }
+            }
+        }
+        v4d_ acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc;
+    #pragma unroll
+        for (int third = 0; third < RQ_RND; third++) {
+    #pragma unroll
+            for (int U = 0; U < RQ_PFU; U++) {
+                const int u = RQ_PFU * third + U;
+                if (u < RQ_MAXU && !((skip >> u) & 1u)) {   // wave-uniform
+                    const double *bu = bq + 4 * u;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arP[2 * U][0], bu[0], acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(arP[2 * U][1], bu[1], acc1, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arP[2 * U + 1][0], bu[2], acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(arP[2 * U + 1][1], bu[3], acc1, 0, 0, 0);
+                }
+                // unconditional refill of the ring slot: the unit RQ_PFU further on, then the first units of the next row
+                if (third < RQ_RND - 1) { if (u + RQ_PFU < RQ_MAXU) L2_LDA(arP + 2 * U, so1 + NMW * 2048 * (u + RQ_PFU), vlane) }
+                else L2_LDA(arP + 2 * U, so2 + NMW * 2048 * U, vlane)
+            }
+        }
+        acc = acc + acc1;
+        if (i >= 2) {
+            // this parity's slot held product i - 2: read by the chain at the start of interval i - 2
+            const long long tw0 = prof_on ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            for (;;) {
+                const rq_i4 s4 = rq_sync_read(sy);
+                if (s4[RQ_STOP]) { stop = true; break; }
+                if (s4[RQ_CONS] >= (int)i - 1) break;
+                if (++spins > L2_WD) { stop = true; rq_sync_write(sy, L2_ABORT, 1, lane); rq_sync_write(sy, RQ_STOP, 1, lane); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (stop) break;
+            spins = 0;
+            if (prof_on) pw_cons += (long long)__builtin_amdgcn_s_memtime() - tw0;
+        }
+        {
+            double *part = part2 + (int)(i & 1) * NMW * 256 + m * 256;
+    #pragma unroll
+            for (int v = 0; v < 4; v++) part[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
+        }
+        rq_sync_write(sy, RQ_PARTS + m, (int)i + 1, lane);
+        row = row2;
+    }
+    if (prof_on && lane == 0) {
+        atomicAdd(pprof + 9, (unsigned long long)pw_commit);
+        atomicAdd(pprof + 10, (unsigned long long)pw_cons);
+    }
+    #undef L2_LDA
+}
+
+// ========================================================================== chain role (a real function as well)
+template <int NMW, int CS, int KIND>
+__device__ __attribute__((noinline)) void l2_chain_role() {
+    constexpr int MAXC = 1;
+    constexpr int CSU = CS > 0 ? CS : 1;
+    constexpr bool PRE = KIND == L2_KIND_LIN;      // a restart's phase 2 starts with a frozen sweep that evaluates f0
+    L2_LDS_VIEW
+    (void)slk; (void)snew; (void)ctl; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof;
+    const int lane = threadIdx.x & 63, r = lane >> 2, gq = lane & 3;
+    LG const double *Apk = l2_g(l2_uni(par->Apack));
+    LG const double *Apk2 = l2_g(l2_uni(par->Apack2));
+    LG const double *Dpk = l2_g(l2_uni(par->Dpack));
+    LG const double *Spk = l2_g(l2_uni(par->Spack));
+    LG double *Xg = l2_g(l2_uni(par->Xg));
+    LG const int *pnext = l2_g(l2_uni(par->next));
+    unsigned long long *pprof = l2_uni(par->prof);
+    const int pRtotal = l2_uni(par->Rtotal);
+    const int NB = l2_uni(par->NB), KS = l2_uni(par->KS), nlast = l2_uni(par->nlast);
+    struct { int64_t n; double r0; } P = {(int64_t)l2_uni(par->n), l2_uni(par->r0)};
+    struct { double tol, fbound; int64_t num_iters; } a = {l2_uni(par->tol), l2_uni(par->fbound), (int64_t)l2_uni(par->num_iters)};
+    const int64_t gmax = (int64_t)1 << 40;         // the role ends when nothing is live / at the episode's end
+    // ========================================================================== chain role
+    __builtin_amdgcn_s_setprio(3);
+    // feasible set of this lane's restart for the episode (from the table the refill step keeps)
+    const int Un = TC.n[r], Uslow = TC.slow[r];
+    const double Ul0 = TC.lo[r], Uh0 = TC.hi[r], Ul1 = TC.lo[16 + r], Uh1 = TC.hi[16 + r];
+    const bool two = Un >= 2;
+    // BAND: [-symb, -syma] u [syma, symb], near-tie = vertex within thr of 0
+    // GEN : [Ul0, Uh0] (u [Ul1, Uh1]); the vertex is projected onto the interval on its side of the gap's midpoint
+    // LIN : the lowest / highest end point against the slope; near-tie = |slope| below tl
+    const double thr = two ? 1e-7 * (Ul1 - Uh0) : 0.0;
+    const double syma = two ? Ul1 : 0.0, symb = two ? Uh1 : Uh0;
+    const double gmid = two ? 0.5 * (Uh0 + Ul1) : QM_INF;
+    const double linL = Ul0, linH = two ? Uh1 : Uh0;
+    double tl = 0.0;
+    if (KIND == L2_KIND_LIN) {
+        // candidates of the reference's end-point comparison (utilities.py:275-288) differ by slope x distance; they
+        // are told apart safely when that exceeds 1e-12 of the objective's scale (rounding: 1e-16 of it)
+        const double w0 = Uh0 - Ul0, w1 = two ? Uh1 - Ul1 : w0;
+        const double wmin = w0 < w1 ? w0 : w1;
+        const double hh = fabs(linL) > fabs(linH) ? fabs(linL) : fabs(linH);
+        const double scale = a.fbound * (hh * hh > 1.0 ? hh * hh : 1.0);
+        tl = (wmin > 0.0) ? 0.5e-12 * scale / wmin : QM_INF;
+    }
+    struct { int upd_counter, visits, accepted, sweeps, status; bool conv; } S;      // (32-bit in the loop: < 2^31 visits per restart)
+    S.upd_counter = (int)cst[0 * 64 + lane]; S.visits = (int)cst[1 * 64 + lane]; S.accepted = (int)cst[2 * 64 + lane];
+    S.sweeps = (int)cst[3 * 64 + lane]; S.conv = cst[4 * 64 + lane] != 0; S.status = (int)cst[5 * 64 + lane];
+    double fpart = __longlong_as_double(cst[6 * 64 + lane]);
+    // The objective of the result is not tracked from an evaluated start value: `facc` sums x_i ((P0 x)_i + q_i) over
+    // the visits since the restart's last move -- when it converges (n visits without a move, qcqp.py:172-176) those
+    // are all n coordinates at the FINAL point: f0(x) - r0 freshly evaluated from the products the sweep computed
+    // anyway.  A restart that stops otherwise (sweep limit, gate not passed) takes one FROZEN sweep (no moves, not
+    // counted) that sums the same terms.  fpart tracks the objective through the moves: relative to the start of
+    // phase 2, or -- linear kind, where the reference's end-point comparison works on rounded absolute values --
+    // from f0 evaluated by a frozen sweep before the first real one (`pre`).
+    bool frz = (cst[7 * 64 + lane] & 1) != 0, done = (cst[7 * 64 + lane] & 2) != 0, pre = PRE && (cst[7 * 64 + lane] & 4) != 0;
+    double facc = __longlong_as_double(cst[8 * 64 + lane]);
+    const bool occupied = sid[r] >= 0;
+    const RqOwn cown = l2_own(NB, CS, -1, NMW);
+    v2d_ arC[2 * CSU];
+    double afix[4] = {0.0, 0.0, 0.0, 0.0}, afix2[4] = {0.0, 0.0, 0.0, 0.0};
+    v4d_ carry = {0.0, 0.0, 0.0, 0.0};      // the block rewritten last times the fragments of the row after next
+    double xon[4], d4[4], s3 = 0.0;         // prefetched for the next interval: x of the block, its staged operands
+    {
+        // staged operands of block 0, x of block 0
+    #pragma unroll
+        for (int e = 0; e < 4; e++) d4[e] = Dpk[lane + 64 * e];
+        if (lane < 48) s3 = Spk[lane];
+    #pragma unroll
+        for (int v = 0; v < 4; v++) xon[v] = Xg[(4 * v + gq) * 16 + r];
+    #pragma unroll
+        for (int e = 0; e < 4; e++) DU2[lane + 64 * e] = d4[e];
+        if (lane < 48) sc2[lane] = s3;
+        // virtual interval before the episode: the two blocks that a sweep rewrites last (NB - 2, NB - 1) times the
+        // fragments of block rows 0 and 1, exactly as the end of a sweep leaves them (carry: NB - 1 x row 1; the
+        // chain's plane: NB - 2 and NB - 1 x row 0 + the chain's share of row 0 without those two)
+        v4d_ c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+        const int bl2 = NB - 2, bl1 = NB - 1;
+        double f0a[4], f0b[4], f1b[4], x2[4], x1[4];
+    #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            f0a[u] = Apk[((int64_t)0 * KS + 4 * bl2 + u) * 64 + lane];
+            f0b[u] = Apk[((int64_t)0 * KS + 4 * bl1 + u) * 64 + lane];
+            f1b[u] = Apk[((int64_t)1 * KS + 4 * bl1 + u) * 64 + lane];
+            x2[u] = Xg[(4 * bl2 + u) * 64 + lane];
+            x1[u] = Xg[(4 * bl1 + u) * 64 + lane];
+        }
+    #pragma unroll
+        for (int u = 0; u < 4; u++) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0a[u], x2[u], c0, 0, 0, 0);
+    #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0b[u], x1[u], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1b[u], x1[u], c1, 0, 0, 0);
+        }
+        carry = c1;
+        if (CS > 0) {
+            l2_load_A<CSU>(arC, Apk2, KS, cown, lane, 0);
+            double bqC[4 * CSU];
+    #pragma unroll
+            for (int U = 0; U < CSU; U++) {
+                const int bb = rq_block(cown, U);
+    #pragma unroll
+                for (int q = 0; q < 4; q++) bqC[4 * U + q] = Xg[(4 * bb + q) * 64 + lane];
+            }
+    #pragma unroll
+            for (int U = 0; U < CSU; U++)
+    #pragma unroll
+                for (int q = 0; q < 4; q++) cshare[U * 256 + q * 64 + lane] = bqC[4 * U + q];
+            c0 = l2_product<CSU>(arC, bqC, Apk2, KS, cown, lane, rq_slot(cown, bl1), rq_slot(cown, bl2), 1, c0);
+        }
+    #pragma unroll
+        for (int v = 0; v < 4; v++) fixp[v * 64 + (lane & 15) * 4 + (lane >> 4)] = c0[v];
+    }
+    const double tolv = a.tol;
+    int b = 0, spins = 0;
+    bool wdog = false;
+    const bool prof_on = pprof != nullptr;
+    long long pw_part = 0, pt_sum = 0, pt_steps = 0, pt_end = 0, pt_fix = 0, ptl = 0;
+    int pn_int = 0, pn_gen = 0;
+#define L2_TICK(acc) if (prof_on) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); acc += now_ - ptl; ptl = now_; }
+    for (int64_t g = 0; g < gmax; g++) {
+        const int bn = (b + 1 == NB) ? 0 : b + 1, bn2 = (bn + 1 == NB) ? 0 : bn + 1;
+        const int bprev = (b == 0) ? NB - 1 : b - 1;
+        const int cur = (int)(g & 1);
+        const double *DU = DU2 + cur * 256, *hqb = sc2 + cur * 48, *rtb = sc2 + cur * 48 + 16, *dgb = sc2 + cur * 48 + 32;
+        const double *part = part2 + cur * NMW * 256;
+        double *rb = ring + (int)(g & 3) * 256;
+        const int ncol = (b == NB - 1) ? nlast : 16;         // real coordinates of the block (the padded ones never move)
+        // ---- requests whose answers the NEXT interval needs: staged operands and x of block bn (committed NB - 1
+        // intervals ago, or part of the tile the episode started from)
+        double xo[4];
+    #pragma unroll
+        for (int v = 0; v < 4; v++) xo[v] = xon[v];
+    #pragma unroll
+        for (int e = 0; e < 4; e++) d4[e] = Dpk[(int64_t)bn * 256 + lane + 64 * e];
+        if (lane < 48) s3 = Spk[(int64_t)bn * 48 + lane];
+    #pragma unroll
+        for (int v = 0; v < 4; v++) xon[v] = Xg[(16 * (int64_t)bn + 4 * v + gq) * 16 + r];
+        {   // A fragments of this block's k-steps in the next two block rows (the chain's contribution to both)
+            LG const double *ap = Apk + ((int64_t)bn * KS + 4 * b) * 64 + lane;
+            LG const double *ap2 = Apk + ((int64_t)bn2 * KS + 4 * b) * 64 + lane;
+    #pragma unroll
+            for (int u = 0; u < 4; u++) { afix[u] = ap[u * 64]; afix2[u] = ap2[u * 64]; }
+        }
+        // ---- partial tiles of product g
+        const long long tw0 = prof_on ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        for (;;) {
+            const rq_i4 p4 = rq_sync_read(sy + RQ_PARTS);
+            int lo4 = p4[0] < p4[1] ? p4[0] : p4[1];
+            const int lo2 = p4[2] < p4[3] ? p4[2] : p4[3];
+            lo4 = lo4 < lo2 ? lo4 : lo2;
+            if (NMW > 4) {
+                const rq_i4 q4 = rq_sync_read(sy + RQ_PARTS + 4);
+                const int l1 = q4[0] < q4[1] ? q4[0] : q4[1], l2 = q4[2] < q4[3] ? q4[2] : q4[3];
+                lo4 = lo4 < l1 ? lo4 : l1;
+                lo4 = lo4 < l2 ? lo4 : l2;
+            }
+            if (lo4 >= (int)g + 1) break;
+            if (++spins > L2_WD) { wdog = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (wdog) { rq_sync_write(sy, L2_ABORT, 1, lane); break; }
+        spins = 0;
+        if (prof_on) { ptl = (long long)__builtin_amdgcn_s_memtime(); pw_part += ptl - tw0; pn_int++; }
+        // ---- G + q/2 of the lane's own columns: its own plane, then the partial tiles, in a fixed order, then q/2
+        double gb[4], xn[4], rto[4];
+    #pragma unroll
+        for (int v = 0; v < 4; v++) {
+            double s = fixp[v * 64 + lane];
+    #pragma unroll
+            for (int w = 0; w < NMW; w++) s += part[w * 256 + v * 64 + lane];
+            s += hqb[4 * v + gq];
+            gb[v] = s;
+            gtile[(4 * v + gq) * 16 + r] = s;             // kept for the generic path (the partial tiles are released now)
+        }
+        rq_sync_write(sy, RQ_CONS, (int)g + 1, lane);     // the partial tiles have been read (LDS is in order per wave)
+    #pragma unroll
+        for (int v = 0; v < 4; v++) rto[v] = rtb[4 * v + gq];
+        if (b == 0 && !S.conv && S.sweeps >= (int)a.num_iters) {      // sweep limit reached (qcqp.py:160): the restart is done
+            S.conv = true;
+            frz = true; facc = 0.0;                               // ... after one frozen sweep that evaluates its objective
+        }
+        if (b == 0 && !S.conv) S.sweeps++;
+        const bool act = !S.conv;
+        const bool actn = act && Un > 0;
+        const double tole = actn ? tolv : QM_INF;     // a restart that is not sweeping never moves (the padded coordinates of
+                                                      // the last block hold a fixed point of the step: see the column build)
+        L2_TICK(pt_sum)
+        // ---- the 16 steps: only what the next step waits for
+    #pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int v = c >> 2, go = c & 3;
+            // every lane works on its own column 4 v + gq; only the owner quad-lane (gq == go) is at step c
+            double pick;
+            if (KIND == L2_KIND_BAND) {
+                const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);          // vertex of the scalar objective
+                pick = __builtin_copysign(fmin(fmax(fabs(xv), syma), symb), xv);
+            } else if (KIND == L2_KIND_GEN) {
+                const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);
+                const double p0 = fmin(fmax(xv, Ul0), Uh0), p1 = fmin(fmax(xv, Ul1), Uh1);
+                pick = (xv > gmid) ? p1 : p0;
+            } else {
+                pick = (gb[v] > 0.0) ? linL : linH;                               // linear: the end point against the slope
+            }
+            const double dlt = pick - xo[v];
+            const double dl = (fabs(dlt) > tole) ? dlt : 0.0;
+            double delta;
+            if (go == 0) delta = rq_quad_bcast<0x00>(dl);
+            else if (go == 1) delta = rq_quad_bcast<0x55>(dl);
+            else if (go == 2) delta = rq_quad_bcast<0xAA>(dl);
+            else delta = rq_quad_bcast<0xFF>(dl);
+    #pragma unroll
+            for (int v2 = v; v2 < 4; v2++) gb[v2] = __builtin_fma(DU[c * 16 + 4 * v2 + gq], delta, gb[v2]);
+        }
+        L2_TICK(pt_steps)
+        // ---- once per block, per own column: the decision again from the frozen G (bit-identical to what the step
+        // computed when the lane was the owner), new x, near-tie test, move mask, objective tracking
+        bool allfar = true;
+        unsigned mv = 0;
+        double fadd = 0.0;
+    #pragma unroll
+        for (int v = 0; v < 4; v++) {
+            double pick;
+            bool far;
+            if (KIND == L2_KIND_BAND) {
+                const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);
+                pick = __builtin_copysign(fmin(fmax(fabs(xv), syma), symb), xv);
+                far = fabs(xv) > thr;                                             // false for NaN as well
+            } else if (KIND == L2_KIND_GEN) {
+                const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);
+                const double p0 = fmin(fmax(xv, Ul0), Uh0), p1 = fmin(fmax(xv, Ul1), Uh1);
+                pick = (xv > gmid) ? p1 : p0;
+                far = fabs(xv - gmid) > thr;
+            } else {
+                pick = (gb[v] > 0.0) ? linL : linH;
+                far = fabs(gb[v]) > tl;
+            }
+            const double dlt = pick - xo[v];
+            const bool mvd = fabs(dlt) > tole;
+            const double d = mvd ? dlt : 0.0;
+            xn[v] = mvd ? pick : xo[v];
+            allfar = allfar && (far || 4 * v + gq >= ncol);
+            mv |= mvd ? (1u << (4 * v + gq)) : 0u;
+            // f(x + d e_i) - f(x) = d (2 (P x)_i + q_i + P_ii d) = d (t2 d + 2 g):  g = G_i + q_i / 2 contains P_ii x_i
+            fadd = __builtin_fma(d, __builtin_fma(dgb[4 * v + gq], d, gb[v] + gb[v]), fadd);
+        }
+        mv = rq_quad_or(mv);                                                       // bit c = coordinate c moved
+        // per RESTART: does the block need the reference's arithmetic?  Only those restarts walk the generic loop
+        const bool redo = rq_quad_or((act && Un > 0 && (!allfar || Uslow != 0)) ? 1u : 0u) != 0u;
+        auto fast_commit = [&]() {
+            if (act) {
+                fpart += fadd;
+                const int accn = __builtin_popcount(mv);
+                const int upd = mv ? (ncol - 1 - (31 - __builtin_clz(mv))) : S.upd_counter + ncol;
+                S.accepted += accn;
+                const int over = upd - (int)P.n;
+                S.visits += ncol - (over > 0 ? over : 0);
+                S.upd_counter = upd;
+                if (over >= 0) S.conv = true;
+                // the window: visits after the block's last move (all of them if none moved), up to the visit that
+                // completes the n consecutive visits without a move
+                const int cl = mv ? 31 - __builtin_clz(mv) : -1, ce = ncol - 1 - (over > 0 ? over : 0);
+                double w = 0.0;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int c = 4 * v + gq;
+                    w = (c > cl && c <= ce) ? __builtin_fma(xn[v], gb[v] + hqb[c], w) : w;
+                }
+                facc = (cl >= 0 ? 0.0 : facc) + w;
+                if (over >= 0) done = true;
+            } else if (frz || pre) {
+                double w = 0.0;
+#pragma unroll
+                for (int v = 0; v < 4; v++) w = __builtin_fma(xo[v], gb[v] + hqb[4 * v + gq], w);
+                facc += w;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) rb[(4 * v + gq) * 16 + r] = xn[v];
+        };
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo) == 0ull, 1)) {
+            fast_commit();
+        } else {
+            // ---- generic loop (rare): the reference's arithmetic on the G tile kept from the block's start and the block's
+            // x in its ring slot; all four lanes of a quad walk their restart redundantly (same values, benign identical
+            // LDS writes)
+            if (prof_on) pn_gen++;
+            if (!redo) fast_commit();
+            else {
+                ChainState G;
+                G.fcur = rq_quad_sum(fpart); G.upd_counter = S.upd_counter; G.visits = S.visits; G.accepted = S.accepted;
+                G.sweeps = S.sweeps; G.conv = S.conv; G.status = S.status;
+                double fa = rq_quad_sum(facc);
+                const uint64_t dseed = sseed[r], dfirst = sfirst[r];
+                FeasSet<MAXC> C;
+                C.n = Un; C.lo[0] = TC.lo[r]; C.hi[0] = TC.hi[r]; C.lo[1] = TC.lo[16 + r]; C.hi[1] = TC.hi[16 + r];
+#pragma unroll
+                for (int v = 0; v < 4; v++) rb[(4 * v + gq) * 16 + r] = xo[v];
+                for (int c = 0; c < ncol; c++) {
+                    const int64_t i = 16 * (int64_t)b + c;
+                    const double t2g = dgb[c];
+                    const double xi = rb[c * 16 + r];
+                    const double hq = hqb[c];
+                    const double gc = gtile[c * 16 + r];
+                    const double t1 = 2.0 * ((gc - hq) - t2g * xi) + (hq + hq);
+                    const double t0 = G.fcur - xi * (t2g * xi + t1);
+                    DrawKey dk{dseed, dfirst + (uint64_t)sid[r], (uint32_t)i, (uint32_t)(G.sweeps - 1) | 0x80000000u, 0u};
+                    double xnew = xi;
+                    int got = G.conv ? 0 : onevar_minimise<MAXC>(t2g, t1, t0, C, dk, &xnew);
+                    bool moved;
+                    double delta;
+                    const bool wasconv = G.conv;
+                    chain_commit<MAXC>(G, got, xnew, xi, t2g, t1, t0, a.tol, P.n, moved, delta);
+                    if (!wasconv) fa = moved ? 0.0 : fa + xi * (gc + hq);
+                    if (moved) {
+                        rb[c * 16 + r] = xnew;
+                        for (int c2 = c + 1; c2 < 16; c2++) gtile[c2 * 16 + r] += DU[c * 16 + c2] * delta;
+                    }
+                }
+                S.upd_counter = (int)G.upd_counter; S.visits = (int)G.visits; S.accepted = (int)G.accepted; S.conv = G.conv; S.status = G.status;
+                fpart = (gq == 0) ? G.fcur : 0.0;
+                facc = (gq == 0) ? fa : 0.0;
+                if (S.conv) done = true;
+#pragma unroll
+                for (int v = 0; v < 4; v++) xn[v] = rb[(4 * v + gq) * 16 + r];
+            }
+        }
+        // the block goes to the global tile as well (the next sweep's prefetch, the next episode's operands, the result)
+    #pragma unroll
+        for (int v = 0; v < 4; v++) Xg[(16 * (int64_t)b + 4 * v + gq) * 16 + r] = xn[v];
+        rq_sync_write(sy, RQ_COMMIT, (int)g + 1, lane);   // block b is in the ring
+        L2_TICK(pt_end)
+        if (b == NB - 1) {
+            if (frz) { frz = false; done = true; }        // the frozen sweep is complete
+            if (PRE && pre) {
+                // f0 at the start of phase 2: the restart starts sweeping with the next block
+                const double f0s = rq_quad_sum(facc) + P.r0;
+                fpart = (gq == 0) ? f0s : 0.0;
+                facc = 0.0; pre = false; S.conv = false;
+            }
+        }
+        const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv || frz || pre);
+        if (livem == 0ull) break;
+        if (b == NB - 1) {
+            // sweep boundary: slots whose restart is done can take a new restart -- end the episode if the queue has one
+            const bool fin = !occupied || done;
+            const unsigned long long finm = __builtin_amdgcn_ballot_w64(fin);
+            if (finm == ~0ull) break;
+            if (finm != 0ull) {
+                const bool more = l2_load_int(pnext) < pRtotal;
+                if (more) break;
+            }
+        }
+        // ---- the chain's part of the next products: the block just committed times the fragments of the next TWO block
+        // rows, and its own share of the next row
+        {
+            v4d_ acc = carry, acc2 = {0.0, 0.0, 0.0, 0.0};
+            double xb4[4];
+    #pragma unroll
+            for (int u = 0; u < 4; u++) xb4[u] = rb[u * 64 + lane];
+    #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afix[u], xb4[u], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(afix2[u], xb4[u], acc2, 0, 0, 0);
+            }
+            carry = acc2;
+            if (CS > 0) {
+                const int us = rq_slot(cown, b);
+                if (us >= 0) {                       // wave-uniform: the block just committed belongs to the chain's share
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) cshare[us * 256 + q * 64 + lane] = xb4[q];
+                }
+                double bqC[4 * CSU];                 // (short-lived: the step loop's registers are free here)
+    #pragma unroll
+                for (int U = 0; U < CSU; U++)
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) bqC[4 * U + q] = cshare[U * 256 + q * 64 + lane];
+                acc = l2_product<CSU>(arC, bqC, Apk2, KS, cown, lane, us, rq_slot(cown, bprev), bn2, acc);
+            }
+    #pragma unroll
+            for (int v = 0; v < 4; v++) fixp[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
+        }
+        // ---- staged operands of the next block into the other parity's buffers
+        {
+            const int nx = (int)((g + 1) & 1);
+    #pragma unroll
+            for (int e = 0; e < 4; e++) DU2[nx * 256 + lane + 64 * e] = d4[e];
+            if (lane < 48) sc2[nx * 48 + lane] = s3;
+        }
+        L2_TICK(pt_fix)
+        b = bn;
+    }
+#undef L2_TICK
+    rq_sync_write(sy, RQ_STOP, 1, lane);
+    if (prof_on && lane == 0) {
+        atomicAdd(pprof + 13, (unsigned long long)pt_sum);
+        atomicAdd(pprof + 14, (unsigned long long)pt_steps);
+        atomicAdd(pprof + 15, (unsigned long long)pt_end);
+        atomicAdd(pprof + 7, (unsigned long long)pt_fix);
+        atomicAdd(pprof + 8, (unsigned long long)pw_part);
+        atomicAdd(pprof + 11, (unsigned long long)pn_int);
+        atomicAdd(pprof + 12, (unsigned long long)pn_gen);
+    }
+    {
+        cst[0 * 64 + lane] = S.upd_counter; cst[1 * 64 + lane] = S.visits; cst[2 * 64 + lane] = S.accepted;
+        cst[3 * 64 + lane] = S.sweeps; cst[4 * 64 + lane] = S.conv ? 1 : 0; cst[5 * 64 + lane] = S.status;
+        cst[6 * 64 + lane] = __double_as_longlong(fpart);
+        cst[7 * 64 + lane] = (frz ? 1 : 0) | (done ? 2 : 0) | (pre ? 4 : 0);
+        cst[8 * 64 + lane] = __double_as_longlong(facc);
+        const double ftot = rq_quad_sum(facc) + P.r0;
+        const bool fin = occupied && done;
+        if (gq == 0) {
+            sfin[r] = fin ? 1 : 0;
+            if (fin) { ovis[r] = S.visits; oacc[r] = S.accepted; oswp[r] = S.sweeps; ost[r] = S.status; of0[r] = ftot; }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// NMW: multiplying waves (3: four-wave workgroup, two per CU; 7: eight waves, one per CU, 1024 < n <= 2304 -- the eighth
+//      wave multiplies too, beside the chain on SIMD 0)
+// CS : blocks of the contraction the chain wave multiplies itself
+// KIND: L2_KIND_BAND / GEN / LIN (cd_life.h)
+template <int NMW, int CS, int KIND>
+__global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife2Args a0) {
+    const CdLife2Args &a = a0;
+    constexpr int MAXC = 1;
+    constexpr int CSU = CS > 0 ? CS : 1;
+    constexpr int NT = NMW == 3 ? 256 : 512;
+    constexpr int NW = NT / 64;
+    constexpr bool PRE = KIND == L2_KIND_LIN;      // a restart's phase 2 starts with a frozen sweep that evaluates f0 (see the chain role)
+    const DevProblem &P = a.P;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int64_t n16 = P.n16;
+    const int NB = (int)P.NB, KS = (int)P.KS;
+    L2_LDS_VIEW
+    LG double *Xg = l2_g(a0.scratch) + (int64_t)blockIdx.x * n16 * 16;       // this workgroup's X tile [j][16]
+
+    // ---- roles by hardware SIMD.  The dispatcher deals the waves of a workgroup round robin over the four SIMDs starting
+    // wherever the CU's pointer stands (measured, tools/ubench/ubench5.hip: wave w of a four-wave workgroup is NOT on SIMD w).
+    // Two workgroups share a CU: both chains go to SIMD 0 (two latency-bound waves interleave well), the product streams to
+    // SIMDs 1-3.  If the waves do not cover the SIMDs evenly the roles fall back to the wave index (slower, equally correct).
+    if ((tid0 & 63) == 0) simdof[wave] = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)));       // HW_ID[5:4]
+    if (tid0 < 64) {
+#pragma unroll
+        for (int f = 0; f < 10; f++) cst[f * 64 + tid0] = (f == 4) ? 1 : 0;
+    }
+    if (tid0 < 16) { sid[tid0] = -1; sfin[tid0] = 0; }
+    LG const CdLife *lf0 = l2_g(a0.life);
+    const long long life_t0 = (tid0 == 0 && lf0->prof) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    __syncthreads();
+    int role;                                      // 0 chain, 1 .. NMW multiplying wave role - 1
+    {
+        int cnt[4] = {0, 0, 0, 0};
+        int rank = 0;
+        const int mys = simdof[wave];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const int s = simdof[w];
+#pragma unroll
+            for (int q = 0; q < 4; q++) cnt[q] += (s == q) ? 1 : 0;
+            rank += (s == mys && w < wave) ? 1 : 0;
+        }
+        const bool even = cnt[0] == NW / 4 && cnt[1] == NW / 4 && cnt[2] == NW / 4 && cnt[3] == NW / 4;
+        if (NMW == 3) role = even ? mys : wave;
+        else if (even) role = (mys == 0) ? (rank == 0 ? 0 : 7) : mys + 3 * rank;      // SIMD s: waves s (, s + 3); SIMD 0: the chain and wave 7
+        else role = wave;
+        role = __builtin_amdgcn_readfirstlane(role);
+        if (tid0 == 0 && lf0->prof) {                // debug: workgroups whose waves covered the SIMDs evenly / the CU they sat on
+            if (even) atomicAdd((unsigned long long *)lf0->prof + 6, 1ull);
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+            l2_g(a0.scratch)[(int64_t)blockIdx.x * n16 * 16] = (double)(((xcc & 15) << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15));   // overwritten by the first column build
+        }
+    }
+    const int nlast = (int)(P.n - 16 * (int64_t)(NB - 1));      // real coordinates of the last block (1..16)
+    if (tid0 == 0) {
+        par->Apack = P.Apack; par->Apack2 = P.Apack2; par->Dpack = a0.Dpack; par->Spack = a0.Spack;
+        par->Xg = a0.scratch + (int64_t)blockIdx.x * n16 * 16; par->next = a0.b.next; par->prof = (unsigned long long *)lf0->prof;
+        par->num_iters = a.num_iters; par->n16 = n16; par->tol = a.tol; par->r0 = P.r0; par->fbound = a.fbound;
+        par->NB = NB; par->KS = KS; par->n = (int)P.n; par->nlast = nlast; par->Rtotal = (int)lf0->Rtotal; par->pad_ = 0;
+    }
+    __syncthreads();
+
+    for (;;) {
+        // the lane index is made opaque per episode (otherwise every lane-dependent address of every role is hoisted out of
+        // the episode loop and stays live through all roles)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const CdLife *lifep = a0.life;
+        asm volatile("" : "+s"(lifep));
+        const int lane = tid & 63, r = lane >> 2, gq = lane & 3;
+        // ================================================================ refill: free slots take the next restarts
+        if (tid == 0) ctl[0] = 0;
+        __syncthreads();
+        if (tid < 16) {
+            int id = sid[tid], nw = 0;
+            if (id < 0) {
+                LG const CdLife *lf = l2_g(lifep);
+                const int idx = l2_add(l2_g(a0.b.next), 1);
+                if (idx < (int)lf->Rtotal) {
+                    id = idx; nw = 1;
+                    const uint64_t pop = (uint64_t)idx / (uint64_t)lf->Rpop, rho = (uint64_t)idx % (uint64_t)lf->Rpop;
+                    sseed[tid] = lf->seed + pop * lf->seed_stride;
+                    sfirst[tid] = lf->first_index + pop * lf->first_stride + rho - (uint64_t)idx;    // + id = the global restart index
+                }
+            }
+            sid[tid] = id; snew[tid] = nw;
+            if (nw) { p1fin[tid] = 0; p1sw[tid] = 0; p1st[tid] = 0; gatep[tid] = 0; }
+            if (id < 0) {
+                // an empty slot: a zero column that never moves (feasible set of slack 0, restart marked converged)
+                slk[tid] = 0.0;
+                FeasSet<MAXC> C;
+                compute_set<MAXC>(P, P.krep[0], 0.0, C);
+                store_set<MAXC>(TC, tid, C);
+            }
+            if (id >= 0) atomicAdd(&ctl[0], 1);
+        }
+        if (tid < 16) *(volatile rq_lds_int *)(sy + tid) = (tid >= RQ_PARTS + NMW) ? 0x7fffffff : 0;
+        __syncthreads();
+        if (ctl[0] == 0) break;                    // nothing left anywhere: done
+        {
+            // ---- build the columns of the restarts just taken: suggest(RANDOM) (qcqp.py:381-382: keyed normals, the stream
+            // of randn_tiles_kernel) or the resident point, phase 1 (qcqp.py:101-149 through the visit of cd_phase1_sep.h), the
+            // max violation = slack of phase 2 (qcqp.py:157) and the gate (qcqp.py:189).  The tile lives in global memory;
+            // every thread only ever touches its own elements between two barriers.
+            // (priority over the neighbour workgroup's product streams: a double-precision instruction of the build otherwise
+            //  waits for a whole matrix instruction of the other stream every time -- the build is latency, the streams have slack)
+            __builtin_amdgcn_s_setprio(3);
+            LG const CdLife *lf = l2_g(lifep);
+            const long long pt0 = lf->prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            const int lf_generate = lf->generate, lf_phase1 = lf->phase1;
+            const double lf_viol_tol = lf->viol_tol;
+            const int e0 = P.cptr[P.krep[0]];
+            const double cp = P.cp[e0], cq = P.cq[e0], cr = P.cr[e0];
+            const int rel = P.crel[e0];
+            for (int c = 0; c < 16; c++) {
+                if (!snew[c]) {
+                    if (sid[c] < 0) for (int64_t j = tid; j < n16; j += NT) Xg[j * 16 + c] = 0.0;
+                    continue;
+                }
+                if (lf_generate) {
+                    const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
+                    for (int64_t j = 2 * (int64_t)tid; j < n16; j += 2 * NT) {
+                        double xo = 0.0;
+                        const double xe = (j < P.n) ? l2_keyed_normal_pair(sd, gidx, (uint64_t)j, &xo) : 0.0;
+                        Xg[j * 16 + c] = xe;
+                        Xg[(j + 1) * 16 + c] = (j + 1 < P.n) ? xo : 0.0;
+                    }
+                } else {
+                    LG const double *src = l2_g(a0.b.X) + ((int64_t)(sid[c] >> 4) * n16) * 16 + (sid[c] & 15);
+                    for (int64_t j0 = tid; j0 < n16; j0 += 4 * NT) {
+                        double t4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) t4[u] = (j0 + u * NT < n16) ? src[(j0 + u * NT) * 16] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (j0 + u * NT < n16) Xg[(j0 + u * NT) * 16 + c] = t4[u];
+                    }
+                }
+            }
+            __syncthreads();
+            if (lf->prof && tid == 0) atomicAdd((unsigned long long *)lf->prof + 4, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pt0));
+            if (lf_phase1) {
+                for (int64_t t = 0; t < a.num_iters; t++) {
+                    if (tid == 0) { int cnt = 0; for (int k = 0; k < 16; k++) cnt += (snew[k] && !p1fin[k]) ? 1 : 0; ctl[4] = cnt; }
+                    if (tid < 16) { p1key[tid] = l2_key(-QM_INF); p1upd[tid] = 0; }
+                    __syncthreads();
+                    if (ctl[4] == 0) break;
+                    for (int c = 0; c < 16; c++) {
+                        if (!snew[c] || p1fin[c]) continue;       // workgroup-uniform
+                        const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
+                        double vmax = -QM_INF;
+                        int upd = 0, st = 0;
+                        for (int64_t i = tid; i < P.n; i += NT) {
+                            int fl;
+                            double va;
+                            const double xi = l2_p1_visit(cp, cq, cr, rel, i, Xg[i * 16 + c], a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
+                            if (fl >> 8) st = -(fl >> 8);
+                            if (fl & 1) { Xg[i * 16 + c] = xi; upd = 1; }
+                            vmax = va > vmax ? va : vmax;
+                        }
+                        vmax = l2_wave_max(vmax);
+                        if (lane == 0) atomicMax(&p1key[c], l2_key(vmax));
+                        if (upd) p1upd[c] = 1;
+                        if (st) p1st[c] = st;
+                    }
+                    __syncthreads();
+                    if (tid < 16 && snew[tid] && !p1fin[tid]) {
+                        p1sw[tid]++;
+                        // done when feasible enough (qcqp.py:111); a sweep without any update is a fixed point of the map
+                        if (l2_unkey(p1key[tid]) < lf_viol_tol || !p1upd[tid]) p1fin[tid] = 1;
+                    }
+                    __syncthreads();
+                }
+            }
+            if (tid < 16) p1key[tid] = l2_key(-QM_INF);
+            __syncthreads();
+            for (int c = 0; c < 16; c++) {
+                if (!snew[c]) continue;
+                double v = -QM_INF;
+                for (int64_t i = tid; i < P.n; i += NT) {
+                    const double x = Xg[i * 16 + c];
+                    const double f = (cp * x + cq) * x + cr;
+                    const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+                    v = w > v ? w : v;
+                }
+                v = l2_wave_max(v);
+                if (lane == 0) atomicMax(&p1key[c], l2_key(v));
+            }
+            __syncthreads();
+            if (tid < 16 && snew[tid]) {
+                const double mvx = l2_unkey(p1key[tid]);
+                slk[tid] = mvx;
+                gatep[tid] = (mvx < lf_viol_tol && p1st[tid] == 0) ? 1 : 0;
+                FeasSet<MAXC> C;
+                compute_set<MAXC>(P, P.krep[0], mvx, C);
+                store_set<MAXC>(TC, tid, C);
+            }
+            __syncthreads();
+            if (nlast < 16) {
+                // n is not a multiple of 16: the padded coordinates of the last block (zero rows and columns of P0) hold a value
+                // the step maps onto ITSELF -- the band's inner end / an end of the first interval / the highest end point --
+                // so that they never move without a test in the chain's steps; zero again when the column is written out
+                const int c = tid & 15;
+                if (tid < 16 * (16 - nlast) && (snew[c] || sid[c] < 0)) {
+                    const int nn = TC.n[c];
+                    double xp = 0.0;
+                    if (KIND == L2_KIND_BAND) xp = nn >= 2 ? TC.lo[16 + c] : 0.0;
+                    else if (KIND == L2_KIND_GEN) xp = nn >= 1 ? TC.hi[c] : 0.0;
+                    else xp = nn >= 2 ? TC.hi[16 + c] : TC.hi[c];
+                    if (!(xp == xp) || __builtin_isinf(xp)) xp = 0.0;
+                    Xg[(P.n + (tid >> 4)) * 16 + c] = xp;
+                }
+                __syncthreads();
+            }
+            if (lf->prof && tid == 0) {
+                int nn = 0;
+                for (int k = 0; k < 16; k++) nn += snew[k] ? 1 : 0;
+                atomicAdd((unsigned long long *)lf->prof + 0, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pt0));
+                atomicAdd((unsigned long long *)lf->prof + 2, 1ull);
+                atomicAdd((unsigned long long *)lf->prof + 3, (unsigned long long)nn);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (role == 0) {
+            if (snew[r]) {
+#pragma unroll
+                for (int f = 0; f < 6; f++) cst[f * 64 + lane] = 0;
+                // the restart is not sweeping yet: gate not passed -> one frozen sweep (flag 1) that evaluates its objective;
+                // passed, linear kind -> a frozen sweep first (flag 4) that evaluates f0 at the start of phase 2
+                const int pass = gatep[r];
+                cst[6 * 64 + lane] = 0;
+                cst[4 * 64 + lane] = (pass && !PRE) ? 0 : 1;
+                cst[7 * 64 + lane] = pass ? (PRE ? 4 : 0) : 1;
+                cst[8 * 64 + lane] = 0;
+            } else if (sid[r] < 0) {
+                cst[4 * 64 + lane] = 1; cst[6 * 64 + lane] = 0;
+                cst[7 * 64 + lane] = 2; cst[8 * 64 + lane] = 0;
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && l2_g(lifep)->prof) *(long long *)(ctl + 6) = (long long)__builtin_amdgcn_s_memtime();
+
+        // ================================================================ episode: the roles
+        if (role > 0) l2_mfma_role<NMW, CS>(role - 1);
+        else l2_chain_role<NMW, CS, KIND>();
+
+        __syncthreads();
+        if (sy[L2_ABORT]) {                          // a wait gave up: unwind (the host reports it)
+            if (tid == 0) __hip_atomic_store(l2_g(a0.abort), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (tid == 0 && l2_g(lifep)->prof)
+            atomicAdd((unsigned long long *)l2_g(lifep)->prof + 5, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - *(long long *)(ctl + 6)));
+        // ================================================================ write out the slots that finished
+        {
+            // max violation of the final points, same expression as eval_kernel: (p x + q) x + r of the one constraint
+            // every coordinate carries (single class, one constraint per coordinate)
+            const int e0 = P.cptr[P.krep[0]];
+            const double cp = P.cp[e0], cq = P.cq[e0], cr = P.cr[e0];
+            const int rel = P.crel[e0];
+            const int col = tid & 15, slot = tid >> 4;
+            double v = -QM_INF;
+            if (sfin[col]) {
+                // (eight loads in flight per thread: the tile lives in L2, a dependent load-store pair per row costs a round trip each)
+                LG double *dst = l2_g(a0.b.X) + ((int64_t)(sid[col] >> 4) * n16) * 16 + (sid[col] & 15);
+                for (int64_t i0 = slot; i0 < n16; i0 += (NT / 16) * 8) {
+                    double xv8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int64_t i = i0 + (NT / 16) * u;
+                        xv8[u] = (i < P.n) ? Xg[i * 16 + col] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int64_t i = i0 + (NT / 16) * u;
+                        if (i < n16) dst[i * 16] = xv8[u];
+                        if (i < P.n) {
+                            const double f = (cp * xv8[u] + cq) * xv8[u] + cr;
+                            const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+                            v = w > v ? w : v;
+                        }
+                    }
+                }
+            }
+            double *red = part2;                 // NT doubles of the partial-tile area, free between episodes
+            red[tid] = v;
+            __syncthreads();
+            if (tid < 16 && sfin[tid]) {
+                double mx = -QM_INF;
+                for (int s2 = 0; s2 < NT / 16; s2++) { const double w = red[s2 * 16 + tid]; mx = w > mx ? w : mx; }
+                const int id = sid[tid];
+                l2_g(a0.b.visits)[id] = ovis[tid]; l2_g(a0.b.accepted)[id] = oacc[tid]; l2_g(a0.b.sweeps)[id] = oswp[tid];
+                l2_g(a0.b.status)[id] = ost[tid];
+                if (a0.b.f0out) l2_g(a0.b.f0out)[id] = of0[tid];
+                if (a0.b.mvout) l2_g(a0.b.mvout)[id] = mx;
+                LG const CdLife *lf = l2_g(lifep);
+                l2_g(lf->sweeps1)[id] = p1sw[tid]; l2_g(lf->status1)[id] = p1st[tid];
+                l2_g(lf->ran2)[id] = (uint8_t)gatep[tid];
+                sid[tid] = -1; sfin[tid] = 0;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid0 == 0 && lf0->prof)
+        atomicAdd((unsigned long long *)lf0->prof + 1, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - life_t0));
+}
+
+// strictly upper triangle of the diagonal blocks (zeros elsewhere) and the per-block scalars the chain stages
+__global__ void l2_pack_kernel(DevProblem P, double *Dpack, double *Spack) {
+    const int b = blockIdx.x, t = threadIdx.x;            // 256 threads: entry (row t >> 4, column t & 15) of block b
+    const int64_t n16 = P.n16;
+    const int rr = t >> 4, cc = t & 15;
+    Dpack[(int64_t)b * 256 + t] = (cc > rr) ? P.P0[(16 * (int64_t)b + rr) * n16 + 16 * b + cc] : 0.0;
+    if (t < 16) {
+        const int64_t i = 16 * (int64_t)b + t;
+        const double d = P.P0[i * n16 + i], rc = P.rcp2d[i];
+        Spack[(int64_t)b * 48 + t] = 0.5 * P.q0[i];
+        Spack[(int64_t)b * 48 + 16 + t] = rc + rc;
+        Spack[(int64_t)b * 48 + 32 + t] = d;
+    }
+}
+
+template <int NMW, int CS>
+int l2_launch_kind(const CdLife2Args &a, int kind, int wgs, size_t lds, hipStream_t st) {
+    auto k = kind == L2_KIND_BAND ? cd_life_kernel<NMW, CS, L2_KIND_BAND> : kind == L2_KIND_GEN ? cd_life_kernel<NMW, CS, L2_KIND_GEN> : cd_life_kernel<NMW, CS, L2_KIND_LIN>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3(NMW == 3 ? 256 : 512), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+size_t cd_life2_lds_bytes(int nmw) {
+    const size_t d = (size_t)2 * nmw * 256 + 256 + 256 + 4 * 256 + 512 + 96 + 1024 + 16 + 64 + 8 + 8 + 8 + 16 * 4 + 8 * 5 + 640 + 16 * 3 + 8 * 5 + 8 + 32;
+    return d * sizeof(double) + 256;
+}
+
+int cd_life2_max_wgs(int nmw, int cus) { return nmw == 3 ? 2 * cus : cus; }
+
+bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, int *nmw, int *cs, int *kind) {
+    if (!P.sep || P.maxc != 1 || Kreal != 1) return false;
+    if (objclass != 1 && objclass != 2) return false;
+    const int NB = (int)P.NB;
+    if (NB < 3) return false;
+    int w, c;
+    if (NB <= 4) { w = 3; c = 0; }
+    else if (NB - 4 <= 3 * RQ_MAXU) { w = 3; c = (NB < 8) ? 2 : 4; }
+    else if (NB - 4 <= 7 * RQ_MAXU) { w = 7; c = 4; }
+    else return false;
+    *nmw = w; *cs = c;
+    *kind = objclass == 2 ? L2_KIND_LIN : (symcls ? L2_KIND_BAND : L2_KIND_GEN);
+    return true;
+}
+
+int cd_life2_pack(const DevProblem &P, double *Dpack, double *Spack, hipStream_t st) {
+    hipLaunchKernelGGL(l2_pack_kernel, dim3((unsigned)P.NB), dim3(256), 0, st, P, Dpack, Spack);
+    return (int)hipGetLastError();
+}
+
+int cd_life2_launch(const CdLife2Args &a, int nmw, int cs, int kind, int wgs, hipStream_t st) {
+    const size_t lds = cd_life2_lds_bytes(nmw);
+    if (getenv("QCQPMI_L2_DEBUG")) {
+        int occ = -1;
+        hipError_t e = nmw == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cd_life_kernel<3, 4, L2_KIND_BAND>, 256, lds)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cd_life_kernel<7, 4, L2_KIND_BAND>, 512, lds);
+        fprintf(stderr, "cd_life2_launch: nmw %d cs %d kind %d wgs %d lds %zu: occupancy %d workgroups per CU (%s)\n", nmw, cs, kind, wgs, lds, occ, hipGetErrorString(e));
+    }
+    if (wgs < 1) wgs = 1;
+    if (nmw == 3) {
+        if (cs == 0) return l2_launch_kind<3, 0>(a, kind, wgs, lds, st);
+        if (cs == 2) return l2_launch_kind<3, 2>(a, kind, wgs, lds, st);
+        if (cs == 4) return l2_launch_kind<3, 4>(a, kind, wgs, lds, st);
+        return (int)hipErrorInvalidValue;
+    }
+    if (nmw == 7 && cs == 4) return l2_launch_kind<7, 4>(a, kind, wgs, lds, st);
+    return (int)hipErrorInvalidValue;
+}
+
+const char *cd_life2_name(int nmw, int kind) {
+    if (nmw == 3) return kind == L2_KIND_BAND ? "cd_life_kernel<3,band>" : kind == L2_KIND_GEN ? "cd_life_kernel<3,gen>" : "cd_life_kernel<3,lin>";
+    return kind == L2_KIND_BAND ? "cd_life_kernel<7,band>" : kind == L2_KIND_GEN ? "cd_life_kernel<7,gen>" : "cd_life_kernel<7,lin>";
+}
+
+}  // namespace qcqpmi

@@ -121,12 +121,24 @@ __device__ inline void p1_band_visit(double p, double q, double r, int64_t i, do
     double ss = -tol, es = viol - viol_tol, sp = 0.0;
     uint32_t it = 0, itp = 0;
     bool pending = false;
+    // The bisection's test on the two discriminants D1 = 4 p (s - r), D2 = 4 p (-r - s) is, in exact arithmetic,
+    // s > r and (s > -r or s > 0).  D1 > 0 and D2 < 0 are decided by the SIGN of one rounded difference (exact); D2 < D1 compares
+    // two rounded products that differ by 8 p s.  For r well below zero (the Boolean family: r = -1; every slack of the
+    // bisection is >= -tol > r) the test is therefore just s > 0 unless s is within rounding of 0 -- there, and for any other
+    // r, the discriminants are formed as the reference forms them.  13 double-precision operations per step become 4: under
+    // the matrix instructions of the neighbouring workgroup every one of them waits for a slot of the pipe.
+    const bool plain = r < -1e-3;
+    const double guard = 1e-9 * (1.0 - r);
     while (es - ss > tol) {
         const double s = (ss + es) / 2.0;
         const uint32_t itb = it++;
-        const double D1 = 0.0 - 4.0 * p * (r - s);
-        const double D2 = 0.0 - 4.0 * (-p) * (-r - s);
-        const bool nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
+        bool nonempty;
+        if (plain && fabs(s) > guard) nonempty = s > 0.0;
+        else {
+            const double D1 = 0.0 - 4.0 * p * (r - s);
+            const double D2 = 0.0 - 4.0 * (-p) * (-r - s);
+            nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
+        }
         if (!nonempty) { ss = s; continue; }
         sp = s; itp = itb; pending = true;
         new_viol = s; es = s;

@@ -390,6 +390,10 @@ class Engine(object):
         a device-side queue (cd_phase2_qs_kernel)."""
         self._chk(self.L.qcqpmi_cd_queue(self.h, int(mode)))
 
+    def cd_life_version(self, version=2):
+        """Lifecycle kernel of cd_stream_run: 2 = cd_life_kernel (round 5, default), 1 = cd_phase2_qs_kernel<lifecycle> (round 4)."""
+        self._chk(self.L.qcqpmi_cd_life_version(self.h, int(version)))
+
     def cd_reference_order(self, enable=True):
         """Coupled constraints: coordinate descent in the reference's summation order (slow, value-for-value comparable with
         the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""

@@ -7,6 +7,7 @@ with the objective first (relop ``None``) -- the raw-array form accepted by
 
 * ``boolean_least_squares``  -- examples/boolean_least_squares.py:6-15
 * ``maxcut``                 -- examples/maxcut.py:9-21
+* ``box_least_squares``      -- the box-constrained sibling of the Boolean family (one interval per coordinate)
 * ``beamforming``            -- examples/secondary_user_beamforming.py:18-41
 * ``dense_indefinite``       -- SURVEY.md section 8(d) cfg5 generator
 * ``circle_packing``         -- examples/circle_packing.py:6-17 (two variables: centres 2 x N and the radius)
@@ -38,6 +39,23 @@ def boolean_least_squares(n, m_rows, seed=1, legacy_seed=False):
     for i in range(n):
         P = sp.csr_matrix(([1.0], ([i], [i])), shape=(n, n))
         funcs.append((P, np.zeros(n), -1.0, '=='))
+    return funcs, False, dict(A=A, b=b)
+
+
+def box_least_squares(n, m_rows, bound=1.0, seed=1, ridge=0.1):
+    """minimize ||Ax-b||^2 + ridge ||x||^2  s.t. x_i^2 <= bound^2  (the box -bound <= x_i <= bound as one convex quadratic per
+    coordinate: ONE constraint class, one interval per coordinate -- the relaxed sibling of boolean_least_squares)."""
+    rs = np.random.RandomState(seed)
+    A = rs.randn(m_rows, n)
+    b = rs.randn(m_rows, 1) * np.sqrt(n)
+    P0 = A.T.dot(A) + ridge * np.eye(n)
+    P0 = (P0 + P0.T) / 2.
+    q0 = (-2. * A.T.dot(b)).ravel()
+    r0 = float(b.T.dot(b)[0, 0])
+    funcs = [(P0, q0, r0, None)]
+    for i in range(n):
+        P = sp.csr_matrix(([1.0], ([i], [i])), shape=(n, n))
+        funcs.append((P, np.zeros(n), -float(bound) ** 2, '<='))
     return funcs, False, dict(A=A, b=b)
 
 
