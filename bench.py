@@ -101,7 +101,7 @@ def secondary_records(device, sdr_full=False):
                                'slot-queue kernel (a converged restart is replaced at the next sweep boundary); first figures: 16384 restarts, '
                                'slot queue',
                      'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': head['value'], 'unit': 'restart-sweeps/s',
-                     'by_restarts_and_kernel': pts,
+                     'kernel': head['kernel'], 'by_restarts_and_kernel': pts,
                      'roofline': {'bound': 'mfma', 'kernel': head['kernel'], 'achieved': head['achieved'],
                                   'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': head['frac'],
                                   'kernel_ms_per_launch': head['kernel_ms_per_launch']}})
@@ -116,8 +116,10 @@ def secondary_records(device, sdr_full=False):
         funcs, _, _ = problems.boolean_least_squares(n, 256, seed=1)
         e = Engine(QCQPForm.from_arrays(funcs), device=device)
         pts = []
+        stream_kernel = None
         for R, K in ((4096, 40), (512, 160)):
             e.cd_stream_run(K, R, seed=300, seed_stride=1)
+            stream_kernel = e.last_cd_kernel()
             e.sync()
             t0 = time.perf_counter()
             o = e.cd_stream_run(K, R, seed=400, seed_stride=1)
@@ -144,12 +146,12 @@ def secondary_records(device, sdr_full=False):
         recs.append({'config': 'headline workload through the lifecycle kernel: 40 steps of 4096 restarts in one launch (steady state), and the '
                                'strong-scaling share of BASELINE.json configs[1] on 8 GPUs -- 512 restarts per GPU and step, 160 steps in one launch',
                      'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': pts[0]['value'], 'unit': 'restart-sweeps/s',
-                     'kernel': e.last_cd_kernel(), 'by_restarts_per_step': pts,
-                     'one_launch_per_step_512_restarts_ms': 1e3 * dt1,
+                     'kernel': stream_kernel, 'by_restarts_per_step': pts,
+                     'one_launch_per_step_512_restarts_ms': 1e3 * dt1, 'one_launch_per_step_kernel': e.last_cd_kernel(),
                      'note': 'a streamed step of 512 restarts takes %.3f ms against %.3f ms for a step of 4096 (ratio %.2f; 8.0 = perfect strong '
                              'scaling of the step rate) and against %.2f ms with one launch per step (suggest + improve + selection, tile-bound '
                              'phase 2: 32 tiles on 256 CUs)' % (pts[1]['ms_per_step'], pts[0]['ms_per_step'], pts[0]['ms_per_step'] / pts[1]['ms_per_step'], 1e3 * dt1),
-                     'roofline': {'bound': 'mfma', 'kernel': 'cd_phase2_qs_kernel<lifecycle>', 'achieved': pts[0]['achieved'], 'peak': FP64_PEAK_TFLOPS,
+                     'roofline': {'bound': 'mfma', 'kernel': stream_kernel, 'achieved': pts[0]['achieved'], 'peak': FP64_PEAK_TFLOPS,
                                   'unit': 'TFLOP/s', 'frac': pts[0]['frac'], 'kernel_ms_per_launch': pts[0]['kernel_ms_per_launch']}})
         del e
     except Exception as ex:
@@ -192,6 +194,38 @@ def secondary_records(device, sdr_full=False):
         del e
     except Exception as ex:      # a secondary record must never take the headline down
         recs.append({'config': 'configs[2]', 'error': repr(ex)})
+    # configs[2]'s graph through improve(COORD_DESCENT) (examples/maxcut.py:25-28): n = 2000 > 1024 and a ZERO diagonal -- the second
+    # generation lifecycle kernel (eight-wave workgroups, linear scalar objective); rounds 1-4 ran it through cd_phase2_rs_kernel
+    try:
+        n, R, K = 2000, 2048, 2
+        pts = []
+        for weighted in (True, False):
+            funcs, _, _ = problems.maxcut(n, 0.5, seed=1, weighted=weighted)
+            e = Engine(QCQPForm.from_arrays(funcs), device=device)
+            e.cd_stream_run(1, 512, seed=5, num_iters=50)
+            e.sync()
+            t0 = time.perf_counter()
+            o = e.cd_stream_run(K, R, seed=6, seed_stride=1, num_iters=50)
+            e.sync()
+            dt = time.perf_counter() - t0
+            ms = e.kernel_ms(Engine.KERNEL_CD2)
+            sw = float(o['visits2'].sum()) / n
+            pts.append({'graph': 'weighted U(0.5, 1.5)' if weighted else 'unweighted (examples/maxcut.py)', 'kernel': e.last_cd_kernel(),
+                        'value': sw / dt, 'kernel_ms_per_launch': ms, 'sweeps_per_restart': sw / (K * R),
+                        'best_cut': float(-o['best_f0'].min()), 'achieved': sw * 2.0 * n * n / 1e12 / (ms / 1e3),
+                        'frac': sw * 2.0 * n * n / 1e12 / (ms / 1e3) / FP64_PEAK_TFLOPS})
+            del e
+        recs.append({'config': 'MAXCUT G(2000, 0.5) (the graph of BASELINE.json configs[2]) through improve(COORD_DESCENT): 2 populations of 2048 random '
+                               'restarts in one launch, num_iters = 50',
+                     'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': pts[0]['value'], 'unit': 'restart-sweeps/s',
+                     'kernel': pts[0]['kernel'], 'by_graph': pts,
+                     'note': 'unweighted graphs are full of exact ties (t1 = 0 up to the rounding of a row sum): those visits replay the '
+                             'reference\'s arithmetic and its random tie-breaks one restart at a time -- the rate of the second entry is that replay',
+                     'roofline': {'bound': 'mfma', 'kernel': pts[0]['kernel'], 'achieved': pts[0]['achieved'], 'peak': FP64_PEAK_TFLOPS,
+                                  'unit': 'TFLOP/s', 'frac': pts[0]['frac'], 'kernel_ms_per_launch': pts[0]['kernel_ms_per_launch'],
+                                  'algorithmic_flops_per_restart_sweep': 2.0 * n * n}})
+    except Exception as ex:
+        recs.append({'config': 'MAXCUT G(2000, 0.5) through improve(COORD_DESCENT)', 'error': repr(ex)})
     # configs[3]: secondary-user beamforming, 512 antennas (n = 1024 real), 16 + 64 constraints, improve(ADMM, rho = 1)
     try:
         funcs, _, _ = problems.beamforming(512, 16, 64, seed=1)
@@ -578,7 +612,7 @@ def main():
     args = ap.parse_args()
 
     from qcqp_amd import dist, problems
-    from qcqp_amd.engine import Engine, EngineError
+    from qcqp_amd.engine import E_UNSUPPORTED, Engine, EngineError
     from qcqp_amd.form import QCQPForm
 
     kids = dist.spawn_local_ranks(args.gpus)       # no-op under a launcher or for 1 GPU
@@ -601,12 +635,13 @@ def main():
     # ------------------------------------------------------------------ scheme `stream` (default): one launch for all steps
     def run_stream(count, base):
         """`count` steps -- step k = suggest(RANDOM) with seed + k, improve(COORD_DESCENT), best point -- through ONE launch of the
-        lifecycle kernel on this rank's restarts, then ONE exchange over the ranks for the global best of every step (two
-        all-reduces: the keys, the winners' points)."""
+        lifecycle kernel on this rank's restarts, then ONE exchange over the ranks for the global best of every step (an all-gather
+        of the 32-byte keys, an all-reduce of the winners' points)."""
         o = eng.cd_stream_run(count, R, generate=True, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=args.seed + base,
                               seed_stride=1, first_index=first, first_stride=0, select_tol=1e-4)
         ms = eng.kernel_ms(Engine.KERNEL_CD2)
-        keys, X = dist.global_best_of_populations(allreduce_sum, rank, world, o['best_f0'], o['best_maxviol'], first + o['best_index'], o['best_x'])
+        keys, X = dist.global_best_of_populations(allreduce_sum, rank, world, o['best_f0'], o['best_maxviol'], first + o['best_index'], o['best_x'],
+                                                     allgather=getattr(eng, 'comm_allgather', None))
         return o, keys, X, ms
 
     # ------------------------------------------------------------------ scheme `two` (rounds 2 / 3): one phase-2 launch per step
@@ -688,10 +723,12 @@ def main():
     scheme = args.scheme
     if scheme in ('auto', 'stream'):
         try:
-            run_stream(args.warmup, -1000)
+            run_stream(max(args.warmup, 1), -1000)       # (--warmup 0: one probing step, outside the timed region)
             ok = 1.0
-        except EngineError as ex:       # a problem family the lifecycle kernel does not take (--n not a multiple of 16, ...)
-            if scheme == 'stream':
+        except EngineError as ex:
+            # only "this problem family is not the lifecycle kernels'" (several constraint classes, coupled constraints, ...) selects
+            # the other scheme; any other failure (a HIP error, bad arguments) is a failure of the benchmark
+            if scheme == 'stream' or ex.code != E_UNSUPPORTED:
                 raise
             sys.stderr.write('bench: scheme stream not available (%s): scheme two\n' % (ex,))
             ok = 0.0

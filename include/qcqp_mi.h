@@ -367,6 +367,12 @@ int qcqpmi_comm_barrier(qcqpmi_ctx *ctx);
  * step time, sum-over-ranks work counters; the exchange of a streamed run: the table of the local winners' keys of all
  * populations, then the table of the winners' points -- qcqp_amd.dist.global_best_of_populations) */
 int qcqpmi_comm_allreduce(qcqpmi_ctx *ctx, double *values, int64_t count, int op);
+/* all-gather of host bytes (ABI 5): every rank contributes nbytes bytes, recv receives world x nbytes bytes in rank order -- one
+ * ncclAllGather.  The exchange of a streamed run uses it for the local winners' KEYS: 32 bytes per population and rank -- the
+ * QCQPForm.better bucket int(maxviol / tol) (utilities.py:139-140), the objective, the max violation, the GLOBAL restart index
+ * (int64: exact; the ticket cap K R < 2^30 of qcqpmi_cd_stream_run bounds it per rank, not per job) -- then ONE sum-all-reduce of
+ * the K winners' points with only the owner's rows filled (qcqp_amd.dist.global_best_of_populations). */
+int qcqpmi_comm_allgather(qcqpmi_ctx *ctx, const void *send, int64_t nbytes, void *recv);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,7 @@ def lib():
         L.orc_rng_mt_set.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
         L.orc_rng_mt_get.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         L.orc_rng_set_restart.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_rng_set_ctx.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_rng_uniform.restype = C.c_double
         L.orc_rng_uniform.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.orc_rng_choice.restype = C.c_int64
@@ -135,6 +136,10 @@ class Rng:
         lib().orc_rng_mt_get(self.h, key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos))
         st = np.random.get_state()
         np.random.set_state((st[0], key, pos.value, st[3], st[4]))
+
+    def set_ctx(self, coord, sweep_tag, it):
+        """Keyed mode: the counter words (coordinate, sweep tag, bisection iteration) of the next draw."""
+        lib().orc_rng_set_ctx(self.h, int(coord), int(sweep_tag), int(it))
 
     def set_restart(self, r):
         lib().orc_rng_set_restart(self.h, int(r))

@@ -222,6 +222,9 @@ static void rng_ctx(orc_rng *g, uint32_t coord, uint32_t sweep_tag, uint32_t ite
     if (!g) return;
     g->coord = coord; g->sweep_tag = sweep_tag; g->iter = iter;
 }
+/* the counter words of the NEXT keyed draw, set from outside: lets tests/test_oracle_golden.py pin orc_rng_uniform / orc_rng_choice
+ * in keyed mode against the committed Philox table (tests/golden/g11_philox_keyed.npz) for arbitrary (coordinate, sweep tag, iteration) */
+void orc_rng_set_ctx(orc_rng *g, uint32_t coord, uint32_t sweep_tag, uint32_t iter) { rng_ctx(g, coord, sweep_tag, iter); }
 
 /* np.random.uniform(lo, hi) (legacy: lo + (hi-lo)*random_double) */
 double orc_rng_uniform(orc_rng *g, double lo, double hi) {

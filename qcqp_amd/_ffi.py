@@ -82,6 +82,7 @@ PROTOTYPES = [
     ('qcqpmi_comm_select_best', C.c_int, [C.c_void_p, C.c_double, C.c_int64, c_ip, c_dp, c_dp, c_dp]),
     ('qcqpmi_comm_barrier', C.c_int, [C.c_void_p]),
     ('qcqpmi_comm_allreduce', C.c_int, [C.c_void_p, c_dp, C.c_int64, C.c_int]),
+    ('qcqpmi_comm_allgather', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 ]
 
 _lib = None

@@ -25,6 +25,9 @@ from .form import QCQPForm
 # never touches the root logger and reports per-run statistics instead: QCQP.last_stats and INFO records here)
 log = logging.getLogger('qcqp_amd')
 
+# improve(COORD_DESCENT): populations of at least this many points go through the lifecycle launch (see _improve)
+STREAM_MIN = 512
+
 
 class Variable(object):
     """Minimal stand-in for a cvxpy variable: ``size`` (rows, cols), ``value``, ``id``."""
@@ -272,9 +275,14 @@ class QCQP(object):
             self.engine.cd_reference_order(bool(kwargs.get('reference_order', False)))
             first_index = int(kwargs.get('first_index', 0))
             batches = getattr(self, '_batches', None) if self._resident_batches() else None
-            if batches is None and self.engine.pop_size >= 8192 and not kwargs.get('reference_order', False):
-                # one large population: more restarts than the chip has slots -- the lifecycle launch (phase 1, gate, phase 2
-                # and the evaluation inside one kernel) beats the separate launches from about two generations on; same restarts
+            # stream = True / False forces / forbids the lifecycle launch (qcqpmi_cd_stream_run: phase 1, gate, phase 2 and the
+            # evaluation of every restart inside ONE persistent kernel); default: from STREAM_MIN restarts on -- below that the
+            # launch is as long as its slowest restart either way and the serial kernels are the simpler path.  Same restarts,
+            # same points either way (tests/test_gpu_life.py); problems the kernel does not take fall back to qcqpmi_cd_run.
+            stream = kwargs.get('stream', None)
+            if stream is False:
+                batches = None
+            elif batches is None and not kwargs.get('reference_order', False) and (stream or self.engine.pop_size >= STREAM_MIN):
                 batches = (1, self.engine.pop_size, first_index)
             out = None
             if batches is not None:
@@ -291,9 +299,9 @@ class QCQP(object):
             if out is None:
                 out = self.engine.cd_run(phase1=phase1, num_iters=num_iters, viol_tol=viol_tol, tol=tol,
                                          seed=seed, first_index=first_index)
-            if batches is not None and getattr(self, '_batches', None) is not None and self._resident_batches():
+            if getattr(self, '_batches', None) is not None and self._resident_batches():
                 from .dist import select_best_host
-                Kb, Rb, _ = batches
+                Kb, Rb, _ = self._batches
                 self.batch_results = []
                 for b in range(Kb):
                     key = select_best_host(out['f0'][b * Rb:(b + 1) * Rb], out['maxviol'][b * Rb:(b + 1) * Rb], 1e-4)

@@ -1012,7 +1012,7 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
                 c->Kreal = kr;
             }
             c->symcls = false;
-            if (dp.K == 1 && maxc == 1) {
+            if (c->Kreal == 1 && maxc == 1) {        // (Kreal: the padded coordinates of n16 form a class of their own)
                 const int e0 = cptr[krep[0]];
                 c->symcls = cq[e0] == 0.0 && crel[e0] == RELOP_EQ && cp[e0] != 0.0;
             }
@@ -1806,6 +1806,27 @@ int qcqpmi_comm_allreduce(qcqpmi_ctx *c, double *values, int64_t count, int op) 
     HIPCHK(c, hipMemcpyAsync(buf, values, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
     NCCLCHK(c, rccl()->AllReduce(buf, buf, (size_t)count, ncclDouble, op == 0 ? ncclMax : ncclSum, c->comm, c->stream));
     HIPCHK(c, hipMemcpyAsync(values, buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// every rank contributes `nbytes` bytes; everyone receives the world x nbytes bytes in rank order (one ncclAllGather)
+int qcqpmi_comm_allgather(qcqpmi_ctx *c, const void *send, int64_t nbytes, void *recv) {
+    if (!c || !send || !recv || nbytes < 1 || nbytes > ((int64_t)1 << 28)) return QCQPMI_EINVAL;
+    if (!c->comm) return fail(c, QCQPMI_ESTATE, "comm_init has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t need = ((int64_t)(c->world + 1) * nbytes + 7) / 8;      // doubles: send area + receive area
+    if (need > c->comm_big_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_comm_big) (void)hipFree(c->d_comm_big);
+        c->d_comm_big = nullptr; c->comm_big_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_comm_big, (size_t)need * sizeof(double)));
+        c->comm_big_cap = need;
+    }
+    char *d_send = (char *)c->d_comm_big, *d_recv = d_send + nbytes;
+    HIPCHK(c, hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, rccl()->AllGather(d_send, d_recv, (size_t)nbytes, ncclInt8, c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(recv, d_recv, (size_t)nbytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -500,19 +500,20 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
         spins = 0;
         if (prof_on) { ptl = (long long)__builtin_amdgcn_s_memtime(); pw_part += ptl - tw0; pn_int++; }
         // ---- G + q/2 of the lane's own columns: its own plane, then the partial tiles, in a fixed order, then q/2
-        double gb[4], xn[4], rto[4];
+        double gb[4], xn[4], rto[4], t2o[4], hq4[4];
     #pragma unroll
         for (int v = 0; v < 4; v++) {
             double s = fixp[v * 64 + lane];
     #pragma unroll
             for (int w = 0; w < NMW; w++) s += part[w * 256 + v * 64 + lane];
-            s += hqb[4 * v + gq];
+            hq4[v] = hqb[4 * v + gq];
+            s += hq4[v];
             gb[v] = s;
             gtile[(4 * v + gq) * 16 + r] = s;             // kept for the generic path (the partial tiles are released now)
         }
         rq_sync_write(sy, RQ_CONS, (int)g + 1, lane);     // the partial tiles have been read (LDS is in order per wave)
     #pragma unroll
-        for (int v = 0; v < 4; v++) rto[v] = rtb[4 * v + gq];
+        for (int v = 0; v < 4; v++) { rto[v] = rtb[4 * v + gq]; t2o[v] = dgb[4 * v + gq]; }
         if (b == 0 && !S.conv && S.sweeps >= (int)a.num_iters) {      // sweep limit reached (qcqp.py:160): the restart is done
             S.conv = true;
             frz = true; facc = 0.0;                               // ... after one frozen sweep that evaluates its objective
@@ -579,7 +580,7 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
             allfar = allfar && (far || 4 * v + gq >= ncol);
             mv |= mvd ? (1u << (4 * v + gq)) : 0u;
             // f(x + d e_i) - f(x) = d (2 (P x)_i + q_i + P_ii d) = d (t2 d + 2 g):  g = G_i + q_i / 2 contains P_ii x_i
-            fadd = __builtin_fma(d, __builtin_fma(dgb[4 * v + gq], d, gb[v] + gb[v]), fadd);
+            fadd = __builtin_fma(d, __builtin_fma(t2o[v], d, gb[v] + gb[v]), fadd);
         }
         mv = rq_quad_or(mv);                                                       // bit c = coordinate c moved
         // per RESTART: does the block need the reference's arithmetic?  Only those restarts walk the generic loop
@@ -601,14 +602,14 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     const int c = 4 * v + gq;
-                    w = (c > cl && c <= ce) ? __builtin_fma(xn[v], gb[v] + hqb[c], w) : w;
+                    w = (c > cl && c <= ce) ? __builtin_fma(xn[v], gb[v] + hq4[v], w) : w;
                 }
                 facc = (cl >= 0 ? 0.0 : facc) + w;
                 if (over >= 0) done = true;
             } else if (frz || pre) {
                 double w = 0.0;
 #pragma unroll
-                for (int v = 0; v < 4; v++) w = __builtin_fma(xo[v], gb[v] + hqb[4 * v + gq], w);
+                for (int v = 0; v < 4; v++) w = __builtin_fma(xo[v], gb[v] + hq4[v], w);
                 facc += w;
             }
 #pragma unroll

@@ -59,28 +59,47 @@ def select_best_host(f0, maxviol, tol=1e-4, index_offset=0):
     return best
 
 
-def global_best_of_populations(allreduce_sum, rank, world, f0, maxviol, gindex, xs, tol=1e-4):
+def global_best_of_populations(allreduce_sum, rank, world, f0, maxviol, gindex, xs, tol=1e-4, allgather=None):
     """The global best of K populations at once -- ONE exchange for a whole streamed run instead of one per population.
     Every rank holds, per population k, its local winner (f0[k], maxviol[k], gindex[k] = GLOBAL restart index, xs[k] = the
-    point); `allreduce_sum(array) -> array` sums a float64 array over the ranks (RCCL all-reduce: Engine.comm_allreduce).
-    Round 1: the (world, K, 3) table of keys with only the own row filled; everyone then knows every rank's winners and
-    picks the owner per population (QCQPForm.better ordering, ties -> lowest global index).  Round 2: the (K, n) table of
-    points with only the rows this rank owns filled.  Returns ([(gindex, f0, maxviol)] * K, X (K, n)), identical on every rank."""
+    point).  Round 1, the keys: `allgather(array) -> (world,) + array.shape` (Engine.comm_allgather: one ncclAllGather) of the
+    K records (bucket:int64, f0:fp64 bits, maxviol:fp64 bits, gindex:int64) = 32 bytes per population and rank -- the
+    QCQPForm.better ordering (utilities.py:135-146) on (bucket, f0) with the global index as the final tie-break; integers
+    travel as integers.  Everyone then knows the owner of every population.  Round 2, the points: `allreduce_sum(array) -> array`
+    (Engine.comm_allreduce: one all-reduce) of the (K, n) table with only the rows this rank owns filled.  Bytes a rank sends:
+    32 K for the keys + at most 2 x 8 K n for the points (ring all-reduce), independent of the number of ranks.
+    Without `allgather` (older callers) the keys travel through a sum-all-reduce of the (world, K, 3) table like in round 4.
+    Returns ([(gindex, f0, maxviol)] * K, X (K, n)), identical on every rank."""
     f0 = np.asarray(f0, dtype=np.float64)
     K = f0.size
     xs = np.asarray(xs, dtype=np.float64).reshape(K, -1)
-    keys = np.zeros((world, K, 3))
-    keys[rank, :, 0], keys[rank, :, 1], keys[rank, :, 2] = f0, np.asarray(maxviol, dtype=np.float64), np.asarray(gindex, dtype=np.float64)
-    if world > 1:
-        keys = np.asarray(allreduce_sum(keys.ravel())).reshape(world, K, 3)
-    owner = [min(range(world), key=lambda g: better_key(keys[g, k, 0], keys[g, k, 1], int(keys[g, k, 2]), tol)) for k in range(K)]
+    mv = np.asarray(maxviol, dtype=np.float64)
+    gi = np.asarray(gindex, dtype=np.int64)
+    if world > 1 and allgather is not None:
+        rec = np.zeros((K, 4), dtype=np.int64)
+        rec[:, 0] = [better_key(f0[k], mv[k], 0, tol)[0] for k in range(K)]
+        rec[:, 1] = f0.view(np.int64)
+        rec[:, 2] = mv.view(np.int64)
+        rec[:, 3] = gi
+        allrec = np.asarray(allgather(rec)).reshape(world, K, 4)
+        fall = np.ascontiguousarray(allrec[:, :, 1]).view(np.float64)
+        vall = np.ascontiguousarray(allrec[:, :, 2]).view(np.float64)
+        iall = allrec[:, :, 3]
+        owner = [min(range(world), key=lambda g: (int(allrec[g, k, 0]), float(fall[g, k]), int(iall[g, k]))) for k in range(K)]
+    else:
+        keys = np.zeros((world, K, 3))
+        keys[rank, :, 0], keys[rank, :, 1], keys[rank, :, 2] = f0, mv, gi.astype(np.float64)
+        if world > 1:
+            keys = np.asarray(allreduce_sum(keys.ravel())).reshape(world, K, 3)
+        fall, vall, iall = keys[:, :, 0], keys[:, :, 1], keys[:, :, 2].astype(np.int64)
+        owner = [min(range(world), key=lambda g: better_key(fall[g, k], vall[g, k], int(iall[g, k]), tol)) for k in range(K)]
     X = np.zeros_like(xs)
     for k in range(K):
         if owner[k] == rank:
             X[k] = xs[k]
     if world > 1:
         X = np.asarray(allreduce_sum(X.ravel())).reshape(K, -1)
-    return [(int(keys[owner[k], k, 2]), float(keys[owner[k], k, 0]), float(keys[owner[k], k, 1])) for k in range(K)], X
+    return [(int(iall[owner[k], k]), float(fall[owner[k], k]), float(vall[owner[k], k])) for k in range(K)], X
 
 
 def _job_key():

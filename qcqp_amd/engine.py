@@ -440,6 +440,7 @@ class Engine(object):
     def comm_init(self, rank, world, uid):
         uid = np.ascontiguousarray(uid, dtype=np.uint8)
         self._chk(self.L.qcqpmi_comm_init(self.h, int(rank), int(world), _bp(uid)))
+        self._world = int(world)
 
     def comm_barrier(self):
         self._chk(self.L.qcqpmi_comm_barrier(self.h))
@@ -448,6 +449,15 @@ class Engine(object):
         v = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)))
         self._chk(self.L.qcqpmi_comm_allreduce(self.h, _dp(v), v.size, 0 if op == 'max' else 1))
         return v
+
+    def comm_allgather(self, arr):
+        """All-gather of a contiguous array: returns an array of shape (world,) + arr.shape with every rank's contribution in rank
+        order (one ncclAllGather of the raw bytes: integer fields travel exactly)."""
+        a = np.ascontiguousarray(arr)
+        world = int(self._world) if getattr(self, '_world', None) else 1
+        out = np.empty((world,) + a.shape, dtype=a.dtype)
+        self._chk(self.L.qcqpmi_comm_allgather(self.h, a.ctypes.data_as(C.c_void_p), a.nbytes, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def comm_select_best(self, tol=1e-4, index_offset=0):
         idx = np.zeros(1, dtype=np.int64)

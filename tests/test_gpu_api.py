@@ -388,7 +388,7 @@ def test_suggest_batches_streams_improve(n):
     q.suggest(RANDOM, num_samples=R, batches=K, seed=5)
     f, v = q.improve(COORD_DESCENT, seed=7)
     if n == 64:
-        assert q.engine.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
+        assert q.engine.last_cd_kernel() == 'cd_life_kernel<3,band>'
     assert len(q.batch_results) == K
     q2 = QCQP(form)
     serial = []
@@ -521,12 +521,12 @@ def test_large_population_takes_the_lifecycle_launch():
     q.suggest(RANDOM, num_samples=8192, seed=4)
     X0 = q.population()
     f, v = q.improve(COORD_DESCENT, seed=9)
-    assert q.engine.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
+    assert q.engine.last_cd_kernel() == 'cd_life_kernel<3,band>'
     X = q.population()
     q2 = QCQP(form)
     q2.engine.upload(X0)
     out = q2.engine.cd_run(phase1=True, seed=9)
-    assert q2.engine.last_cd_kernel() != 'cd_phase2_qs_kernel<lifecycle>'
+    assert not q2.engine.last_cd_kernel().startswith('cd_life_kernel')
     assert np.max(np.abs(X - q2.engine.download())) < 1e-12
     idx, fb, vb, xb = q2.engine.select_best(1e-4)
     assert q.best_index == idx and abs(f - fb) <= 1e-11 * (1 + abs(fb)) and abs(v - vb) <= 1e-12

@@ -1,0 +1,277 @@
+"""GPU parity tests of cd_life_kernel (csrc/cd_life.hip, round 5) -- improve_coord_descent (qcqp.py:181-192: phase 1 qcqp.py:101-149,
+gate :189, phase 2 :152-178) for a queue of restarts inside ONE persistent launch, for every problem class the kernel takes:
+the Boolean family at any n (also n not a multiple of 16), box / disc families (one interval per coordinate), MAXCUT (zero
+diagonal: the scalar objective is linear) up to BASELINE.json configs[2]'s n = 2000.  Every case goes against
+  * the ORACLE (oracle/: the C restatement of the reference, keyed Philox stream), >= 8 trajectories per family, 16 at the headline size,
+  * the serial path (qcqpmi_pop_randn + qcqpmi_cd_run per population: other kernels, same draws),
+  * where it applies, the round-4 lifecycle kernel (cd_phase2_qs_kernel<lifecycle>).
+Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import oracle_map
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ('sweeps1', 'sweeps2', 'visits2', 'accepted2', 'ran_phase2', 'status1', 'status2')
+
+
+@pytest.fixture(scope='module')
+def eng_mod():
+    from qcqp_amd import engine
+    assert engine.device_count() >= 1, 'no HIP device visible'
+    return engine
+
+
+def make(eng_mod, funcs):
+    from qcqp_amd.form import QCQPForm
+    return eng_mod.Engine(QCQPForm.from_arrays(funcs))
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b)) / (1.0 + np.abs(np.asarray(b))))
+
+
+def family(name, n):
+    from qcqp_amd import problems
+    if name == 'bls':
+        return problems.boolean_least_squares(n, max(4, n // 4), seed=1)[0]
+    if name == 'box':
+        return problems.box_least_squares(n, max(4, n // 2), bound=1.0, seed=1)[0]
+    if name == 'disc':          # x_i^2 <= 0.49 around an objective whose unconstrained minimiser lies outside: active bounds
+        return problems.box_least_squares(n, max(4, n // 3), bound=0.7, seed=5)[0]
+    if name == 'maxcutw':       # weighted edges: no exact ties between cuts (see test_maxcut_unweighted_* for the tied case)
+        return problems.maxcut(n, 0.5, seed=1, weighted=True)[0]
+    raise KeyError(name)
+
+
+def oracle_restarts(orc, funcs, eng_mod, seed, first, R, picks, iters):
+    """improve_coord_descent of the oracle on the keyed normals of restarts `picks` of the population (seed, first)."""
+    e = make(eng_mod, funcs)
+    e.randn(R, seed=seed, first_index=first)
+    X0 = e.download()
+    prob = orc.Problem(funcs)
+
+    def run(r):
+        rng = orc.Rng(orc.RNG_KEYED, seed)
+        rng.set_restart(first + r)
+        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+        return r, x, s1, s2, prob.eval(0, x), prob.max_violation(x)
+    return oracle_map(run, picks)
+
+
+CASES = [
+    # family, n, R, K, num_iters, oracle restarts per population, kernel name
+    ('bls', 128, 100, 3, 1000, 8, 'cd_life_kernel<3,band>'),
+    ('bls', 1000, 200, 2, 1000, 4, 'cd_life_kernel<3,band>'),          # n not a multiple of 16; 8 oracle trajectories in all
+    ('bls', 1024, 4096, 2, 1000, 8, 'cd_life_kernel<3,band>'),         # BASELINE.json configs[1]: 16 oracle trajectories in all
+    ('bls', 50, 40, 2, 1000, 8, 'cd_life_kernel<3,band>'),             # NB = 4: no chain share
+    ('bls', 1040, 32, 1, 3, 8, 'cd_life_kernel<7,band>'),              # just past 1024: eight waves, seven multiplying (three sweeps:
+                                                                        # the serial path's kernel for n > 1024 takes minutes to converge)
+    ('box', 128, 100, 2, 1000, 8, 'cd_life_kernel<3,gen>'),
+    ('box', 1000, 128, 2, 4, 4, 'cd_life_kernel<3,gen>'),             # (the box family takes ~170 sweeps: four of them here, then the frozen sweep)
+    ('disc', 200, 64, 2, 1000, 8, 'cd_life_kernel<3,gen>'),
+    ('maxcutw', 200, 64, 2, 1000, 8, 'cd_life_kernel<3,lin>'),
+    ('maxcutw', 2000, 64, 1, 2, 8, 'cd_life_kernel<7,lin>'),           # configs[2]'s size; two sweeps: frozen sweeps evaluate the objective
+]
+
+
+@pytest.mark.parametrize('fam,n,R,K,iters,norc,kname', CASES)
+def test_life_kernel_vs_oracle_and_serial(eng_mod, orc, fam, n, R, K, iters, norc, kname):
+    """Every restart of the launch is the restart the reference computes: `norc` restarts per population through the oracle
+    (points 1e-9, every counter, objective and max violation against the oracle's evaluation of its own point), ALL restarts
+    against the serial path (points 1e-12: the same arithmetic per column in another kernel), the reported objective / max
+    violation against a fresh evaluation of the returned points, the per-population winner against select_best."""
+    funcs = family(fam, n)
+    es = make(eng_mod, funcs)
+    seed0, sstride, first0, fstride = 500, 3, 11, 70000
+    o = es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=sstride, first_index=first0, first_stride=fstride)
+    assert es.last_cd_kernel() == kname
+    assert es.pop_size == K * R
+    X = es.download()
+    f0e, mve = es.eval()
+    assert rel(o['f0'], f0e) < 1e-11 and np.max(np.abs(o['maxviol'] - mve)) < 1e-12
+    e = make(eng_mod, funcs)
+    for p in range(K):
+        sd, fi = seed0 + p * sstride, first0 + p * fstride
+        sl = slice(p * R, (p + 1) * R)
+        # ---- the oracle
+        picks = sorted(set(np.linspace(0, R - 1, norc).astype(int).tolist()))
+        for r, x, s1, s2, f_or, v_or in oracle_restarts(orc, funcs, eng_mod, sd, fi, R, picks, iters):
+            k = p * R + r
+            assert rel(X[:, k], x) < 1e-9, (fam, n, p, r, np.max(np.abs(X[:, k] - x)))
+            # (a restart that phase 1 cannot improve any further stops after its first sweep without an update; the reference burns
+            #  all num_iters sweeps on the same point: documented deviation 4)
+            assert o['sweeps1'][k] == s1[0] or (s1[0] == iters and not o['ran_phase2'][k])
+            assert o['visits2'][k] == s2[1] and o['accepted2'][k] == s2[2], (fam, n, p, r)
+            assert abs(o['f0'][k] - f_or) <= 1e-9 * (1 + abs(f_or)) and abs(o['maxviol'][k] - v_or) <= 1e-12
+        # ---- the serial path
+        e.randn(R, seed=sd, first_index=fi)
+        outr = e.cd_run(phase1=True, num_iters=iters, seed=sd, first_index=fi)
+        Xr = e.download()
+        assert rel(X[:, sl], Xr) < 1e-12, (fam, n, p, np.max(np.abs(X[:, sl] - Xr)))
+        for key in COUNTERS:
+            assert np.array_equal(o[key][sl], outr[key]), (fam, n, p, key)
+        assert rel(o['f0'][sl], outr['f0']) < 1e-11
+        idx, fb, vb, xb = e.select_best(1e-4)
+        assert o['best_index'][p] == idx and o['best_f0'][p] == o['f0'][sl][idx] and o['best_maxviol'][p] == o['maxviol'][sl][idx]
+        assert np.array_equal(o['best_x'][p], X[:, p * R + idx])
+
+
+def test_life_kernel_equals_round4_lifecycle_kernel(eng_mod):
+    """Where both apply (Boolean family, n a multiple of 16, n <= 1024) the two lifecycle kernels produce the same restarts:
+    points to rounding of nothing, all counters equal -- four waves and a global tile against eight waves and an LDS tile."""
+    from qcqp_amd import problems
+    for n, R, K in ((256, 600, 3), (1024, 1024, 2)):
+        funcs, _, _ = problems.boolean_least_squares(n, n // 4, seed=2)
+        e2, e1 = make(eng_mod, funcs), make(eng_mod, funcs)
+        e1.cd_life_version(1)
+        o2 = e2.cd_stream_run(K, R, seed=9, seed_stride=2, first_index=100, first_stride=5000)
+        o1 = e1.cd_stream_run(K, R, seed=9, seed_stride=2, first_index=100, first_stride=5000)
+        assert e2.last_cd_kernel() == 'cd_life_kernel<3,band>' and e1.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
+        assert np.max(np.abs(e2.download() - e1.download())) < 1e-12
+        for key in COUNTERS:
+            assert np.array_equal(o2[key], o1[key]), key
+        assert rel(o2['f0'], o1['f0']) < 1e-11 and np.array_equal(o2['best_index'], o1['best_index'])
+
+
+def test_life_kernel_scheduling_invariance(eng_mod):
+    """A restart's result does not depend on the slot, the workgroup, the episode boundaries or the number of populations in the
+    launch: the same 96 restarts as one population, as three populations of 32 and with the launch confined to 3 workgroups are
+    bit-identical (every product is summed in one association wherever an episode begins)."""
+    from qcqp_amd import problems
+    funcs = family('box', 176)
+    ref = None
+    for K, R, dbg in ((1, 96, 0), (3, 32, 0), (1, 96, 1024 | (3 << 12))):
+        e = make(eng_mod, funcs)
+        if dbg:
+            e.L.qcqpmi_debug_profile(e.h, dbg << 4, None)
+        o = e.cd_stream_run(K, R, num_iters=400, seed=77, seed_stride=0, first_index=5, first_stride=R)
+        got = (e.download(), o['f0'].copy(), o['visits2'].copy(), o['accepted2'].copy())
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b)
+
+
+def test_life_kernel_uploaded_starts_and_gate(eng_mod, orc):
+    """generate = 0: improve() on resident points (the reference's improve after the user set the variables), with and without
+    phase 1; restarts that do not pass the gate (qcqp.py:189) keep their point and report its objective (one frozen sweep)."""
+    funcs = family('box', 100)
+    n, R = 100, 48
+    rs = np.random.RandomState(4)
+    X0 = rs.randn(n, R) * 1.5
+    X0[:, ::3] = np.clip(X0[:, ::3], -0.99, 0.99)          # a third of the starts is feasible already
+    prob = orc.Problem(funcs)
+    for phase1 in (True, False):
+        e = make(eng_mod, funcs)
+        e.upload(X0)
+        o = e.cd_stream_run(1, R, generate=False, phase1=phase1, num_iters=500, seed=3, first_index=40)
+        assert e.last_cd_kernel() == 'cd_life_kernel<3,gen>'
+        X = e.download()
+        ran = o['ran_phase2'].astype(bool)
+        assert ran.any() and (phase1 or (~ran).any())
+        for r in range(0, R, 5):
+            rng = orc.Rng(orc.RNG_KEYED, 3)
+            rng.set_restart(40 + r)
+            x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=500, phase1=phase1, rng=rng)
+            assert rel(X[:, r], x) < 1e-9, (phase1, r)
+            assert abs(o['f0'][r] - prob.eval(0, x)) <= 1e-9 * (1 + abs(prob.eval(0, x)))
+        if not phase1:
+            assert np.array_equal(X[:, ~ran], X0[:, ~ran])
+
+
+def test_maxcut_unweighted_ties_are_the_references(eng_mod, orc):
+    """Unweighted MAXCUT (examples/maxcut.py: W in {0, 1}) is full of EXACT ties: once every |x_j| sits at the same end point, a
+    vertex with as many neighbours on either side has t1 = 0 up to the rounding of the row sum -- and the reference's onevar_qcqp
+    then either draws a uniform point (t1 == 0 exactly, utilities.py:266-267) or picks one of four end points at random (t1 = +-1e-16,
+    utilities.py:275-288): WHICH depends on the summation order of the row, i.e. on the BLAS / CSR layout.  No arithmetic other
+    than SciPy's can follow such a restart (the weighted family above is followed to 1e-9).  What is asserted instead: restarts
+    whose oracle trajectory never met a tie are reproduced exactly; all restarts end feasible with the objective a fresh
+    evaluation of the returned point; the population's cut values have the oracle's distribution."""
+    from qcqp_amd import problems
+    n, R = 200, 96
+    funcs, _, _ = problems.maxcut(n, 0.5, seed=1)
+    e = make(eng_mod, funcs)
+    o = e.cd_stream_run(1, R, num_iters=300, seed=21, first_index=0)
+    assert e.last_cd_kernel() == 'cd_life_kernel<3,lin>'
+    X = e.download()
+    f0e, mve = e.eval()
+    ran = o['ran_phase2'].astype(bool)
+    assert rel(o['f0'], f0e) < 1e-11 and ran.sum() >= R - 2 and np.all(o['maxviol'][ran] <= 1e-2)
+    res = oracle_restarts(orc, funcs, eng_mod, 21, 0, R, list(range(R)), 300)
+    f_or = np.array([t[4] for t in res])
+    same = np.array([rel(X[:, r], x) < 1e-9 for r, x, *_ in res])
+    print('unweighted MAXCUT n = %d: %d of %d restarts identical to the oracle; median cut value engine %.1f / oracle %.1f'
+          % (n, int(same.sum()), R, -np.median(o['f0']), -np.median(f_or)))
+    assert same.sum() >= R // 8
+    # same distribution of local optima: medians within 1 % of the spread-normalised cut value, best within 1 %
+    assert abs(np.median(o['f0']) - np.median(f_or)) < 0.01 * abs(np.median(f_or))
+    assert abs(o['f0'].min() - f_or.min()) < 0.01 * abs(f_or.min())
+
+
+def test_stream_run_refusal_leaves_population(eng_mod):
+    """A problem the lifecycle kernels do not take (two constraint classes) is refused BEFORE the resident population is touched
+    (ADVICE round 4): the points uploaded before the call are still there and still evaluate."""
+    from qcqp_amd import problems
+    funcs, _, _ = problems.boolean_least_squares(64, 16, seed=1)
+    funcs = [funcs[0]] + [(P * (1.0 + (i % 2)), q, r * (1.0 + (i % 2)), rel_) for i, (P, q, r, rel_) in enumerate(funcs[1:])]
+    e = make(eng_mod, funcs)
+    X0 = np.random.RandomState(0).randn(64, 24)
+    e.upload(X0)
+    with pytest.raises(eng_mod.EngineError) as ei:
+        e.cd_stream_run(2, 50, seed=1)
+    assert ei.value.code == eng_mod.E_UNSUPPORTED
+    assert e.pop_size == 24 and np.array_equal(e.download(), X0)
+    f0, mv = e.eval()
+    assert np.all(np.isfinite(f0))
+
+
+def test_comm_allgather_over_rccl_one_rank(eng_mod):
+    """qcqpmi_comm_allgather (round 5: the 32-byte keys of a streamed run's exchange travel through ONE ncclAllGather, integers as
+    integers) on the library's communicator: with one rank the gathered table is the contribution itself, for byte counts that
+    are not multiples of 8 and for int64 fields beyond 2^53."""
+    from qcqp_amd import dist, problems
+    funcs, _, _ = problems.boolean_least_squares(64, 16, seed=7)
+    e = make(eng_mod, funcs)
+    dist.init_rccl(e, 0, 1)
+    rec = np.array([[3, np.float64(1.25).view(np.int64), (1 << 62) + 12345, -7]] * 5, dtype=np.int64)
+    out = e.comm_allgather(rec)
+    assert out.shape == (1, 5, 4) and out.dtype == np.int64 and np.array_equal(out[0], rec)
+    odd = np.arange(13, dtype=np.uint8)
+    assert np.array_equal(e.comm_allgather(odd)[0], odd)
+    o = e.cd_stream_run(4, 40, seed=3, seed_stride=1)
+    ks, X = dist.global_best_of_populations(lambda a: e.comm_allreduce(a, 'sum'), 0, 1, o['best_f0'], o['best_maxviol'], o['best_index'],
+                                            o['best_x'], allgather=e.comm_allgather)
+    assert [k[0] for k in ks] == list(o['best_index']) and np.array_equal(X, o['best_x'])
+
+
+@pytest.mark.parametrize('launch', ['torch_distributed_run', 'visible_devices'])
+def test_bench_under_the_drivers_launcher_on_one_gpu(tmp_path, launch):
+    """bench.py the way the driver starts it for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- with the one GPU this box has (N = 1): RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* come from the launcher, the RCCL communicator is created on the real device, comm_barrier and the max / sum
+    all-reduces of the timing run through RCCL, one JSON line comes out.  And under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES
+    = 0, the isolation a launcher may set per rank: Engine(device=LOCAL_RANK) must still find its device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--n', '128', '--m-rows', '32', '--restarts', '256',
+            '--no-secondary', '--no-cpu-baseline']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'QCQP_AMD_RDZV')}
+    if launch == 'torch_distributed_run':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+               '--master-port', str(29400 + os.getpid() % 500)] + args
+    else:
+        cmd = [sys.executable] + args
+        env.update(HIP_VISIBLE_DEVICES='0', ROCR_VISIBLE_DEVICES='0')
+    pr = subprocess.run(cmd, cwd=repo, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert pr.returncode == 0, pr.stderr.decode()[-3000:]
+    lines = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, pr.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['config']['scheme'] == 'stream' and d['value'] > 0
+    assert d['roofline']['kernel'].startswith('cd_life_kernel')

@@ -1,4 +1,5 @@
-"""GPU parity tests of the LIFECYCLE mode of the slot-queue kernel (qcqpmi_cd_stream_run, csrc/cd_queue.hip): K populations of R
+"""GPU parity tests of the lifecycle launch (qcqpmi_cd_stream_run) -- every test with BOTH kernels: cd_life_kernel (csrc/cd_life.hip,
+round 5, the default) and the lifecycle mode of the slot-queue kernel it replaced (csrc/cd_queue.hip, round 4) --: K populations of R
 restarts -- suggest(RANDOM) + improve(COORD_DESCENT) + best point each, the reference's user loop (README.md:51-57, qcqp.py:381-382,
 181-192) -- inside ONE persistent launch, against the serial path (one qcqpmi_pop_randn + qcqpmi_cd_run per population) and against
 the oracle.  Run with `-m gpu` on an MI355X."""
@@ -15,9 +16,22 @@ def eng_mod():
     return engine
 
 
+LIFE = {'version': 2}
+KNAME = {2: 'cd_life_kernel<3,band>', 1: 'cd_phase2_qs_kernel<lifecycle>'}
+
+
+@pytest.fixture(autouse=True, params=[2, 1], ids=['cd_life_kernel', 'round4_lifecycle_kernel'])
+def life_version(request):
+    LIFE['version'] = request.param
+    yield request.param
+    LIFE['version'] = 2
+
+
 def make(eng_mod, funcs):
     from qcqp_amd.form import QCQPForm
-    return eng_mod.Engine(QCQPForm.from_arrays(funcs))
+    e = eng_mod.Engine(QCQPForm.from_arrays(funcs))
+    e.cd_life_version(LIFE['version'])
+    return e
 
 
 def rel(a, b):
@@ -47,7 +61,7 @@ def test_cd_stream_run_equals_serial_runs(eng_mod, orc, n, m_rows, R, K, iters):
     if K > 1:
         es.cd_stream_reserve(K, R)          # buffers ahead of the run (qcqpmi_cd_stream_reserve): allocation only, same results
     o = es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=sstride, first_index=first0, first_stride=fstride)
-    assert es.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
+    assert es.last_cd_kernel() == KNAME[LIFE['version']]
     assert es.pop_size == K * R
     X = es.download()
     f0e, mve = es.eval()        # fresh evaluation of all final points by the evaluation kernel
@@ -158,13 +172,23 @@ def test_cd_stream_run_exact_ties_take_the_reference_path(eng_mod, orc):
 
 
 def test_cd_stream_run_refuses_other_families(eng_mod):
-    """The lifecycle kernel is the Boolean family's (one mirrored equality class on a positive diagonal, n a multiple of 16): a box
-    family is refused with a message that names the serial entry point -- no silent fallback."""
+    """No silent fallback: a family the kernel does not take is refused with a message that names the serial entry point -- for the
+    round-4 kernel anything but the Boolean family with n a multiple of 16; for cd_life_kernel several constraint classes (a
+    different right-hand side on every other coordinate), which it refuses, while n = 40 runs."""
     from qcqp_amd import problems
     funcs, _, _ = problems.boolean_least_squares(40, 10, seed=1)       # n not a multiple of 16
     e = make(eng_mod, funcs)
-    with pytest.raises(eng_mod.EngineError, match='lifecycle'):
+    if LIFE['version'] == 1:
+        with pytest.raises(eng_mod.EngineError, match='lifecycle'):
+            e.cd_stream_run(2, 32)
+    else:
         e.cd_stream_run(2, 32)
+        assert e.last_cd_kernel() == 'cd_life_kernel<3,band>'
+    funcs2 = [funcs[0]] + [(P * (1.0 + (i % 2)), q, r * (1.0 + (i % 2)), rl) for i, (P, q, r, rl) in enumerate(funcs[1:])]
+    e2 = make(eng_mod, funcs2)
+    with pytest.raises(eng_mod.EngineError, match='lifecycle') as ei:
+        e2.cd_stream_run(2, 32)
+    assert ei.value.code == eng_mod.E_UNSUPPORTED
 
 
 @pytest.mark.parametrize('K,R,iters,p1', [(3, 1, 1000, True),       # single-restart populations (the reference's own use)
@@ -228,3 +252,4 @@ def test_streamed_run_exchange_over_rccl_one_rank(eng_mod):
     assert calls == [K * 3, K * 64] and np.array_equal(kk, keys) and np.array_equal(xx, o['best_x'])
     ks, X = dist.global_best_of_populations(allreduce, 0, 1, o['best_f0'], o['best_maxviol'], o['best_index'], o['best_x'])
     assert [k[0] for k in ks] == list(o['best_index']) and np.array_equal(X, o['best_x'])
+

@@ -213,3 +213,34 @@ def test_generated_eval_matches_materialised_functions(orc):
         ref = np.array([X[:, s].dot(P).dot(X[:, s]) + q.dot(X[:, s]) + r for s in range(3)])
         got = orc.generated_eval(form.specs[k], k, n, X)
         assert np.allclose(ref, got, rtol=1e-13, atol=1e-13), (k, ref, got)
+
+
+def test_g11_keyed_rng_branch_against_independent_philox_table(orc):
+    """The KEYED branch of the oracle's random numbers -- orc_philox4x32, keyed_draw's counter layout, orc_rng_uniform /
+    orc_rng_choice and orc_keyed_normal -- against tests/golden/g11_philox_keyed.npz: a table computed by
+    tools/gen_philox_table.py with arbitrary-precision Python integers (nothing shared with the C code) and checked there
+    against Random123's published known-answer vectors of philox4x32_10.  Every GPU parity test of phase 1 compares the
+    engine with the oracle in this mode; no fixture of the reference can pin it (the reference draws from MT19937)."""
+    import ctypes as C
+    z = load_golden('g11_philox_keyed')
+    L = orc.lib()
+    out = (C.c_uint32 * 4)()
+    for ctr, key, want in zip(z['kat_ctr'], z['kat_key'], z['kat_out']):      # Random123 known answers through the oracle's rounds
+        L.orc_philox4x32((C.c_uint32 * 4)(*[int(v) for v in ctr]), (C.c_uint32 * 2)(*[int(v) for v in key]), out)
+        assert [int(v) for v in out] == [int(v) for v in want]
+    N = len(z['seed'])
+    for j in range(N):
+        sd, rr = int(z['seed'][j]), int(z['restart'][j])
+        ctr = (C.c_uint32 * 4)(int(z['coord'][j]), int(z['sweep'][j]), int(z['it'][j]), rr & 0xffffffff)
+        key = (C.c_uint32 * 2)(sd & 0xffffffff, (sd >> 32) & 0xffffffff)
+        L.orc_philox4x32(ctr, key, out)
+        assert [int(v) for v in out] == [int(v) for v in z['words'][j]], j
+        g = orc.Rng(orc.RNG_KEYED, sd)
+        g.set_restart(rr)
+        g.set_ctx(z['coord'][j], z['sweep'][j], z['it'][j])
+        assert g.uniform(float(z['lo'][j]), float(z['hi'][j])) == z['uniform'][j], j          # np.random.uniform stand-in (utilities.py:267)
+        g.set_ctx(z['coord'][j], z['sweep'][j], z['it'][j])
+        assert g.choice(int(z['k'][j])) == int(z['choice'][j]), j                              # np.random.choice stand-in (utilities.py:266, 288)
+        assert g.choice(1) == 0
+        nv = orc.keyed_normal(sd, rr, int(z['elem'][j]))
+        assert abs(nv - z['normal'][j]) <= 4e-16 * (1.0 + abs(z['normal'][j])), (j, nv, z['normal'][j])   # libm's log / sin / cos: last-bit slack
