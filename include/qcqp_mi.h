@@ -266,13 +266,14 @@ int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);     /* 0 off, 1 on wherever it a
  * spin-waiting launch for several contexts.  They needed GPU_MAX_HW_QUEUES > 4, worked on the 192-CU partition only and could
  * stall; qcqpmi_cd_stream_run below does what they were after inside ONE self-contained launch.) */
 /* debug (after qcqpmi_debug_profile enabled profiling): tick sums (s_memtime) over the workgroups of the last
- * qcqpmi_cd_stream_run launch, SIXTEEN entries (ABI 5; 8 before) -- [0] column build (suggest + phase 1 + gate), [1] whole launch,
+ * qcqpmi_cd_stream_run launch, TWENTY-FOUR entries (ABI 5; 8 before) -- [0] column build (suggest + phase 1 + gate), [1] whole launch,
  * [2] episodes, [3] columns built, [4] the normals' share of [0], [5] the roles of the episodes (the rest: write-out, queue,
  * refill); cd_life_kernel only: [6] workgroups whose waves covered the four SIMDs evenly, [8] the chain waves' wait for
  * partial tiles, [9] / [10] multiplying wave 0's waits for a commit / for its slot, [11] block intervals, [12] blocks with a
  * near-tie replay, [13] / [14] / [15] / [7] the chain's stages: sum of the partial tiles + requests, the 16 steps, block end +
- * commit, fix-up + own share + staging */
-int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out16);
+ * commit, fix-up + own share + staging, [16] the longest workgroup's [1] (ticks of the launch as the device saw it: with the
+ * HIP-event duration the tick rate; [1] / workgroups / [16] = how much of the launch the average workgroup was alive) */
+int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out24);
 /* POPULATION STREAMING (round 4) -- the reference's user loop `for ...: suggest(); improve(COORD_DESCENT)` (README.md:51-57)
  * for K populations of R restarts in ONE persistent launch: a workgroup owns 16 restart slots; a slot that becomes free draws
  * the next restart index of the run and runs that restart's WHOLE step itself -- suggest(RANDOM) (qcqp.py:381-382; the keyed

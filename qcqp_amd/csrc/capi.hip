@@ -1532,8 +1532,8 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     L.sweeps1 = c->d_sweeps1; L.status1 = c->d_status1; L.ran2 = c->d_flag;
     L.prof = nullptr;
     if (c->profile) {      // qcqpmi_debug_profile: tick sums of the launch (qcqpmi_debug_life_profile)
-        if (!c->d_life_prof) HIPCHK(c, hipMalloc((void **)&c->d_life_prof, 16 * sizeof(long long)));
-        HIPCHK(c, hipMemsetAsync(c->d_life_prof, 0, 16 * sizeof(long long), c->stream));
+        if (!c->d_life_prof) HIPCHK(c, hipMalloc((void **)&c->d_life_prof, 24 * sizeof(long long)));
+        HIPCHK(c, hipMemsetAsync(c->d_life_prof, 0, 24 * sizeof(long long), c->stream));
         L.prof = c->d_life_prof;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_life, &L, sizeof(L), hipMemcpyHostToDevice, c->stream));
@@ -1550,7 +1550,7 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         qa.P = c->dp; qa.num_iters = num_iters; qa.tol = tol; qa.life = c->d_life;
         cd_queue_fill_batch(c, qa.b, seed, first_index);
         qa.b.R = K * R;
-        qa.scratch = c->l2_scratch; qa.Dpack = c->l2_D; qa.Spack = c->l2_S; qa.abort = c->l2_abort; qa.fbound = c->fbound;
+        qa.scratch = c->l2_scratch; qa.Dpack = c->l2_D; qa.Spack = c->l2_S; qa.abort = c->l2_abort; qa.fbound = c->fbound; qa.dbg = (c->dbg & 2048) ? 1 : 0;
         if (c->dbg & 128) { const int k2 = (c->dbg >> 8) & 7; if (nmw == 3 && (k2 == 0 || k2 == 2 || k2 == 4) && k2 < (int)(c->n16 / 16)) cs2 = k2; }
         (void)hipEventRecord(c->timers[2].beg, c->stream);
         hipError_t qe = (hipError_t)cd_life2_launch(qa, nmw, cs2, kind, (int)wgs, c->stream);
@@ -1631,11 +1631,11 @@ int qcqpmi_cd_stream_reserve(qcqpmi_ctx *c, int64_t K, int64_t R) {
 
 int qcqpmi_debug_life_profile(qcqpmi_ctx *c, int64_t *out16) {
     if (!c || !out16) return QCQPMI_EINVAL;
-    for (int k = 0; k < 16; k++) out16[k] = 0;
+    for (int k = 0; k < 24; k++) out16[k] = 0;
     if (!c->d_life_prof) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out16, c->d_life_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out16, c->d_life_prof, 24 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

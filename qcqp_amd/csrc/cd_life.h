@@ -44,6 +44,7 @@ struct CdLife2Args {
     const double *Spack;         // [NB][48]: q0 / 2, 1 / P0[i,i] (0 where the diagonal is 0), P0[i,i] of the block's coordinates
     int *abort;                  // [0] set by a wave whose wait ran into the watchdog (a bug, never the data): the launch unwinds
     double fbound;               // sum |P0| + sum |q0| + |r0|: scale of the objective for the near-tie test of the linear kind
+    int dbg;                     // timing experiments (results INVALID when != 0): 1 = every block row reads the fragments of rows 0..7 (an L2-resident stream)
 };
 
 // does the kernel take this problem?  nmw / cs / kind: the instantiation (multiplying waves 3 | 7, chain share, step kind)

@@ -170,6 +170,7 @@ __device__ __attribute__((always_inline)) inline v4d_ l2_product(v2d_ (&ar)[2 * 
     int *p1st = (int *)sp; sp += 8; \
     int *gatep = (int *)sp; sp += 8; \
     int *simdof = (int *)sp; sp += 8; \
+    int *p1cols = (int *)sp; sp += 8; \
     L2Par *par = (L2Par *)sp; sp += 32;
 
 // parameters the role functions need, in LDS: arguments of a real function call travel in vector registers, i.e. the callee
@@ -182,7 +183,7 @@ struct L2Par {
     unsigned long long *prof;
     long long num_iters, n16;
     double tol, r0, fbound;
-    int NB, KS, n, nlast, Rtotal, pad_;
+    int NB, KS, n, nlast, Rtotal, dbg;
 };
 __device__ __attribute__((always_inline)) inline int l2_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __attribute__((always_inline)) inline long long l2_uni(long long v) {
@@ -203,7 +204,7 @@ __device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
     constexpr int CSU = CS > 0 ? CS : 1;
     L2_LDS_VIEW
     (void)fixp; (void)gtile; (void)DU2; (void)sc2; (void)cshare; (void)slk; (void)TC; (void)of0; (void)ovis; (void)oacc; (void)oswp; (void)sid; (void)snew;
-    (void)sfin; (void)ost; (void)ctl; (void)cst; (void)sseed; (void)sfirst; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof;
+    (void)sfin; (void)ost; (void)ctl; (void)cst; (void)sseed; (void)sfirst; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols;
     const int lane = threadIdx.x & 63;
     const int m = l2_uni(m_in);
     const double *pApack2 = l2_uni(par->Apack2);
@@ -211,6 +212,7 @@ __device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
     unsigned long long *pprof = l2_uni(par->prof);
     const int NB = l2_uni(par->NB), KS = l2_uni(par->KS);
     const int64_t n16 = l2_uni(par->n16);
+    const int rowmask = (l2_uni(par->dbg) & 1) ? 7 : -1;       // timing experiment: alias the block rows (results invalid)
     const int64_t gmax = (int64_t)1 << 40;         // the role ends through RQ_STOP
     // =========================================================================== multiplying role
     // Wave m owns the blocks m, m + NMW, ... of the contraction (unit u = block m + NMW u) and computes EVERY product
@@ -262,7 +264,7 @@ __device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
         if (h1 % NMW == m && h1 < NB - CS) skip |= 1u << (h1 / NMW);
         if (h2 % NMW == m && h2 < NB - CS) skip |= 1u << (h2 / NMW);
         if (r1 >= 0 && r1 % NMW == m && r1 < NB - CS) fresh |= 1u << (r1 / NMW);
-        const int so1 = row * rowstride + m * 2048, so2 = row2 * rowstride + m * 2048;
+        const int so1 = (row & rowmask) * rowstride + m * 2048, so2 = (row2 & rowmask) * rowstride + m * 2048;
         bool stop = false;
         if (i >= 3) {
             // every block except the two holes must be final: the latest one was committed in interval i - 3
@@ -342,7 +344,7 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
     constexpr int CSU = CS > 0 ? CS : 1;
     constexpr bool PRE = KIND == L2_KIND_LIN;      // a restart's phase 2 starts with a frozen sweep that evaluates f0
     L2_LDS_VIEW
-    (void)slk; (void)snew; (void)ctl; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof;
+    (void)slk; (void)snew; (void)ctl; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols;
     const int lane = threadIdx.x & 63, r = lane >> 2, gq = lane & 3;
     LG const double *Apk = l2_g(l2_uni(par->Apack));
     LG const double *Apk2 = l2_g(l2_uni(par->Apack2));
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
         par->Apack = P.Apack; par->Apack2 = P.Apack2; par->Dpack = a0.Dpack; par->Spack = a0.Spack;
         par->Xg = a0.scratch + (int64_t)blockIdx.x * n16 * 16; par->next = a0.b.next; par->prof = (unsigned long long *)lf0->prof;
         par->num_iters = a.num_iters; par->n16 = n16; par->tol = a.tol; par->r0 = P.r0; par->fbound = a.fbound;
-        par->NB = NB; par->KS = KS; par->n = (int)P.n; par->nlast = nlast; par->Rtotal = (int)lf0->Rtotal; par->pad_ = 0;
+        par->NB = NB; par->KS = KS; par->n = (int)P.n; par->nlast = nlast; par->Rtotal = (int)lf0->Rtotal; par->dbg = a0.dbg;
     }
     __syncthreads();
 
@@ -876,15 +878,7 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                     if (sid[c] < 0) for (int64_t j = tid; j < n16; j += NT) Xg[j * 16 + c] = 0.0;
                     continue;
                 }
-                if (lf_generate) {
-                    const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
-                    for (int64_t j = 2 * (int64_t)tid; j < n16; j += 2 * NT) {
-                        double xo = 0.0;
-                        const double xe = (j < P.n) ? l2_keyed_normal_pair(sd, gidx, (uint64_t)j, &xo) : 0.0;
-                        Xg[j * 16 + c] = xe;
-                        Xg[(j + 1) * 16 + c] = (j + 1 < P.n) ? xo : 0.0;
-                    }
-                } else {
+                if (!lf_generate) {
                     LG const double *src = l2_g(a0.b.X) + ((int64_t)(sid[c] >> 4) * n16) * 16 + (sid[c] & 15);
                     for (int64_t j0 = tid; j0 < n16; j0 += 4 * NT) {
                         double t4[4];
@@ -895,30 +889,69 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                     }
                 }
             }
+            if (lf_generate) {
+                // keyed normals of the new columns, dealt to the waves in chunks of 64 element PAIRS (see phase 1 below: the waves
+                // do not run at the same speed)
+                if (tid == 0) {
+                    int cnt = 0;
+                    for (int k = 0; k < 16; k++) if (snew[k]) p1cols[cnt++] = k;
+                    ctl[4] = cnt; ctl[5] = 0;
+                }
+                __syncthreads();
+                const int ncolg = ctl[4], nchg = (int)((n16 + 127) / 128);
+                for (;;) {
+                    int ch = 0;
+                    if (lane == 0) ch = atomicAdd(&ctl[5], 1);
+                    ch = __builtin_amdgcn_readfirstlane(ch);
+                    if (ch >= ncolg * nchg) break;
+                    const int c = p1cols[ch / nchg];
+                    const int64_t j = (int64_t)(ch % nchg) * 128 + 2 * lane;
+                    const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
+                    if (j < n16) {
+                        double xo = 0.0;
+                        const double xe = (j < P.n) ? l2_keyed_normal_pair(sd, gidx, (uint64_t)j, &xo) : 0.0;
+                        Xg[j * 16 + c] = xe;
+                        Xg[(j + 1) * 16 + c] = (j + 1 < P.n) ? xo : 0.0;
+                    }
+                }
+            }
             __syncthreads();
             if (lf->prof && tid == 0) atomicAdd((unsigned long long *)lf->prof + 4, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pt0));
             if (lf_phase1) {
+                // The visits of a sweep are dealt to the waves in CHUNKS of 64 coordinates of one column from a counter in LDS:
+                // the waves do not work at the same speed -- a double-precision instruction on SIMDs 1-3 waits for a slot between
+                // the matrix instructions of the neighbouring workgroup's product streams, the wave on SIMD 0 (two chains, little
+                // matrix work) runs several times faster -- and an even split made the build as slow as its slowest wave.  A visit's
+                // result depends on (restart, coordinate, sweep) only: who computes it is immaterial.
+                const int nch = (int)((P.n + 63) / 64);
                 for (int64_t t = 0; t < a.num_iters; t++) {
-                    if (tid == 0) { int cnt = 0; for (int k = 0; k < 16; k++) cnt += (snew[k] && !p1fin[k]) ? 1 : 0; ctl[4] = cnt; }
+                    if (tid == 0) {
+                        int cnt = 0;
+                        for (int k = 0; k < 16; k++) if (snew[k] && !p1fin[k]) p1cols[cnt++] = k;
+                        ctl[4] = cnt; ctl[5] = 0;
+                    }
                     if (tid < 16) { p1key[tid] = l2_key(-QM_INF); p1upd[tid] = 0; }
                     __syncthreads();
-                    if (ctl[4] == 0) break;
-                    for (int c = 0; c < 16; c++) {
-                        if (!snew[c] || p1fin[c]) continue;       // workgroup-uniform
+                    const int ncol1 = ctl[4];
+                    if (ncol1 == 0) break;
+                    for (;;) {
+                        int ch = 0;
+                        if (lane == 0) ch = atomicAdd(&ctl[5], 1);
+                        ch = __builtin_amdgcn_readfirstlane(ch);
+                        if (ch >= ncol1 * nch) break;
+                        const int c = p1cols[ch / nch];
+                        const int64_t i = (int64_t)(ch % nch) * 64 + lane;
                         const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
-                        double vmax = -QM_INF;
-                        int upd = 0, st = 0;
-                        for (int64_t i = tid; i < P.n; i += NT) {
-                            int fl;
-                            double va;
+                        double va = -QM_INF;
+                        int fl = 0;
+                        if (i < P.n) {
                             const double xi = l2_p1_visit(cp, cq, cr, rel, i, Xg[i * 16 + c], a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
-                            if (fl >> 8) st = -(fl >> 8);
-                            if (fl & 1) { Xg[i * 16 + c] = xi; upd = 1; }
-                            vmax = va > vmax ? va : vmax;
+                            if (fl & 1) Xg[i * 16 + c] = xi;
                         }
-                        vmax = l2_wave_max(vmax);
-                        if (lane == 0) atomicMax(&p1key[c], l2_key(vmax));
-                        if (upd) p1upd[c] = 1;
+                        const double vmax = l2_wave_max(va);
+                        const bool anyupd = __builtin_amdgcn_ballot_w64((fl & 1) != 0) != 0ull;
+                        const int st = (fl >> 8) ? -(fl >> 8) : 0;
+                        if (lane == 0) { atomicMax(&p1key[c], l2_key(vmax)); if (anyupd) p1upd[c] = 1; }
                         if (st) p1st[c] = st;
                     }
                     __syncthreads();
@@ -1016,36 +1049,41 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
             const int e0 = P.cptr[P.krep[0]];
             const double cp = P.cp[e0], cq = P.cq[e0], cr = P.cr[e0];
             const int rel = P.crel[e0];
-            const int col = tid & 15, slot = tid >> 4;
-            double v = -QM_INF;
-            if (sfin[col]) {
-                // (eight loads in flight per thread: the tile lives in L2, a dependent load-store pair per row costs a round trip each)
-                LG double *dst = l2_g(a0.b.X) + ((int64_t)(sid[col] >> 4) * n16) * 16 + (sid[col] & 15);
-                for (int64_t i0 = slot; i0 < n16; i0 += (NT / 16) * 8) {
-                    double xv8[8];
+            // the finished columns (two per episode on average) are spread over ALL threads: item w = (column, row) with eight loads
+            // in flight per thread (the tile lives in L2: a dependent load-store pair per row costs a round trip each, and with
+            // one thread column per slot 14 of 16 threads had nothing to do); the max violation per column through LDS keys
+            if (tid == 0) { int cnt = 0; for (int k = 0; k < 16; k++) if (sfin[k]) p1cols[cnt++] = k; ctl[4] = cnt; }
+            if (tid < 16) p1key[tid] = l2_key(-QM_INF);
+            __syncthreads();
+            const int nfin = ctl[4];
+            const int64_t items = (int64_t)nfin * n16;
+            for (int64_t w0 = tid; w0 < items; w0 += (int64_t)NT * 8) {
+                double xv8[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int64_t i = i0 + (NT / 16) * u;
-                        xv8[u] = (i < P.n) ? Xg[i * 16 + col] : 0.0;
-                    }
+                for (int u = 0; u < 8; u++) {
+                    const int64_t w = w0 + (int64_t)NT * u;
+                    const int col = p1cols[w < items ? w / n16 : 0];
+                    const int64_t i = w % n16;
+                    xv8[u] = (w < items && i < P.n) ? Xg[i * 16 + col] : 0.0;
+                }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int64_t i = i0 + (NT / 16) * u;
-                        if (i < n16) dst[i * 16] = xv8[u];
+                for (int u = 0; u < 8; u++) {
+                    const int64_t w = w0 + (int64_t)NT * u;
+                    if (w < items) {
+                        const int col = p1cols[w / n16];
+                        const int64_t i = w % n16;
+                        l2_g(a0.b.X)[((int64_t)(sid[col] >> 4) * n16 + i) * 16 + (sid[col] & 15)] = xv8[u];
                         if (i < P.n) {
                             const double f = (cp * xv8[u] + cq) * xv8[u] + cr;
-                            const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
-                            v = w > v ? w : v;
+                            const double vv = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+                            atomicMax(&p1key[col], l2_key(vv));
                         }
                     }
                 }
             }
-            double *red = part2;                 // NT doubles of the partial-tile area, free between episodes
-            red[tid] = v;
             __syncthreads();
             if (tid < 16 && sfin[tid]) {
-                double mx = -QM_INF;
-                for (int s2 = 0; s2 < NT / 16; s2++) { const double w = red[s2 * 16 + tid]; mx = w > mx ? w : mx; }
+                const double mx = l2_unkey(p1key[tid]);
                 const int id = sid[tid];
                 l2_g(a0.b.visits)[id] = ovis[tid]; l2_g(a0.b.accepted)[id] = oacc[tid]; l2_g(a0.b.sweeps)[id] = oswp[tid];
                 l2_g(a0.b.status)[id] = ost[tid];
@@ -1059,8 +1097,11 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
             __syncthreads();
         }
     }
-    if (tid0 == 0 && lf0->prof)
-        atomicAdd((unsigned long long *)lf0->prof + 1, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - life_t0));
+    if (tid0 == 0 && lf0->prof) {
+        const unsigned long long dtl = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - life_t0);
+        atomicAdd((unsigned long long *)lf0->prof + 1, dtl);
+        atomicMax((unsigned long long *)lf0->prof + 16, dtl);
+    }
 }
 
 // strictly upper triangle of the diagonal blocks (zeros elsewhere) and the per-block scalars the chain stages
@@ -1090,7 +1131,7 @@ int l2_launch_kind(const CdLife2Args &a, int kind, int wgs, size_t lds, hipStrea
 }  // namespace
 
 size_t cd_life2_lds_bytes(int nmw) {
-    const size_t d = (size_t)2 * nmw * 256 + 256 + 256 + 4 * 256 + 512 + 96 + 1024 + 16 + 64 + 8 + 8 + 8 + 16 * 4 + 8 * 5 + 640 + 16 * 3 + 8 * 5 + 8 + 32;
+    const size_t d = (size_t)2 * nmw * 256 + 256 + 256 + 4 * 256 + 512 + 96 + 1024 + 16 + 64 + 8 + 8 + 8 + 16 * 4 + 8 * 5 + 640 + 16 * 3 + 8 * 5 + 8 + 8 + 32;
     return d * sizeof(double) + 256;
 }
 

@@ -259,8 +259,8 @@ def test_bench_under_the_drivers_launcher_on_one_gpu(tmp_path, launch):
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    args = ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--n', '128', '--m-rows', '32', '--restarts', '256',
-            '--no-secondary', '--no-cpu-baseline']
+    # (no --n / --m-rows here: torch.distributed.run's own parser rejects `--n` as an ambiguous abbreviation of its options)
+    args = ['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--restarts', '256', '--no-secondary', '--no-cpu-baseline']
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'QCQP_AMD_RDZV')}
     if launch == 'torch_distributed_run':
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
@@ -275,3 +275,63 @@ def test_bench_under_the_drivers_launcher_on_one_gpu(tmp_path, launch):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['steps'] == 2 and d['config']['scheme'] == 'stream' and d['value'] > 0
     assert d['roofline']['kernel'].startswith('cd_life_kernel')
+
+
+def _fuzz_shape(rs):
+    fam = str(rs.choice(['bls', 'bls', 'box', 'maxcutw']))
+    n = int(rs.choice([48, 50, 64, 77, 96, 100, 128, 130, 176, 200, 256, 300, 320]))
+    R = int(rs.choice([1, 2, 15, 16, 17, 100, 257, 600]))
+    K = int(rs.choice([1, 2, 3, 5]))
+    iters = int(rs.choice([0, 1, 2, 5, 40, 1000])) if fam != 'box' else int(rs.choice([0, 1, 3, 25]))
+    return fam, n, R, K, iters, bool(rs.rand() < 0.7), bool(rs.rand() < 0.6)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_life_kernel_fuzz_shapes(eng_mod, orc, seed):
+    """Ten random shapes per seed (40 in all; tools/fuzz_stream.py promoted to a test, with the ORACLE in it): family (Boolean / box /
+    weighted MAXCUT), n = 48 .. 320 incl. sizes that are not multiples of 16, 1 .. 600 restarts, 1 .. 5 populations, sweep limits
+    0 .. 1000, with and without phase 1, generated and uploaded starts (a share of the uploaded ones fails the gate).  Every
+    population against the serial path (points 1e-12, all counters, objective, winner), two restarts per shape against the oracle."""
+    rs = np.random.RandomState(1000 + seed)
+    for case in range(10):
+        fam, n, R, K, iters, phase1, generate = _fuzz_shape(rs)
+        funcs = family(fam, n)
+        es, e = make(eng_mod, funcs), make(eng_mod, funcs)
+        seed0, sstride, first0, fstride = int(rs.randint(1 << 20)), int(rs.randint(0, 4)), int(rs.randint(100)), int(rs.choice([0, R, 100000]))
+        tag = (seed, case, fam, n, R, K, iters, phase1, generate)
+        X0 = None
+        if generate:
+            o = es.cd_stream_run(K, R, generate=True, phase1=phase1, num_iters=iters, seed=seed0, seed_stride=sstride, first_index=first0, first_stride=fstride)
+        else:
+            X0 = np.sign(rs.randn(n, K * R)) * (1.0 - 2e-3 * rs.rand(n, K * R))     # feasible for the box, near-feasible for x^2 == 1
+            far = rs.rand(K * R) < 0.3
+            X0[:, far] *= 1.0 + rs.rand(int(far.sum()))
+            es.upload(X0)
+            o = es.cd_stream_run(K, R, generate=False, phase1=phase1, num_iters=iters, seed=seed0, seed_stride=sstride, first_index=first0, first_stride=fstride)
+        assert es.last_cd_kernel().startswith('cd_life_kernel<3,'), tag
+        X = es.download()
+        prob = orc.Problem(funcs)
+        for p in range(K):
+            sd, fi = seed0 + p * sstride, first0 + p * fstride
+            sl = slice(p * R, (p + 1) * R)
+            if generate:
+                e.randn(R, seed=sd, first_index=fi)
+            else:
+                e.upload(X0[:, sl])
+            Xs = e.download()
+            outr = e.cd_run(phase1=phase1, num_iters=iters, seed=sd, first_index=fi)
+            Xr = e.download()
+            assert rel(X[:, sl], Xr) < 1e-12, (tag, p)
+            for key in COUNTERS:
+                assert np.array_equal(o[key][sl], outr[key]), (tag, p, key)
+            assert rel(o['f0'][sl], outr['f0']) < 1e-10 and np.max(np.abs(o['maxviol'][sl] - outr['maxviol'])) < 1e-12, (tag, p)
+            assert o['best_index'][p] == e.select_best(1e-4)[0], (tag, p)
+            if p == 0:
+                for r in sorted({0, R - 1}):
+                    rng = orc.Rng(orc.RNG_KEYED, sd)
+                    rng.set_restart(fi + r)
+                    x, s1, s2 = prob.improve_cd(Xs[:, r], num_iters=iters, phase1=phase1, rng=rng)
+                    assert rel(X[:, r], x) < 1e-9, (tag, r)
+                    assert o['visits2'][r] == s2[1] and o['accepted2'][r] == s2[2], (tag, r)
+        es.close()
+        e.close()

@@ -56,12 +56,15 @@ def main():
         import ctypes as C
         es.L.qcqpmi_debug_profile(es.h, 1 | (dbg << 4), None)
         es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
-        pr = np.zeros(16, dtype=np.int64)
+        pr = np.zeros(24, dtype=np.int64)
         es.L.qcqpmi_debug_life_profile(es.h, pr.ctypes.data_as(C.POINTER(C.c_int64)))
         es.L.qcqpmi_debug_profile(es.h, dbg << 4, None)
         print('profile (%.3f ms): column build %.1f %% of the workgroups\' time (normals %.1f %%), roles %.1f %%, rest %.1f %%; %d episodes, %d columns; workgroups with evenly spread waves: %d' % (
             es.kernel_ms(2), 100.0 * pr[0] / max(pr[1], 1), 100.0 * pr[4] / max(pr[1], 1), 100.0 * pr[5] / max(pr[1], 1),
             100.0 * (pr[1] - pr[0] - pr[5]) / max(pr[1], 1), pr[2], pr[3], pr[6]), flush=True)
+        nwg = max(int(pr[6]), 1)
+        print('  longest workgroup %.3e ticks = %.3f GHz tick rate; the average workgroup was alive %.1f %% of the launch' % (
+            pr[16], pr[16] / (es.kernel_ms(2) * 1e-3) / 1e9, 100.0 * pr[1] / nwg / max(pr[16], 1)), flush=True)
         ni = max(int(pr[11]), 1)
         print('  per block interval (s_memtime ticks): roles %.1f, chain waits for partials %.1f, multiplying wave 0 waits: commit %.1f, slot %.1f; intervals %d, with a near-tie replay %d' % (
             pr[5] / ni, pr[8] / ni, pr[9] / ni, pr[10] / ni, pr[11], pr[12]), flush=True)

@@ -41,7 +41,7 @@ def main():
     import ctypes as C
     es.L.qcqpmi_debug_profile(es.h, 1 | (((128 | (cs << 8)) << 4) if cs >= 0 else 0), None)
     o2 = es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
-    pr = np.zeros(16, dtype=np.int64)
+    pr = np.zeros(24, dtype=np.int64)
     es.L.qcqpmi_debug_life_profile(es.h, pr.ctypes.data_as(C.POINTER(C.c_int64)))
     es.L.qcqpmi_debug_profile(es.h, ((128 | (cs << 8)) << 4) if cs >= 0 else 0, None)
     print('profile: column build %.1f %% of the workgroups\' time (normals %.1f %%), roles %.1f %%, write-out / queue / idle at the end %.1f %%; %d episodes, %d columns' % (

@@ -43,7 +43,7 @@ if ks:
         lines.append('| %s | %s | %.3f | %.1f | %.1f | %.1f | %.1f |' % (
             short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3,
             float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, float(r['Percentage'])))
-        if 'cd_phase2' in r['Name']:
+        if 'cd_phase2' in r['Name'] or 'cd_life_kernel' in r['Name']:
             out['cd_phase2_avg_ms'] = float(r['AverageNs']) / 1e6
             out['kernel'] = short(r['Name']).split('<')[0]
             out['cd_phase2_calls'] = int(r['Calls'])
@@ -75,7 +75,7 @@ for k in sorted(set(fetch) | set(write)):
     hbm = (2.0 * fe + wr) * 1024.0
     lines.append('| %s | %d | %.1f | %.1f | %.3e | %s |' % (k, fetch[k][1], fe, wr, hbm,
                                                           ('%.3f' % (h / (h + m))) if h + m else 'n/a'))
-    if 'cd_phase2' in k:
+    if 'cd_phase2' in k or 'cd_life_kernel' in k:
         out['cd_phase2_hbm_bytes_per_launch'] = hbm
         out['cd_phase2_fetch_kb_raw'] = fe
         out['cd_phase2_write_kb'] = wr
@@ -94,14 +94,14 @@ if mb:
         g_ = ga[k][0] / max(ga[k][1], 1)
         frac = b_ / (1024.0 * g_ / 8.0) if g_ else 0.0
         lines.append('| %s | %d | %.3e | %.3e | %.3f |' % (k, mb[k][1], b_, g_, frac))
-        if 'cd_phase2' in k:
+        if 'cd_phase2' in k or 'cd_life_kernel' in k:
             out['cd_phase2_mfma_busy_frac'] = frac
 bj = os.path.join(src, 'bench_under_profiler.json')
 if os.path.exists(bj) and os.path.getsize(bj):
     out['bench_under_profiler'] = json.load(open(bj))
 hdr = ['# rocprofv3 summary %s' % tag, '',
        'Command: `python bench.py --scheme stream --steps 20 --warmup 20 --no-cpu-baseline --no-secondary` (tools/profile_round.sh):',
-       'two launches of `cd_phase2_qs_kernel<4, true>` (the lifecycle mode of the slot-queue kernel), each = 20 steps of 4096 restarts --',
+       'two launches of the lifecycle kernel (round 5: `cd_life_kernel<3, 4, 0>`; round 4: `cd_phase2_qs_kernel<4, true>`), each = 20 steps of 4096 restarts --',
        'suggest, phase 1, gate, phase 2, objective of 81920 restarts inside the launch.',
        'Pass 1 `--kernel-trace --stats`; passes 2-4 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc TCC_HIT_sum TCC_MISS_sum`',
        '(separate runs, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled (gfx950 reports half the bytes of',
