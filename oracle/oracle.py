@@ -93,6 +93,9 @@ def lib():
         L.orc_cd_trace.restype = None
         L.orc_cd_trace.argtypes = [_dp, C.c_int64]
         L.orc_cd_trace_len.restype = C.c_int64
+        L.orc_cd_visit_limit.restype = None
+        L.orc_cd_visit_limit.argtypes = [C.c_int64]
+        L.orc_cd_visits.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.orc_cd_trace_len.argtypes = []
         L.orc_cd_phase2_incremental.argtypes = [C.c_void_p, _dp, _dp, C.c_int64, C.c_double, C.c_void_p, _ip]
         L.orc_onecons.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, C.c_double, _dp]
@@ -299,6 +302,38 @@ class Problem:
                 raise RuntimeError('oracle orc_cd_phase2 failed rc=%d' % rc)
             tr2 = buf[:k2].copy()
         return x, s1, s2, tr1, tr2, slack2
+
+    def cd_visits(self, phase, x, sweep, i0, count, slack2=0.0, viol_tol=1e-2, tol=1e-4, rng=None):
+        """`count` coordinate visits i0, i0 + 1, ... of sweep `sweep` of phase 1 / phase 2 from the state x (phase 2: with the
+        slack `slack2` fixed at its start, qcqp.py:157): the reference's answer for ONE block from an arbitrary state."""
+        rng = rng or Rng(RNG_MT, 0, from_numpy_global=True)
+        x = _vec(x).copy()
+        rc = lib().orc_cd_visits(self.h, _d(x), int(phase), int(sweep), int(i0), int(count), float(slack2), viol_tol, tol, rng.h)
+        if rc:
+            raise RuntimeError('oracle orc_cd_visits failed rc=%d' % rc)
+        return x
+
+    def cd_phase_traced(self, phase, x, visits, viol_tol=1e-2, tol=1e-4, rng=None):
+        """The first `visits` coordinate visits of coord_descent_phase1 (qcqp.py:101-149) or coord_descent_phase2 (qcqp.py:152-178)
+        from x: returns (x after them, the value of x[i] after each visit, the slack phase 2 fixes at its start -- None for
+        phase 1).  For problems whose sweep costs minutes on the host (257 dense 1024 x 1024 functions: 0.13 s per visit)."""
+        L = lib()
+        rng = rng or Rng(RNG_MT, 0, from_numpy_global=True)
+        x = _vec(x).copy()
+        buf = np.zeros(max(1, int(visits)))
+        st = np.zeros(3, dtype=np.int64)
+        slack = None if phase == 1 else self.max_violation(x)
+        L.orc_cd_trace(_d(buf), buf.size)
+        L.orc_cd_visit_limit(int(visits))
+        try:
+            rc = (L.orc_cd_phase1 if phase == 1 else L.orc_cd_phase2)(self.h, _d(x), 1000, viol_tol, tol, rng.h, _i(st))
+            k = int(L.orc_cd_trace_len())
+        finally:
+            L.orc_cd_visit_limit(-1)
+            L.orc_cd_trace(None, 0)
+        if rc:
+            raise RuntimeError('oracle cd phase %d failed rc=%d' % (phase, rc))
+        return x, buf[:k].copy(), slack
 
     # ---- utilities.py:149-196
     def eig(self):

@@ -516,6 +516,11 @@ static int64_t g_trace_cap = 0, g_trace_len = 0;
 void orc_cd_trace(double *buf, int64_t cap) { g_trace = buf; g_trace_cap = buf ? cap : 0; g_trace_len = 0; }
 int64_t orc_cd_trace_len(void) { return g_trace_len; }
 #define ORC_TRACE(v) do { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len] = (v); if (g_trace) g_trace_len++; } while (0)
+/* test instrumentation like the trace: stop orc_cd_phase1 / orc_cd_phase2 after this many coordinate visits (< 0: off) -- a
+ * visit of a problem with 257 dense 1024 x 1024 functions costs 0.13 s (get_onevar_func forms P_k z for every function,
+ * utilities.py:99-105), a sweep two minutes: the teacher-forced parity test at that size follows the first visits only */
+static int64_t g_visit_limit = -1;
+void orc_cd_visit_limit(int64_t visits) { g_visit_limit = visits; }
 
 int orc_cd_phase1(const orc_prob *p, double *x, int64_t num_iters, double viol_tol,
                   double tol, orc_rng *g, int64_t *stats) {
@@ -528,7 +533,9 @@ int orc_cd_phase1(const orc_prob *p, double *x, int64_t num_iters, double viol_t
     for (int64_t t = 0; t < num_iters && rc == 0; t++) {
         if (viol_last < viol_tol) break;
         sweeps++;
+        int cut = 0;
         for (int64_t i = 0; i < n; i++) {
+            if (g_visit_limit >= 0 && visits >= g_visit_limit) { cut = 1; break; }
             visits++;
             int64_t mf = gather_onevars(p, x, i, fs3, relops);
             if (mf == 0) { rc = -3; break; } /* python: max() of empty list -> ValueError */
@@ -559,7 +566,7 @@ int orc_cd_phase1(const orc_prob *p, double *x, int64_t num_iters, double viol_t
                 if (update_counter == n) break; /* failed = True; outer loop goes on (qcqp.py:138-141) */
             }
         }
-        if (rc) break;
+        if (rc || cut) break;
         viol_last = orc_max_violation(p, x);
     }
     if (stats) { stats[0] = sweeps; stats[1] = visits; stats[2] = accepted; }
@@ -579,6 +586,7 @@ int orc_cd_phase2(const orc_prob *p, double *x, int64_t num_iters, double viol_t
     for (int64_t t = 0; t < num_iters && !converged && rc == 0; t++) {
         sweeps++;
         for (int64_t i = 0; i < n; i++) {
+            if (g_visit_limit >= 0 && visits >= g_visit_limit) { converged = 1; break; }
             visits++;
             double obj[3];
             orc_onevar_coeffs(p, 0, x, i, obj);
@@ -597,6 +605,54 @@ int orc_cd_phase2(const orc_prob *p, double *x, int64_t num_iters, double viol_t
         }
     }
     if (stats) { stats[0] = sweeps; stats[1] = visits; stats[2] = accepted; }
+    free(fs3); free(relops);
+    return rc;
+}
+
+/* Test instrumentation: `count` coordinate visits i0, i0 + 1, ... of sweep t of phase 1 (qcqp.py:113-136) or phase 2
+ * (qcqp.py:162-170; `viol2` = the slack phase 2 fixed at its start, qcqp.py:157) from the state x, with the bodies of the loops
+ * above and the same keyed draws -- the oracle's own answer for ONE block of the engine's blocked kernels from an arbitrary state
+ * (the block-level yardstick of the dense path's parity test: how far does the reference itself move when that state moves by
+ * one ulp?).  Phase 1 does not update its stop bookkeeping here (no sweep ends inside a block). */
+int orc_cd_visits(const orc_prob *p, double *x, int phase, int64_t t, int64_t i0, int64_t count, double viol2,
+                  double viol_tol, double tol, orc_rng *g) {
+    int64_t n = p->n;
+    double *fs3 = (double *)malloc(sizeof(double) * 3 * (size_t)(p->m + 1));
+    int *relops = (int *)malloc(sizeof(int) * (size_t)(p->m + 1));
+    int rc = 0;
+    for (int64_t i = i0; i < i0 + count && i < n && rc == 0; i++) {
+        int64_t mf = gather_onevars(p, x, i, fs3, relops);
+        if (phase == 1) {
+            if (mf == 0) { rc = -3; break; }
+            double viol = -INFINITY;
+            for (int64_t k = 0; k < mf; k++) {
+                int st = 0;
+                double v = viol_of(onevar_eval(fs3[3 * k], fs3[3 * k + 1], fs3[3 * k + 2], x[i], &st), relops[k]);
+                if (v > viol) viol = v;
+            }
+            double new_xi = x[i], new_viol = viol;
+            double ss = -tol, es = viol - viol_tol;
+            uint32_t it = 0;
+            while (es - ss > tol) {
+                double s = (ss + es) / 2.0;
+                double xi;
+                rng_ctx(g, (uint32_t)i, (uint32_t)t, it++);
+                int got = orc_onevar_qcqp(0.0, 0.0, 0.0, fs3, relops, mf, s, g, &xi, NULL, 0, NULL);
+                if (got < 0) { rc = got; break; }
+                if (!got) ss = s;
+                else { new_xi = xi; new_viol = s; es = s; }
+            }
+            if (rc) break;
+            if (new_viol < viol) x[i] = new_xi;
+        } else {
+            double obj[3], new_xi;
+            orc_onevar_coeffs(p, 0, x, i, obj);
+            rng_ctx(g, (uint32_t)i, (uint32_t)t | 0x80000000u, 0);
+            int got = orc_onevar_qcqp(obj[0], obj[1], obj[2], fs3, relops, mf, viol2, g, &new_xi, NULL, 0, NULL);
+            if (got < 0) { rc = got; break; }
+            if (got && fabs(new_xi - x[i]) > tol) x[i] = new_xi;
+        }
+    }
     free(fs3); free(relops);
     return rc;
 }
