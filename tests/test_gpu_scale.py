@@ -348,26 +348,33 @@ def test_dense_default_path_follows_the_oracle_step_by_step(eng_mod, orc, family
         family, steps, len(db), np.median(db), np.percentile(db, 99), db.max(), worst[1], int((db > 1e-6).sum()), 100 * np.mean(db > 1e-6), int((db > 1e-9).sum())))
     assert np.median(db) < 1e-11
     assert np.mean(db > 1e-6) < (0.005 if family.startswith('dense') else 0.05), np.mean(db > 1e-6)
-    # THE YARDSTICK for every block beyond 1e-6: the oracle against ITSELF on that block from a start state one ulp away
-    # (nextafter of every coordinate; same draws, same slack).  A block where the engine leaves the oracle because the
-    # reference's own map amplifies rounding is a block where the oracle leaves itself just as far; a bug in the in-block
-    # Gauss-Seidel correction would show as an engine deviation far beyond the oracle's own.  Asserted: engine <= 10 x oracle
-    # (+ 1e-6) on every such block.
-    ratios = []
+    # THE YARDSTICK for every block beyond 1e-6: the oracle against ITSELF on that block from start states 1, 32 and 1024 ulps away
+    # (every coordinate scaled by 1 +- k 2^-52; same draws, same slack).  The engine's coefficients differ from the oracle's by the
+    # rounding of another summation order and of TRACKED function values -- up to ~1e-13 relative, i.e. hundreds of ulps --, so a
+    # block where the reference's own map amplifies rounding (beamforming: 1 ulp in, 1e-5 out: a factor 1e11) is a block where
+    # the oracle leaves itself by as much as the engine leaves it; a bug in the in-block Gauss-Seidel correction would show as an
+    # engine deviation far beyond anything the oracle does to itself.  Asserted on every such block: engine <= 10 x the largest
+    # of the oracle's own deviations (+ 1e-6); the three levels are printed.
+    ratios, levels = [], {1: [], 32: [], 1024: []}
     for d, phase, t, b, r, start in far:
         i0, cnt = 16 * b, min(16, n - 16 * b)
-        outs = []
-        for pert in (0, 1, -1):
-            st = start if pert == 0 else np.nextafter(start, np.inf * pert)
+
+        def block_from(st):
             rng = orc.Rng(orc.RNG_KEYED, seed)
             rng.set_restart(first + r)
-            outs.append(prob.cd_visits(phase, st, t, i0, cnt, slack2=slack2[r], rng=rng)[i0:i0 + cnt])
-        own = max(np.max(np.abs(outs[1] - outs[0])), np.max(np.abs(outs[2] - outs[0]))) / (1 + np.max(np.abs(start)))
-        ratios.append((d, own))
+            return prob.cd_visits(phase, st, t, i0, cnt, slack2=slack2[r], rng=rng)[i0:i0 + cnt]
+        base = block_from(start)
+        own = 0.0
+        for k in (1, 32, 1024):
+            dk = max(np.max(np.abs(block_from(start * (1.0 + sg * k * 2.0 ** -52)) - base)) for sg in (1.0, -1.0)) / (1 + np.max(np.abs(start)))
+            levels[k].append(dk)
+            own = max(own, dk)
+        ratios.append(d / max(own, 1e-300))
         assert d <= 10.0 * own + 1e-6, (family, phase, t, b, r, d, own)
     if ratios:
-        print('%s: %d blocks beyond 1e-6; engine deviation / oracle-vs-oracle-under-one-ulp deviation on them: median %.2f, max %.2f' % (
-            family, len(ratios), np.median([a / max(o_, 1e-300) for a, o_ in ratios]), max(a / max(o_, 1e-300) for a, o_ in ratios)))
+        print('%s: %d blocks beyond 1e-6; the oracle against itself on them under 1 / 32 / 1024 ulps: median %.1e / %.1e / %.1e; '
+              'engine deviation / largest oracle self-deviation: median %.2f, max %.2f'
+              % (family, len(ratios), np.median(levels[1]), np.median(levels[32]), np.median(levels[1024]), np.median(ratios), max(ratios)))
 
 
 def test_dense_default_path_follows_the_oracle_at_1024_by_256(eng_mod, orc):
