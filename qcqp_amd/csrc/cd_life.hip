@@ -645,7 +645,16 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
                     const double t0 = G.fcur - xi * (t2g * xi + t1);
                     DrawKey dk{dseed, dfirst + (uint64_t)sid[r], (uint32_t)i, (uint32_t)(G.sweeps - 1) | 0x80000000u, 0u};
                     double xnew = xi;
-                    int got = G.conv ? 0 : onevar_minimise<MAXC>(t2g, t1, t0, C, dk, &xnew);
+                    int got;
+                    if (KIND == L2_KIND_LIN && Uslow == 0 && fabs(gc) > tl) {
+                        // linear kind, the slope is far from a tie: the end point against the slope IS what the reference's end-point
+                        // comparison returns (utilities.py:275-288 picks among the table's own values: nothing to round) -- only the
+                        // coordinates that are near a tie pay for the replay.  (Unweighted MAXCUT has a tie in almost every block.)
+                        xnew = (gc > 0.0) ? linL : linH;
+                        got = G.conv ? 0 : 1;
+                    } else {
+                        got = G.conv ? 0 : onevar_minimise<MAXC>(t2g, t1, t0, C, dk, &xnew);
+                    }
                     bool moved;
                     double delta;
                     const bool wasconv = G.conv;

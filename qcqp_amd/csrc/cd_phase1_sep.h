@@ -129,19 +129,35 @@ __device__ inline void p1_band_visit(double p, double q, double r, int64_t i, do
     // the matrix instructions of the neighbouring workgroup every one of them waits for a slot of the pipe.
     const bool plain = r < -1e-3;
     const double guard = 1e-9 * (1.0 - r);
-    while (es - ss > tol) {
-        const double s = (ss + es) / 2.0;
-        const uint32_t itb = it++;
-        bool nonempty;
-        if (plain && fabs(s) > guard) nonempty = s > 0.0;
-        else {
+    if (plain) {
+        // branch-free body (selects): the lanes of a wave run the loop in lock step for as long as the slowest one needs it
+        while (es - ss > tol) {
+            const double s = (ss + es) / 2.0;
+            const uint32_t itb = it++;
+            bool nonempty = s > 0.0;
+            if (__builtin_expect(!(fabs(s) > guard), 0)) {       // within rounding of the threshold: the discriminants as the reference forms them
+                const double D1 = 0.0 - 4.0 * p * (r - s);
+                const double D2 = 0.0 - 4.0 * (-p) * (-r - s);
+                nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
+            }
+            ss = nonempty ? ss : s;
+            es = nonempty ? s : es;
+            sp = nonempty ? s : sp;
+            itp = nonempty ? itb : itp;
+            pending = pending || nonempty;
+        }
+        if (pending) new_viol = sp;
+    } else {
+        while (es - ss > tol) {
+            const double s = (ss + es) / 2.0;
+            const uint32_t itb = it++;
             const double D1 = 0.0 - 4.0 * p * (r - s);
             const double D2 = 0.0 - 4.0 * (-p) * (-r - s);
-            nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
+            const bool nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
+            if (!nonempty) { ss = s; continue; }
+            sp = s; itp = itb; pending = true;
+            new_viol = s; es = s;
         }
-        if (!nonempty) { ss = s; continue; }
-        sp = s; itp = itb; pending = true;
-        new_viol = s; es = s;
     }
     if (pending) {
         // feasible_intervals(p, q, r, ==, sp): A = {f - s <= 0} (convex: at most one interval), B = {-f - s <= 0} (concave: two rays, or the line)
@@ -150,13 +166,17 @@ __device__ inline void p1_band_visit(double p, double q, double r, int64_t i, do
         const double DA = q * q - 4.0 * p * rsA;
         const bool hasA = DA >= 0.0;
         const double rDA = sqrt(hasA ? DA : 0.0);
-        const double alo = (-q - rDA) / (2.0 * p), ahi = (-q + rDA) / (2.0 * p);
+        // q is +-0 for this class (the caller checks): -q -+ rD is -+rD exactly and IEEE division is odd in its numerator, so
+        // the reference's four quotients (-q - rD) / (2p), (-q + rD) / (2p), (-qB + rDB) / (2pB), (-qB - rDB) / (2pB) are
+        // -tA, tA, -tB, tB with TWO divisions, bit for bit
         const double pB = -p, qB = -q;
         const double DB = qB * qB - 4.0 * pB * rsB;
         const bool twoB = DB >= 0.0;
         const double rDB = sqrt(twoB ? DB : 0.0);
-        const double bhi0 = twoB ? (-qB + rDB) / (2.0 * pB) : QM_INF;       // B = (-inf, bhi0] u [blo1, +inf), or the whole line
-        const double blo1 = (-qB - rDB) / (2.0 * pB);
+        const double tA = rDA / (2.0 * p), tB = rDB / (2.0 * p);
+        const double alo = -tA, ahi = tA;
+        const double bhi0 = twoB ? -tB : QM_INF;       // B = (-inf, bhi0] u [blo1, +inf), or the whole line
+        const double blo1 = tB;
         // pairwise intersections in the reference's (i, j) order: (A, first piece of B), (A, second piece of B)
         const double l0 = alo > -QM_INF ? alo : -QM_INF, h0 = ahi < bhi0 ? ahi : bhi0;
         const bool ok0 = hasA && l0 <= h0;
