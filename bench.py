@@ -840,6 +840,33 @@ def main():
                                           'step_overlap': overlap_text['two'] if acc['contexts'] > 1 else 'none (steps strictly one after the other)'}}
             except Exception as ex:
                 res['schemes'] = {'reported': 'stream', 'two': {'error': repr(ex)[:400]}}
+        if world == 1 and scheme == 'stream':
+            # the same K steps (same seeds) through the OTHER lifecycle kernel: qcqpmi_cd_stream_run picks the faster one for the
+            # shape (the round-4 kernel for the Boolean family at n >= 960, cd_life_kernel everywhere else); both are in the line
+            try:
+                other = 2 if not (kernel_name or '').startswith('cd_life_kernel') else 1
+                eng.cd_life_version(other)
+                run_stream(max(args.warmup, 1), -1000)
+                eng.sync()
+                t0o = time.perf_counter()
+                oo, keys_o, X_o, ms_o = run_stream(args.steps, 0)
+                eng.sync()
+                dt_o = time.perf_counter() - t0o
+                sw_o = float(oo['visits2'].sum()) / n
+                ach_o = sw_o * 2.0 * n * n / 1e12 / (ms_o / 1e3)
+                bs_o = min(range(K), key=lambda k: dist.better_key(keys_o[k][1], keys_o[k][2], keys_o[k][0]) + (k,))
+                res.setdefault('schemes', {'reported': 'stream'})['other_lifecycle_kernel'] = {
+                    'kernel': eng.last_cd_kernel(), 'value': sw_o / dt_o, 'ms_per_step': 1e3 * dt_o / K, 'kernel_ms_per_launch': ms_o,
+                    'roofline_frac': ach_o / FP64_PEAK_TFLOPS,
+                    'same_best_point': bool(bs_o == best_step and int(keys_o[bs_o][0]) == int(best[0]) and
+                                            float(np.max(np.abs(np.asarray(X_o[bs_o]) - np.asarray(best[3])))) <= 1e-9),
+                    'note': 'qcqpmi_cd_stream_run dispatches by shape (qcqpmi_cd_life_version 0): cd_life_kernel (round 5: four-wave workgroups, '
+                            'two per CU; any n <= 2304, box / MAXCUT families) everywhere except the Boolean family at n >= 960, where the '
+                            'round-4 kernel is faster (profiles/r05_life_vs_round4.md)'}
+            except Exception as ex:
+                res.setdefault('schemes', {'reported': 'stream'})['other_lifecycle_kernel'] = {'error': repr(ex)[:300]}
+            finally:
+                eng.cd_life_version(0)
         if world == 1 and not args.no_secondary:
             res['secondary'] = secondary_records(local_rank, sdr_full=args.sdr_full)
         if world == 1 and not args.no_cpu_baseline:      # a reported baseline of rank 0 at N = 1 only

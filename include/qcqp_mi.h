@@ -307,9 +307,11 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *ctx, int64_t K, int64_t R, int generate, in
  * winners): allocation only, so that a timed or latency-sensitive run does not start with hipMalloc / hipHostMalloc.  A
  * resident population smaller than K R points is dropped (like any reallocation of the population). */
 int qcqpmi_cd_stream_reserve(qcqpmi_ctx *ctx, int64_t K, int64_t R);
-/* Which lifecycle kernel qcqpmi_cd_stream_run launches: 2 (default) cd_life_kernel wherever it applies, else the round-4 kernel;
- * 1: the round-4 kernel only (cd_phase2_qs_kernel<lifecycle>: Boolean family, n a multiple of 16, n <= 1024) -- kept as the
- * cross-check of the new one (tests/test_gpu_life.py). */
+/* Which lifecycle kernel qcqpmi_cd_stream_run launches: 0 (default) the faster one for the shape -- cd_life_kernel (csrc/cd_life.hip,
+ * round 5) everywhere except the Boolean family at n >= 960 with more than 8192 restarts in the run, where the round-4 kernel
+ * (cd_phase2_qs_kernel<lifecycle>, csrc/cd_queue.hip: Boolean family, n a multiple of 16, n <= 1024) is 12 % faster; 2: cd_life_kernel
+ * wherever it applies; 1: the round-4 kernel only.  Both produce the same restarts (tests/test_gpu_life.py, tests/test_gpu_stream.py run
+ * every case with both); qcqpmi_last_cd_kernel names the one that ran. */
 int qcqpmi_cd_life_version(qcqpmi_ctx *ctx, int version);
 /* Coordinate descent for constraints that couple coordinates IN THE REFERENCE'S SUMMATION ORDER (test / diagnostic mode, any
  * n): every one-variable coefficient (t2, t1, t0) of get_onevar_func (utilities.py:99-105) is formed by row-sequential sums

@@ -186,7 +186,7 @@ struct qcqpmi_ctx {
     double *l2_scratch = nullptr; size_t l2_scratch_cap = 0;
     double *l2_D = nullptr, *l2_S = nullptr;
     int *l2_abort = nullptr;
-    int life_version = 2;        // qcqpmi_cd_life_version: 2 = cd_life_kernel where it applies, 1 = cd_phase2_qs_kernel<lifecycle> only
+    int life_version = 0;        // qcqpmi_cd_life_version: 0 = the faster one for the shape, 2 = cd_life_kernel wherever it applies, 1 = cd_phase2_qs_kernel<lifecycle> only
     long long *d_life_prof = nullptr;
     int64_t *d_bestK_idx = nullptr; double *d_bestK_key = nullptr, *d_bestK_x = nullptr; int64_t bestK_cap = 0;
     bool cd_ref_order = false;   // qcqpmi_cd_reference_order: coupled constraints in the reference's summation order
@@ -1504,14 +1504,20 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     HIPCHK(c, hipSetDevice(c->device));
     // ---- which kernel (decided BEFORE the resident population is touched: a refused call leaves the context as it was)
     int nmw = 0, cs2 = 0, kind = 0;
-    const bool use2 = c->life_version >= 2 && !c->force_generic && !(c->dbg & 64) && c->sep &&
-                      cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, &nmw, &cs2, &kind);
+    bool use2 = c->life_version != 1 && !c->force_generic && !(c->dbg & 64) && c->sep &&
+                cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, &nmw, &cs2, &kind);
     int cs = 0;
+    const int queue_switch = c->cd_queue;
+    c->cd_queue = 2;                                   // (qcqpmi_cd_queue chooses the phase-2 kernel of qcqpmi_cd_run; it does not apply here)
+    const bool eligible = cd_queue_eligible(c, false) && (int)(c->n16 / 16) - 4 <= RQ_NSIMD * RQ_MAXU && c->n16 >= 48;
+    c->cd_queue = queue_switch;
+    // life_version 0 (default): the faster kernel for the shape.  Measured on one MI355X, 20 steps of 4096 restarts, Boolean family
+    // (tools/life_vs_r4.py, profiles/r05_life_vs_round4.md): cd_life_kernel takes 0.59 of the round-4 kernel's time at n = 64, 0.75 at 256,
+    // 0.82 at 512, 0.92 at 768, 1.01 at 896, 1.12 at 1024 -- at full width its multiplying waves (20 blocks of the contraction each,
+    // two streams per SIMD) are the bound while the round-4 kernel's eight waves split one tile's product six ways.  So: the round-4
+    // kernel from n = 960 on when the run has more restarts than both kernels have slots, cd_life_kernel everywhere else.
+    if (use2 && c->life_version == 0 && eligible && c->n16 >= 960 && K * R > 8192) use2 = false;
     if (!use2) {
-        const int queue_switch = c->cd_queue;
-        c->cd_queue = 2;                                   // (qcqpmi_cd_queue chooses the phase-2 kernel of qcqpmi_cd_run; it does not apply here)
-        const bool eligible = cd_queue_eligible(c, false);
-        c->cd_queue = queue_switch;
         if (!eligible)
             return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernels need separable constraints of ONE class with one constraint per "
                         "coordinate, a diagonal of P0 that is positive everywhere or zero everywhere, and 48 <= n <= 2048: use qcqpmi_cd_run per population");
@@ -1624,7 +1630,7 @@ int qcqpmi_cd_stream_reserve(qcqpmi_ctx *c, int64_t K, int64_t R) {
     {
         int nmw = 0, cs2 = 0, kind = 0, cus = 0;
         HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        if (c->life_version >= 2 && c->sep && cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, &nmw, &cs2, &kind) && (rc = cd_life2_reserve(c, nmw, cus))) return rc;
+        if (c->life_version != 1 && c->sep && cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, &nmw, &cs2, &kind) && (rc = cd_life2_reserve(c, nmw, cus))) return rc;
     }
     return 0;
 }
@@ -1680,7 +1686,7 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
 
 int qcqpmi_cd_life_version(qcqpmi_ctx *c, int version) {
-    if (!c || version < 1 || version > 2) return QCQPMI_EINVAL;
+    if (!c || version < 0 || version > 2) return QCQPMI_EINVAL;
     c->life_version = version;
     return 0;
 }

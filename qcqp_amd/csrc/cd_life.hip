@@ -932,7 +932,10 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                 // the matrix instructions of the neighbouring workgroup's product streams, the wave on SIMD 0 (two chains, little
                 // matrix work) runs several times faster -- and an even split made the build as slow as its slowest wave.  A visit's
                 // result depends on (restart, coordinate, sweep) only: who computes it is immaterial.
-                const int nch = (int)((P.n + 63) / 64);
+                // (the Boolean family's class runs TWO visits per lane at once -- p1_band_visit_n: their dependency chains interleave)
+                const bool band2 = cq == 0.0 && rel == RELOP_EQ && cp > 1e-4 && cr < -1e-3;      // workgroup-uniform
+                const int cw = band2 ? 128 : 64;
+                const int nch = (int)((P.n + cw - 1) / cw);
                 for (int64_t t = 0; t < a.num_iters; t++) {
                     if (tid == 0) {
                         int cnt = 0;
@@ -949,13 +952,28 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                         ch = __builtin_amdgcn_readfirstlane(ch);
                         if (ch >= ncol1 * nch) break;
                         const int c = p1cols[ch / nch];
-                        const int64_t i = (int64_t)(ch % nch) * 64 + lane;
                         const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
                         double va = -QM_INF;
                         int fl = 0;
-                        if (i < P.n) {
-                            const double xi = l2_p1_visit(cp, cq, cr, rel, i, Xg[i * 16 + c], a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
-                            if (fl & 1) Xg[i * 16 + c] = xi;
+                        if (band2) {
+                            const int64_t i2[2] = {(int64_t)(ch % nch) * 128 + lane, (int64_t)(ch % nch) * 128 + 64 + lane};
+                            const bool on2[2] = {i2[0] < P.n, i2[1] < P.n};
+                            double x2[2] = {on2[0] ? Xg[i2[0] * 16 + c] : 1.0, on2[1] ? Xg[i2[1] * 16 + c] : 1.0};
+                            P1Visit V2[2];
+                            p1_band_visit_n<2>(cp, cq, cr, i2, x2, on2, a.tol, lf_viol_tol, sd, gidx, t, V2);
+#pragma unroll
+                            for (int k = 0; k < 2; k++)
+                                if (on2[k]) {
+                                    if (V2[k].moved) { Xg[i2[k] * 16 + c] = x2[k]; fl |= 1; }
+                                    if (V2[k].status) fl |= (-V2[k].status) << 8;
+                                    va = V2[k].vafter > va ? V2[k].vafter : va;
+                                }
+                        } else {
+                            const int64_t i = (int64_t)(ch % nch) * 64 + lane;
+                            if (i < P.n) {
+                                const double xi = l2_p1_visit(cp, cq, cr, rel, i, Xg[i * 16 + c], a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
+                                if (fl & 1) Xg[i * 16 + c] = xi;
+                            }
                         }
                         const double vmax = l2_wave_max(va);
                         const bool anyupd = __builtin_amdgcn_ballot_w64((fl & 1) != 0) != 0ull;
@@ -972,6 +990,7 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                     __syncthreads();
                 }
             }
+            if (lf->prof && tid == 0) atomicAdd((unsigned long long *)lf->prof + 17, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pt0));
             if (tid < 16) p1key[tid] = l2_key(-QM_INF);
             __syncthreads();
             for (int c = 0; c < 16; c++) {

@@ -215,6 +215,103 @@ __device__ inline void p1_band_visit(double p, double q, double r, int64_t i, do
     V.vafter = fabs((p * xi + q) * xi + r);
 }
 
+// NV visits of the band class at once, their dependency chains side by side in the same basic blocks (round 5): a lone wave
+// executes a visit as one long chain of dependent double-precision instructions -- ~20 cycles each with a single wave on the
+// SIMD -- and two independent chains interleave almost for free.  Element k of the result is p1_band_visit on element k, bit for
+// bit: the bisection loops are fused (an element that is done idles in the body: selects), the tail that builds the set of the
+// last successful slack and draws the point is computed for every element and applied where a step succeeded.  r < -1e-3 only
+// (the Boolean family; see p1_band_visit for the test on the slack); `on[k]` = false: element k is padding.
+template <int NV>
+__device__ inline void p1_band_visit_n(double p, double q, double r, const int64_t (&i)[NV], double (&xi)[NV], const bool (&on)[NV], double tol,
+                                       double viol_tol, uint64_t seed, uint64_t grestart, int64_t t, P1Visit (&V)[NV]) {
+    double viol[NV], ss[NV], es[NV], sp[NV];
+    uint32_t it[NV], itp[NV];
+    bool pending[NV];
+    const double guard = 1e-9 * (1.0 - r);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        V[k].visited = true; V[k].moved = false; V[k].status = 0;
+        viol[k] = fabs(xi[k] * (p * xi[k] + q) + r);
+        ss[k] = -tol; es[k] = on[k] ? viol[k] - viol_tol : -tol; sp[k] = 0.0;
+        it[k] = 0; itp[k] = 0; pending[k] = false;
+    }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < NV; k++) any = any || (es[k] - ss[k] > tol);
+        if (!any) break;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const bool act = es[k] - ss[k] > tol;
+            const double s = (ss[k] + es[k]) / 2.0;
+            const uint32_t itb = it[k];
+            it[k] += act ? 1u : 0u;
+            bool nonempty = s > 0.0;
+            if (__builtin_expect(act && !(fabs(s) > guard), 0)) {       // within rounding of the threshold: the reference's discriminants
+                const double D1 = 0.0 - 4.0 * p * (r - s);
+                const double D2 = 0.0 - 4.0 * (-p) * (-r - s);
+                nonempty = D1 > 0.0 && (D2 < 0.0 || D2 < D1);
+            }
+            const bool up = act && nonempty, dn = act && !nonempty;
+            ss[k] = dn ? s : ss[k];
+            es[k] = up ? s : es[k];
+            sp[k] = up ? s : sp[k];
+            itp[k] = up ? itb : itp[k];
+            pending[k] = pending[k] || up;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        // (the expressions of p1_band_visit's tail, evaluated whether or not a step succeeded)
+        const double spk = sp[k];
+        const double r1 = r - spk, r2 = -r - spk;
+        const double rsA = r1 - 0.0, rsB = r2 - 0.0;
+        const double DA = q * q - 4.0 * p * rsA;
+        const bool hasA = DA >= 0.0;
+        const double rDA = sqrt(hasA ? DA : 0.0);
+        const double pB = -p, qB = -q;
+        const double DB = qB * qB - 4.0 * pB * rsB;
+        const bool twoB = DB >= 0.0;
+        const double rDB = sqrt(twoB ? DB : 0.0);
+        const double tA = rDA / (2.0 * p), tB = rDB / (2.0 * p);
+        const double alo = -tA, ahi = tA;
+        const double bhi0 = twoB ? -tB : QM_INF;
+        const double blo1 = tB;
+        const double l0 = alo > -QM_INF ? alo : -QM_INF, h0 = ahi < bhi0 ? ahi : bhi0;
+        const bool ok0 = hasA && l0 <= h0;
+        const double l1 = alo > blo1 ? alo : blo1, h1 = ahi < QM_INF ? ahi : QM_INF;
+        const bool ok1 = hasA && twoB && l1 <= h1;
+        int n = (ok0 ? 1 : 0) + (ok1 ? 1 : 0);
+        double lo0 = ok0 ? l0 : (ok1 ? l1 : 0.0), hi0 = ok0 ? h0 : (ok1 ? h1 : 0.0);
+        double lo1 = (ok0 && ok1) ? l1 : 0.0, hi1 = (ok0 && ok1) ? h1 : 0.0;
+        const bool same = n == 2 && lo0 == lo1 && hi0 == hi1;
+        const bool m01 = !same && n == 2 && hi0 == lo1;
+        const bool m10 = !same && !m01 && n == 2 && hi1 == lo0;
+        hi0 = m01 ? hi1 : hi0;
+        lo0 = m10 ? lo1 : lo0;
+        n = same ? 0 : ((m01 || m10) ? 1 : n);
+        const bool k0 = n >= 1 && lo0 != hi0 && hi0 != QM_INF;
+        const bool k1 = n >= 2 && lo1 != hi1 && hi1 != QM_INF;
+        const bool sw = k0 && k1 && lo1 < lo0;
+        const double a0 = sw ? lo1 : lo0, b0 = sw ? hi1 : hi0, a1 = sw ? lo0 : lo1, b1 = sw ? hi0 : hi1;
+        const int cn = (k0 ? 1 : 0) + (k1 ? 1 : 0);
+        const double c0lo = k0 ? a0 : a1, c0hi = k0 ? b0 : b1;
+        const U4 rnd = cd_draw(seed, grestart, (uint32_t)i[k], (uint32_t)t, itp[k]);
+        const int c = draw_choice(rnd, cn);
+        const double lo = (c == 1) ? a1 : c0lo, hi = (c == 1) ? b1 : c0hi;
+        const bool unb = __builtin_isinf(lo) || __builtin_isinf(hi);
+        const double xn = draw_uniform(rnd, lo, hi);
+        const int got = (cn > 0) ? (unb ? -1 : 1) : 0;
+        double new_xi = xi[k], new_viol = viol[k];
+        if (pending[k]) {
+            if (got == 1) { new_xi = xn; new_viol = spk; }
+            else if (got < 0) V[k].status = got;
+        }
+        if (on[k] && new_viol < viol[k]) { xi[k] = new_xi; V[k].moved = true; }
+        V[k].vafter = fabs((p * xi[k] + q) * xi[k] + r);
+    }
+}
+
 template <int MAXC>
 __device__ inline void p1_sep_visit(const DevProblem &P, int64_t i, double &xi, double tol, double viol_tol, uint64_t seed,
                                     uint64_t grestart, int64_t t, P1Visit &V) {

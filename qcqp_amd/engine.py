@@ -390,8 +390,9 @@ class Engine(object):
         a device-side queue (cd_phase2_qs_kernel)."""
         self._chk(self.L.qcqpmi_cd_queue(self.h, int(mode)))
 
-    def cd_life_version(self, version=2):
-        """Lifecycle kernel of cd_stream_run: 2 = cd_life_kernel (round 5, default), 1 = cd_phase2_qs_kernel<lifecycle> (round 4)."""
+    def cd_life_version(self, version=0):
+        """Lifecycle kernel of cd_stream_run: 0 = the faster one for the shape (default), 2 = cd_life_kernel (round 5) wherever it
+        applies, 1 = cd_phase2_qs_kernel<lifecycle> (round 4) only."""
         self._chk(self.L.qcqpmi_cd_life_version(self.h, int(version)))
 
     def cd_reference_order(self, enable=True):

@@ -125,6 +125,7 @@ def test_life_kernel_equals_round4_lifecycle_kernel(eng_mod):
     for n, R, K in ((256, 600, 3), (1024, 1024, 2)):
         funcs, _, _ = problems.boolean_least_squares(n, n // 4, seed=2)
         e2, e1 = make(eng_mod, funcs), make(eng_mod, funcs)
+        e2.cd_life_version(2)
         e1.cd_life_version(1)
         o2 = e2.cd_stream_run(K, R, seed=9, seed_stride=2, first_index=100, first_stride=5000)
         o1 = e1.cd_stream_run(K, R, seed=9, seed_stride=2, first_index=100, first_stride=5000)
@@ -335,3 +336,26 @@ def test_life_kernel_fuzz_shapes(eng_mod, orc, seed):
                     assert o['visits2'][r] == s2[1] and o['accepted2'][r] == s2[2], (tag, r)
         es.close()
         e.close()
+
+
+def test_lifecycle_dispatch_by_shape(eng_mod):
+    """qcqpmi_cd_life_version 0 (the default): qcqpmi_cd_stream_run launches the faster kernel for the shape -- the round-4 kernel for the
+    Boolean family at n >= 960 when the run has more restarts than the kernels have slots (BASELINE.json configs[1] streamed: 12 %
+    faster there, profiles/r05_life_vs_round4.md), cd_life_kernel everywhere else; the restarts are the same either way."""
+    from qcqp_amd import problems
+    funcs, _, _ = problems.boolean_least_squares(1024, 256, seed=1)
+    e = make(eng_mod, funcs)
+    o3 = e.cd_stream_run(3, 4096, seed=7, seed_stride=1)
+    assert e.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
+    X3 = e.download()
+    e.cd_life_version(2)
+    o3b = e.cd_stream_run(3, 4096, seed=7, seed_stride=1)
+    assert e.last_cd_kernel() == 'cd_life_kernel<3,band>'
+    assert np.max(np.abs(e.download() - X3)) < 1e-12 and np.array_equal(o3['visits2'], o3b['visits2']) and np.array_equal(o3['best_index'], o3b['best_index'])
+    e.cd_life_version(0)
+    e.cd_stream_run(1, 4096, seed=7)
+    assert e.last_cd_kernel() == 'cd_life_kernel<3,band>'              # one population: nothing to stream, the newer kernel's latency is lower
+    funcs, _, _ = problems.boolean_least_squares(512, 128, seed=1)
+    e = make(eng_mod, funcs)
+    e.cd_stream_run(3, 4096, seed=7, seed_stride=1)
+    assert e.last_cd_kernel() == 'cd_life_kernel<3,band>'

@@ -1,6 +1,12 @@
 mkdir -p gpurun_out
-(
-echo "=== bls 1024 4096 K=20"; LIFE_PROF=1 LIFE_SERIAL=0 timeout 300 python tools/life_check.py bls 1024 4096 20 1000 0
-) > gpurun_out/lc14.log 2>&1
-grep -v "^$" gpurun_out/lc14.log | cut -c1-330 | grep -v "run [01]:" | tail -12
-timeout 2400 python -m pytest tests -q -m gpu --durations=10 -x 2>&1 | tail -30 > gpurun_out/t_all.log; tail -30 gpurun_out/t_all.log
+timeout 600 python -m pytest tests/test_gpu_life.py -q -m gpu -x -k "dispatch or round4 or launcher" 2>&1 | tail -4
+timeout 900 python bench.py --steps 20 --warmup 5 --no-secondary > gpurun_out/bench_r05_b.json 2> gpurun_out/bench_r05_b.err; tail -c 400 gpurun_out/bench_r05_b.err
+python - <<'PY'
+import json
+txt=open('gpurun_out/bench_r05_b.json').read()
+d=json.loads([l for l in txt.splitlines() if l.startswith('{')][-1])
+print({k:d[k] for k in ('value','ms_per_step','n_gpus','steps')}, d['roofline']['kernel'], round(d['roofline']['frac'],4), d['roofline']['traffic_provenance'])
+print('other:', d['schemes'].get('other_lifecycle_kernel'))
+print('two:', d['schemes'].get('two',{}).get('value'))
+print('cpu', d.get('cpu_baseline',{}).get('value'), d['best'])
+PY

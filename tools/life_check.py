@@ -62,6 +62,8 @@ def main():
         print('profile (%.3f ms): column build %.1f %% of the workgroups\' time (normals %.1f %%), roles %.1f %%, rest %.1f %%; %d episodes, %d columns; workgroups with evenly spread waves: %d' % (
             es.kernel_ms(2), 100.0 * pr[0] / max(pr[1], 1), 100.0 * pr[4] / max(pr[1], 1), 100.0 * pr[5] / max(pr[1], 1),
             100.0 * (pr[1] - pr[0] - pr[5]) / max(pr[1], 1), pr[2], pr[3], pr[6]), flush=True)
+        print('  column build: normals %.1f %%, phase-1 sweeps %.1f %%, slack + gate + set + padding %.1f %% of the workgroups\' time' % (
+            100.0 * pr[4] / max(pr[1], 1), 100.0 * (pr[17] - pr[4]) / max(pr[1], 1), 100.0 * (pr[0] - pr[17]) / max(pr[1], 1)), flush=True)
         nwg = max(int(pr[6]), 1)
         print('  longest workgroup %.3e ticks = %.3f GHz tick rate; the average workgroup was alive %.1f %% of the launch' % (
             pr[16], pr[16] / (es.kernel_ms(2) * 1e-3) / 1e9, 100.0 * pr[1] / nwg / max(pr[16], 1)), flush=True)
