@@ -118,6 +118,24 @@ __device__ __attribute__((noinline)) double qs_p1_visit(double p, double q, doub
     return x;
 }
 
+// two visits of the Boolean family's class at once (round 5, cd_phase1_sep.h::p1_band_visit_n: the dependency chains of two visits
+// interleave; element k of the result is the single visit's, bit for bit) -- a call like the one above, for the same reason
+__device__ __attribute__((noinline)) void qs_p1_visit2(double p, double q, double r, int64_t i0, int64_t i1, bool on1, double *x0, double *x1,
+                                                       double tol, double viol_tol, uint64_t seed, uint64_t restart, int64_t t, int *flags,
+                                                       double *vafter) {
+    const int64_t ii[2] = {i0, i1};
+    const bool on[2] = {true, on1};
+    double xx[2] = {*x0, *x1};
+    P1Visit V[2];
+    p1_band_visit_n<2>(p, q, r, ii, xx, on, tol, viol_tol, seed, restart, t, V);
+    *x0 = xx[0]; *x1 = xx[1];
+    int fl = (V[0].moved ? 1 : 0) | ((on1 && V[1].moved) ? 2 : 0);
+    if (V[0].status) fl |= (-V[0].status) << 8;
+    else if (on1 && V[1].status) fl |= (-V[1].status) << 8;
+    *flags = fl;
+    *vafter = on1 ? (V[0].vafter > V[1].vafter ? V[0].vafter : V[1].vafter) : V[0].vafter;
+}
+
 // CS: blocks of the contraction the chain wave multiplies itself (0..RQ_CSMAX); LIFE: lifecycle mode (cd_queue.h)
 template <int CS, bool LIFE>
 __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
@@ -281,6 +299,20 @@ __global__ __launch_bounds__(512) void cd_phase2_qs_kernel(CdQueueArgs a0) {
                         const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
                         double vmax = -QM_INF;
                         int upd = 0, st = 0;
+                        if (cq == 0.0 && rel == RELOP_EQ && cp > 1e-4 && cr < -1e-3) {       // the Boolean family: two visits per call
+                            for (int64_t i = tid; i < P.n; i += 1024) {
+                                int fl;
+                                double va;
+                                const int64_t i1 = i + 512;
+                                const bool on1 = i1 < P.n;
+                                double xa = Xs[i * 16 + c], xb = on1 ? Xs[i1 * 16 + c] : 1.0;
+                                qs_p1_visit2(cp, cq, cr, i, i1, on1, &xa, &xb, a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
+                                if (fl >> 8) st = -(fl >> 8);
+                                if (fl & 1) { Xs[i * 16 + c] = xa; upd = 1; }
+                                if (fl & 2) { Xs[i1 * 16 + c] = xb; upd = 1; }
+                                vmax = va > vmax ? va : vmax;
+                            }
+                        } else
                         for (int64_t i = tid; i < P.n; i += 512) {
                             int fl;
                             double va;

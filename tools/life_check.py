@@ -38,6 +38,7 @@ def main():
     form = QCQPForm.from_arrays(funcs)
     seed0, first0, fstride = 1000, 7, 100000
     es = Engine(form)
+    es.cd_life_version(int(os.environ.get('LIFE_VER', '2')))
     dbg = int(os.environ.get('LIFE_DBG', '0'))
     if dbg:
         es.L.qcqpmi_debug_profile(es.h, dbg << 4, None)
