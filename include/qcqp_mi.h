@@ -272,7 +272,10 @@ int qcqpmi_cd_queue(qcqpmi_ctx *ctx, int mode);     /* 0 off, 1 on wherever it a
  * partial tiles, [9] / [10] multiplying wave 0's waits for a commit / for its slot, [11] block intervals, [12] blocks with a
  * near-tie replay, [13] / [14] / [15] / [7] the chain's stages: sum of the partial tiles + requests, the 16 steps, block end +
  * commit, fix-up + own share + staging, [16] the longest workgroup's [1] (ticks of the launch as the device saw it: with the
- * HIP-event duration the tick rate; [1] / workgroups / [16] = how much of the launch the average workgroup was alive) */
+ * HIP-event duration the tick rate; [1] / workgroups / [16] = how much of the launch the average workgroup was alive), [17] column
+ * build up to the end of phase 1, [18] the chain's prologue per episode (virtual interval, operands of block 0), [19] issuing an
+ * interval's memory requests (top of the chain's loop: not part of [13]), [20] from the chain's last interval to the barrier
+ * that ends the episode */
 int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out24);
 /* POPULATION STREAMING (round 4) -- the reference's user loop `for ...: suggest(); improve(COORD_DESCENT)` (README.md:51-57)
  * for K populations of R restarts in ONE persistent launch: a workgroup owns 16 restart slots; a slot that becomes free draws

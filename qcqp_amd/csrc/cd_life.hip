@@ -223,6 +223,7 @@ __device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
     //   A fragments of block row `row`: buffer loads, descriptor = P.Apack2, scalar offset = row KS 512 + block 2048,
     //   vector offset = lane 16, through a ring of RQ_PFU units refilled in place.
     const RqOwn own = l2_own(NB, CS, m, NMW);
+    const int nu = own.nu;                         // units this wave owns
     v2d_ arP[2 * RQ_PFU];
     const unsigned vlane = (unsigned)lane * 16u;
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(pApack2), 0, NB * KS * 512, 0x00020000);
@@ -249,7 +250,7 @@ __device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
     asm volatile("" : "+v"(rbase));
     int row = 0;
     #pragma unroll
-    for (int U = 0; U < RQ_PFU; U++) L2_LDA(arP + 2 * U, row * rowstride + (m + NMW * U) * 2048, vlane)
+    for (int U = 0; U < RQ_PFU; U++) L2_LDA(arP + 2 * U, row * rowstride + (m + ((U < nu) ? NMW * U : 0)) * 2048, vlane)
     int spins = 0;
     const bool prof_on = pprof != nullptr && m == 0;
     long long pw_commit = 0, pw_cons = 0;
@@ -303,8 +304,10 @@ __device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(arP[2 * U + 1][1], bu[3], acc1, 0, 0, 0);
                 }
                 // unconditional refill of the ring slot: the unit RQ_PFU further on, then the first units of the next row
-                if (third < RQ_RND - 1) { if (u + RQ_PFU < RQ_MAXU) L2_LDA(arP + 2 * U, so1 + NMW * 2048 * (u + RQ_PFU), vlane) }
-                else L2_LDA(arP + 2 * U, so2 + NMW * 2048 * U, vlane)
+                // (a unit the wave does not own: the fragment of its first unit again -- a line the vector cache holds, not another one
+                //  from L2; making the loads conditional instead costs the counted waits of the ring: 48 -> 63 ms at n = 1024)
+                if (third < RQ_RND - 1) { if (u + RQ_PFU < RQ_MAXU) L2_LDA(arP + 2 * U, so1 + ((u + RQ_PFU < nu) ? NMW * 2048 * (u + RQ_PFU) : 0), vlane) }
+                else L2_LDA(arP + 2 * U, so2 + ((U < nu) ? NMW * 2048 * U : 0), vlane)
             }
         }
         acc = acc + acc1;
@@ -344,7 +347,7 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
     constexpr int CSU = CS > 0 ? CS : 1;
     constexpr bool PRE = KIND == L2_KIND_LIN;      // a restart's phase 2 starts with a frozen sweep that evaluates f0
     L2_LDS_VIEW
-    (void)slk; (void)snew; (void)ctl; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols;
+    (void)slk; (void)snew; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols;
     const int lane = threadIdx.x & 63, r = lane >> 2, gq = lane & 3;
     LG const double *Apk = l2_g(l2_uni(par->Apack));
     LG const double *Apk2 = l2_g(l2_uni(par->Apack2));
@@ -454,7 +457,8 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
     int b = 0, spins = 0;
     bool wdog = false;
     const bool prof_on = pprof != nullptr;
-    long long pw_part = 0, pt_sum = 0, pt_steps = 0, pt_end = 0, pt_fix = 0, ptl = 0;
+    long long pw_part = 0, pt_sum = 0, pt_steps = 0, pt_end = 0, pt_fix = 0, pt_req = 0, ptl = 0;
+    if (prof_on) { ptl = (long long)__builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(pprof + 18, (unsigned long long)(ptl - *(long long *)(ctl + 6))); }
     int pn_int = 0, pn_gen = 0;
 #define L2_TICK(acc) if (prof_on) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); acc += now_ - ptl; ptl = now_; }
     for (int64_t g = 0; g < gmax; g++) {
@@ -500,7 +504,7 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
         }
         if (wdog) { rq_sync_write(sy, L2_ABORT, 1, lane); break; }
         spins = 0;
-        if (prof_on) { ptl = (long long)__builtin_amdgcn_s_memtime(); pw_part += ptl - tw0; pn_int++; }
+        if (prof_on) { pt_req += tw0 - ptl; ptl = (long long)__builtin_amdgcn_s_memtime(); pw_part += ptl - tw0; pn_int++; }
         // ---- G + q/2 of the lane's own columns: its own plane, then the partial tiles, in a fixed order, then q/2
         double gb[4], xn[4], rto[4], t2o[4], hq4[4];
     #pragma unroll
@@ -744,6 +748,8 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
         atomicAdd(pprof + 13, (unsigned long long)pt_sum);
         atomicAdd(pprof + 14, (unsigned long long)pt_steps);
         atomicAdd(pprof + 15, (unsigned long long)pt_end);
+        atomicAdd(pprof + 19, (unsigned long long)pt_req);        // issuing the interval's requests (top of the loop)
+        *(long long *)(ctl + 8) = (long long)__builtin_amdgcn_s_memtime();
         atomicAdd(pprof + 7, (unsigned long long)pt_fix);
         atomicAdd(pprof + 8, (unsigned long long)pw_part);
         atomicAdd(pprof + 11, (unsigned long long)pn_int);
@@ -1069,7 +1075,11 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
             break;
         }
         if (tid == 0 && l2_g(lifep)->prof)
-            atomicAdd((unsigned long long *)l2_g(lifep)->prof + 5, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - *(long long *)(ctl + 6)));
+        {
+            const long long now_ = (long long)__builtin_amdgcn_s_memtime();
+            atomicAdd((unsigned long long *)l2_g(lifep)->prof + 5, (unsigned long long)(now_ - *(long long *)(ctl + 6)));
+            atomicAdd((unsigned long long *)l2_g(lifep)->prof + 20, (unsigned long long)(now_ - *(long long *)(ctl + 8)));    // from the chain's last interval to the barrier
+        }
         // ================================================================ write out the slots that finished
         {
             // max violation of the final points, same expression as eval_kernel: (p x + q) x + r of the one constraint

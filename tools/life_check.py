@@ -71,6 +71,7 @@ def main():
         ni = max(int(pr[11]), 1)
         print('  per block interval (s_memtime ticks): roles %.1f, chain waits for partials %.1f, multiplying wave 0 waits: commit %.1f, slot %.1f; intervals %d, with a near-tie replay %d' % (
             pr[5] / ni, pr[8] / ni, pr[9] / ni, pr[10] / ni, pr[11], pr[12]), flush=True)
+        print('  per EPISODE (ticks): chain prologue %.0f, after the chain left its loop %.0f; per interval: requests %.1f' % (pr[18] / max(pr[2], 1), pr[20] / max(pr[2], 1), pr[19] / ni), flush=True)
         print('  chain per interval: sum + requests %.1f, 16 steps %.1f, block end + commit %.1f, fix-up + share + staging %.1f' % (
             pr[13] / ni, pr[14] / ni, pr[15] / ni, pr[7] / ni), flush=True)
     X = es.download()
