@@ -71,6 +71,7 @@ def secondary_records(device, sdr_full=False):
     from qcqp_amd.engine import Engine
     from qcqp_amd.form import QCQPForm
     recs = []
+    only = os.environ.get("BENCH_ONLY")
     # the headline family with 4 tiles per CU: the hardware's workgroup queue refills a CU as soon as its tile of 16 restarts
     # has converged, so the 1-workgroup-per-CU straggler effect of the headline (kernel time = slowest tile) is amortised
     try:
@@ -226,6 +227,47 @@ def secondary_records(device, sdr_full=False):
                                   'algorithmic_flops_per_restart_sweep': 2.0 * n * n}})
     except Exception as ex:
         recs.append({'config': 'MAXCUT G(2000, 0.5) through improve(COORD_DESCENT)', 'error': repr(ex)})
+    # configs[1]'s problem through improve(ADMM): separable constraints x_i^2 = 1 -> bases of unit vectors (round 5)
+    try:
+        n, R, iters = 1024, 4096, 100
+        funcs, _, _ = problems.boolean_least_squares(n, n // 4, seed=1)
+        form = QCQPForm.from_arrays(funcs)
+        e = Engine(form, device=device)
+        t0 = time.perf_counter()
+        lam, Bv, qhat = form.unit_bases()
+        e.admm_set_basis(lam, Bv, qhat)
+        rho = 50.0 / form.m                      # improve_admm's automatic rho for a positive semidefinite P0 (qcqp.py:270-277)
+        e.admm_zsolver_device(rho)
+        e.sync()
+        t_setup = time.perf_counter() - t0
+        pts = {}
+        for unit in (True, False):
+            e.admm_unit_bases(unit)
+            e.randn(R, seed=3)
+            e.admm_run(rho, None, phase1=True, num_iters=2)
+            e.randn(R, seed=3)
+            e.sync()
+            t0 = time.perf_counter()
+            out = e.admm_run(rho, None, phase1=True, num_iters=iters)
+            e.sync()
+            pts[unit] = (time.perf_counter() - t0, float(out['iters1'].sum()), float(out['iters2'].sum()), e.last_admm_kernel()[0], out)
+        dt, i1, i2, name, out = pts[True]
+        fl = 4.0 * n * n                          # per phase-2 restart-iteration: z = Minv rhs and f0(z) = z^T P0 z + ... (qcqp.py:231-232, 249)
+        recs.append({'config': 'BASELINE.json configs[1]\'s problem (Boolean least squares n = 1024, m = 1024 constraints) through improve(ADMM, '
+                               'num_iters=%d), %d restarts on one GPU' % (iters, R),
+                     'metric': 'restart-iterations / s', 'value': (i1 + i2) / dt, 'unit': 'restart-iterations/s', 'kernel': name,
+                     'wall_s': dt, 'gemm_path_wall_s': pts[False][0], 'gemm_path_kernel': pts[False][3],
+                     'setup_s': t_setup, 'setup': 'bases of unit vectors written down (the reference: 1024 LAPACK decompositions of 1024 x 1024 matrices, '
+                                                  '8.6 GB of eigenvectors), (2 (P0 + rho m I))^-1 by Newton-Schulz on the device',
+                     'iterations_per_restart': [i1 / R, i2 / R], 'feasible': int((out['maxviol'] < 1e-2).sum()), 'restarts': R,
+                     'roofline': {'bound': 'mfma', 'kernel': 'gemm_pk_kernel (z = Minv rhs, f0(z)) + gather / secular / scatter / bookkeeping kernels',
+                                  'achieved': i2 * fl / dt / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': i2 * fl / dt / 1e12 / FP64_PEAK_TFLOPS,
+                                  'algorithmic_flops_per_restart_iteration': fl,
+                                  'note': 'wall clock of the whole improve_admm (phase 1: no matrix product at all with unit bases; phase 2: two n x n '
+                                          'products per restart-iteration); 7 launches per iteration, not fused'}})
+        del e
+    except Exception as ex:
+        recs.append({'config': 'configs[1] through improve(ADMM)', 'error': repr(ex)[:300]})
     # configs[3]: secondary-user beamforming, 512 antennas (n = 1024 real), 16 + 64 constraints, improve(ADMM, rho = 1)
     try:
         funcs, _, _ = problems.beamforming(512, 16, 64, seed=1)
@@ -376,8 +418,7 @@ def secondary_records(device, sdr_full=False):
                                   'frac_phase1': fl * s1 / 1e12 / (ms1 / 1e3) / FP64_PEAK_TFLOPS if ms1 > 0 else None,
                                   'algorithmic_flops_per_restart_sweep': fl,
                                   'timing': 'HIP events around the sweep loops of phase 2 (frac) and phase 1 (frac_phase1): block products on the '
-                                            'matrix cores + chain kernels; the chip sustains 47 TFLOP/s = 0.60 of the data-sheet peak on pure fp64 '
-                                            'MFMA loops of this length (profiles/r01_fp64_mfma_sustained.md)'}})
+                                            'matrix cores + chain kernels (sustained fp64 MFMA rate of the chip: profiles/r05_fp64_mfma_sustained.md)'}})
         del e
     except Exception as ex:
         recs.append({'config': 'configs[4] at full size', 'error': repr(ex)[:300]})

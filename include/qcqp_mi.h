@@ -211,6 +211,13 @@ int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, 
  * cross-check; same iteration, other summation order in the two products); default 1.  qcqpmi_last_admm_kernel names the
  * path the last run took ("admm_fused_kernel" / "admm_multi_launch") and the workgroups per tile it used. */
 int qcqpmi_admm_fused(qcqpmi_ctx *ctx, int enable);
+
+/* Unit bases (round 5).  When every basis vector handed to qcqpmi_admm_set_basis is +-e_i -- separable constraints
+ * p x_i^2 + q x_i + r ~ 0 (Boolean least squares, MAXCUT, boxes; /root/reference/examples/boolean_least_squares.py:34-36,
+ * maxcut.py:25-28), for which the eigenvectors utilities.py:160-162 takes from LAPACK are unit vectors -- qcqpmi_admm_run
+ * replaces the two consensus products of an iteration (qcqp.py:204-207, 236-239 in the basis) by a gather and a scatter:
+ * the same values, no n x m operator.  On by default; enable = 0 forces the GEMM path (cross-check). */
+int qcqpmi_admm_unit_bases(qcqpmi_ctx *ctx, int enable);
 const char *qcqpmi_last_admm_kernel(qcqpmi_ctx *ctx, int *workgroups_per_tile);
 
 /* Y = (sum_k w_k P_k) X for the resident population (w: m+1 weights, objective first; Y: R x n like

@@ -58,6 +58,7 @@ PROTOTYPES = [
     ('qcqpmi_admm_run', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double, c_dp,
                                   c_ip, c_ip, c_dp, c_dp]),
     ('qcqpmi_admm_fused', C.c_int, [C.c_void_p, C.c_int]),
+    ('qcqpmi_admm_unit_bases', C.c_int, [C.c_void_p, C.c_int]),
     ('qcqpmi_last_admm_kernel', C.c_char_p, [C.c_void_p, C.POINTER(C.c_int)]),
     ('qcqpmi_select_best', C.c_int, [C.c_void_p, C.c_double, c_ip, c_dp, c_dp, c_dp]),
     ('qcqpmi_last_kernel_ms', C.c_int, [C.c_void_p, C.c_int, c_dp]),

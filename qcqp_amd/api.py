@@ -374,6 +374,13 @@ class QCQP(object):
                 # matrices resident.  The first use in a process loads the 0.9 GB librocsolver.so.
                 self.engine.admm_setup()
                 mode = 'rocsolver'
+            elif self.engine.separable and kwargs.get('unit_bases', True) and form.unit_bases() is not None:
+                # every constraint touches one coordinate: P_k = p e_i e_i^T, whose eigenvectors (utilities.py:160-162) are unit
+                # vectors -- the basis is written down, no eigendecomposition (the reference: m calls of LAPACK on n x n
+                # matrices), and the engine moves entries instead of multiplying by an n x m operator (qcqpmi_admm_unit_bases)
+                lam, Bv, qhat = form.unit_bases()
+                self.engine.admm_set_basis(lam, Bv, qhat)
+                mode = 'unit bases (separable constraints)'
             elif kwargs.get('lowrank', True) and not self.engine.separable and form.n >= 64:
                 from . import lowrank as _lr
                 red = _lr.reduced_bases(self.engine, form, seed=0)

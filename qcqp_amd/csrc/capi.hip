@@ -117,6 +117,10 @@ struct qcqpmi_ctx {
     double *d_Fpack = nullptr, *d_Frow = nullptr, *d_mu = nullptr;
     Timer timers[5];
     // ADMM: the stacked bases B = [B_1 ... B_m] packed for the two products (gemm_pk.h), eigenvalues, B^T q, brackets
+    // unit bases (every basis vector is +-e_i: separable constraints): ZQ = W^T Z is a gather, S = W D a scatter (no GEMM)
+    int *ad_uidx = nullptr, *ad_uptr = nullptr, *ad_ulist = nullptr;       // [Mh16] coordinate of basis row h (-1: padding); CSR coordinate -> rows
+    double *ad_usgn = nullptr;                                             // [Mh16] its sign
+    bool ad_unit = false, ad_unit_off = false;
     double *ad_WTpk = nullptr, *ad_Wpk = nullptr, *ad_lam = nullptr, *ad_qhat = nullptr, *ad_rk = nullptr, *ad_slo = nullptr, *ad_ehi = nullptr;
     double *ad_Minvpk = nullptr;
     int *ad_relop = nullptr;

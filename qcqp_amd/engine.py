@@ -311,6 +311,11 @@ class Engine(object):
         """Fused persistent ADMM kernel on / off (off = the multi-launch path everywhere: the cross-check)."""
         self._chk(self.L.qcqpmi_admm_fused(self.h, 1 if enable else 0))
 
+    def admm_unit_bases(self, enable=True):
+        """Bases of unit vectors (separable constraints): gather / scatter instead of the two consensus GEMMs of an ADMM iteration
+        (default on; off = the GEMM path on the same bases: the cross-check)."""
+        self._chk(self.L.qcqpmi_admm_unit_bases(self.h, 1 if enable else 0))
+
     def last_admm_kernel(self):
         """('admm_fused_kernel' | 'admm_multi_launch', workgroups per tile) of the most recent admm_run."""
         cw = C.c_int(0)

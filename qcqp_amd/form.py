@@ -41,7 +41,35 @@ class QCQPForm(object):
         self.n = f0.P.shape[0]
         self.m = len(fs)
         self.rho = None       # for ADMM
+        self._unit_bases = False   # cache of unit_bases()
         self.z_solver = None  # for ADMM
+
+    def unit_bases(self):
+        """(lam (m, 1), Bv (m, 1, n), qhat (m, 1)) for constraints that each touch ONE coordinate: the nonzero eigenpair of
+        P_k = p e_i e_i^T is (p, e_i), q_k = q e_i (utilities.py:160-166 in closed form).  None if some constraint couples coordinates."""
+        if self._unit_bases is not False:
+            return self._unit_bases
+        form = self
+        m, n = form.m, form.n
+        lam = np.zeros((m, 1)); Bv = np.zeros((m, 1, n)); qhat = np.zeros((m, 1))
+        for k, f in enumerate(form.fs):
+            if sp.issparse(f.P):
+                Pc = f.P.tocoo()
+                keep = Pc.data != 0
+                touched = set(Pc.row[keep].tolist()) | set(Pc.col[keep].tolist())
+            else:
+                rr, cc = np.nonzero(f.P)
+                touched = set(rr.tolist()) | set(cc.tolist())
+            touched |= set(np.nonzero(f.qarray)[0].tolist())
+            if len(touched) > 1:
+                self._unit_bases = None
+                return None
+            i = touched.pop() if touched else 0
+            lam[k, 0] = f.P[i, i]
+            Bv[k, 0, i] = 1.0
+            qhat[k, 0] = f.qarray[i]
+        self._unit_bases = (lam, Bv, qhat)
+        return self._unit_bases
 
     def fi(self, i):
         return self.fs[i]
