@@ -21,6 +21,7 @@ import subprocess
 import sys
 import tempfile
 import time
+import warnings
 import uuid
 
 import numpy as np
@@ -112,12 +113,28 @@ def _job_key():
                                 os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())
 
 
+RANK_START_WINDOW = 300.0      # seconds within which all ranks of one job start
+
+
 def _job_epoch():
-    """Earliest time a message of THIS job can have been written: the start of the launcher (external launcher: the key
-    is predictable, so files of a crashed earlier job with a recycled pid must not be read as messages)."""
+    """Earliest time a message of THIS job can have been written (external launcher: the key is predictable, so files of an
+    earlier job with the same key must not be read as messages): the later of
+      * the start of the launcher (the parent process) -- a crashed job with a recycled launcher pid is older than that;
+      * this rank's own start minus RANK_START_WINDOW -- ranks started one after the other by the SAME parent (a shell script:
+        same ppid, same MASTER_PORT, hence the same key and the same launcher start) still reject what a job that crashed more
+        than the window ago left behind.  Inside the window the files of a crashed twin job cannot be told from this job's
+        by time alone: rank 0 therefore also clears what is older than the epoch when it opens the directory (FileComm)."""
     if os.environ.get(RDZV_ENV):
         return 0.0                      # uuid key: the directory cannot pre-exist
-    return _proc_start_time(os.getppid()) - 2.0
+    launcher = _proc_start_time(os.getppid())
+    own = _proc_start_time(os.getpid())
+    if own <= 0.0:
+        own = time.time()
+    if launcher <= 0.0:
+        warnings.warn('qcqp_amd.dist: the start time of the launcher (pid %d) is unavailable; messages older than %.0f s before this '
+                      'rank started are treated as stale' % (os.getppid(), RANK_START_WINDOW))
+        return own - RANK_START_WINDOW
+    return max(launcher - 2.0, own - RANK_START_WINDOW)
 
 
 def _proc_start_time(pid):
@@ -197,6 +214,15 @@ class FileRendezvous(object):
         self.dir = _private_dir(os.path.join(_rdzv_root(), key))
         self.epoch = _job_epoch()
         self.seq = 0
+        if self.rank == 0 and self.epoch > 0.0:
+            # leftovers of a dead job with the same key: remove what no rank of this job can have written
+            for name in os.listdir(self.dir):
+                path = os.path.join(self.dir, name)
+                try:
+                    if os.lstat(path).st_mtime < self.epoch:
+                        os.remove(path)
+                except OSError:
+                    pass
 
     def _put(self, name, obj):
         path = os.path.join(self.dir, name)

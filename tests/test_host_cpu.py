@@ -5,6 +5,7 @@ import os
 import re
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -226,6 +227,44 @@ def test_two_process_self_spawn_selection(tmp_path, orc):
     subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=600, stdout=subprocess.PIPE,
                    stderr=subprocess.STDOUT)
     _check_two_rank_result(tmp_path, orc)
+
+
+def test_rendezvous_rejects_and_clears_leftovers_of_a_dead_job(tmp_path, monkeypatch):
+    """External launcher: the rendezvous key is predictable (launcher pid + endpoint), so a directory with files of a dead job
+    can pre-exist.  A message file older than the job's epoch is not a message; rank 0 removes such files when it opens the
+    directory; the epoch is the later of the launcher's start and this rank's start minus the window in which the ranks of one
+    job start; without a launcher start time (no /proc entry) a warning is raised and the own start time alone decides."""
+    import warnings
+    from qcqp_amd import dist
+    monkeypatch.delenv(dist.RDZV_ENV, raising=False)
+    monkeypatch.setenv('XDG_RUNTIME_DIR', str(tmp_path))
+    monkeypatch.setenv('MASTER_PORT', '29999')
+    now = time.time()
+    ep = dist._job_epoch()
+    assert now - dist.RANK_START_WINDOW - 5.0 <= ep <= now
+    # a stale message of the same key, 1000 s old: rejected by _fresh, removed by rank 0
+    key = dist._job_key()
+    d = os.path.join(str(tmp_path), 'qcqp_amd_rdzv', key)
+    os.makedirs(d, mode=0o700)
+    os.chmod(os.path.join(str(tmp_path), 'qcqp_amd_rdzv'), 0o700)
+    stale = os.path.join(d, 'b000001')
+    with open(stale, 'wb') as f:
+        f.write(b'Jnull')
+    os.utime(stale, (now - 1000.0, now - 1000.0))
+    cls = dist.FileRendezvous if hasattr(dist, 'FileRendezvous') else dist.FileComm
+    c1 = cls(rank=1, world=2)
+    assert not c1._fresh(stale) and os.path.exists(stale)           # rank 1 ignores it ...
+    c0 = cls(rank=0, world=2)
+    assert not os.path.exists(stale)                                # ... rank 0 clears it
+    c0._put('b000001', b'fresh')
+    assert c1._fresh(os.path.join(d, 'b000001'))
+    # launcher start time unavailable: a warning, and the own start decides
+    monkeypatch.setattr(dist, '_proc_start_time', lambda pid: 0.0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ep2 = dist._job_epoch()
+    assert any('start time of the launcher' in str(x.message) for x in w)
+    assert time.time() - dist.RANK_START_WINDOW - 5.0 <= ep2 <= time.time()
 
 
 def test_product_package_does_not_import_torch():
