@@ -31,6 +31,19 @@ def family(name, n):
         return problems.box_least_squares(n, max(n // 4, 4), seed=3)[0]
     if name == 'maxcut':
         return problems.maxcut(n, 0.5, seed=3, weighted=True)[0]
+    if name == 'lin2':
+        # TWO constraints per coordinate, both linear (P_k = 0: the basis vector carries the q direction only, eigenvalue 0):
+        # x_i <= u_i and -x_i <= -l_i around a least-squares objective -- the scatter sums two rows per coordinate
+        rs = np.random.RandomState(4)
+        A = rs.randn(max(n // 2, 4), n)
+        b = rs.randn(max(n // 2, 4)) * np.sqrt(n)
+        fs = [(A.T.dot(A) + 0.1 * np.eye(n), -2.0 * A.T.dot(b), float(b.dot(b)), None)]
+        lo, hi = -0.5 - rs.rand(n), 0.5 + rs.rand(n)
+        for i in range(n):
+            e = np.zeros(n); e[i] = 1.0
+            fs.append((np.zeros((n, n)), e, -hi[i], '<='))
+            fs.append((np.zeros((n, n)), -e, lo[i], '<='))
+        return fs
     raise ValueError(name)
 
 
@@ -60,7 +73,7 @@ def run_engine(eng_mod, form, bases, rho, X0, iters, unit):
     return X, out
 
 
-@pytest.mark.parametrize('name,n,R', [('bls', 48, 40), ('bls', 100, 24), ('box', 64, 24), ('maxcut', 40, 24)])
+@pytest.mark.parametrize('name,n,R', [('bls', 48, 40), ('bls', 100, 24), ('box', 64, 24), ('maxcut', 40, 24), ('lin2', 32, 24)])
 def test_admm_unit_bases_vs_oracle_and_gemm_path(eng_mod, orc, name, n, R):
     """Two runs against the oracle's improve_admm (LAPACK eigenpairs of every constraint, like the reference):
       * 10 + 10 iterations: every sampled restart within 1e-9 -- the iteration is the reference's;
@@ -72,13 +85,13 @@ def test_admm_unit_bases_vs_oracle_and_gemm_path(eng_mod, orc, name, n, R):
     from qcqp_amd.form import QCQPForm
     funcs = family(name, n)
     form = QCQPForm.from_arrays(funcs)
-    assert form.m == n
+    assert form.m == (2 * n if name == 'lin2' else n)
     ub = form.unit_bases()
     assert ub is not None
     lam = ub[0]
     # what LAPACK returns for these matrices: the eigenvalues are EXACTLY {0, ..., p} (so the bracket of the multiplier,
     # utilities.py:176-180, is the one the nonzero eigenvalue gives) and the eigenvectors are unit vectors
-    for k in (0, n // 2, n - 1):
+    for k in (0, n // 2, form.m - 1):
         Pk = np.asarray(form.fs[k].P.todense()) if hasattr(form.fs[k].P, 'todense') else np.asarray(form.fs[k].P)
         w, Q = np.linalg.eigh((Pk + Pk.T) / 2.0)
         assert sorted(w.tolist()) == sorted([0.0] * (n - 1) + [lam[k, 0]])

@@ -1,3 +1,4 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_life.py tests/test_gpu_stream.py -x -q -m gpu > gpurun_out/t_life.log 2>&1; tail -3 gpurun_out/t_life.log
-timeout 600 python tools/life_vs_r4.py > gpurun_out/life_vs_r4.log 2>&1; tail -20 gpurun_out/life_vs_r4.log
+for w in 5 20 60; do python bench.py --steps 20 --warmup $w --no-secondary --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('warmup', r['warmup'], 'ms/step', r['ms_per_step'], 'frac', r['roofline']['frac'], 'kernel ms', r['roofline']['kernel_ms_per_launch'])"; done
