@@ -372,15 +372,20 @@ __global__ __launch_bounds__(ADMM_TPB) void admm_zupdate_kernel(AdmmZArgs a) {
     }
 }
 
-// dense solve: Znew = Minv rhs came out of the GEMM; Z <- Znew for active restarts, ||Zlast - Znew||^2 per restart
+// dense solve: Znew = Minv rhs came out of the GEMM; Z <- Znew for active restarts, ||Zlast - Znew||^2 per restart.
+// With rhs != nullptr also f0(z) for `better` (qcqp.py:249) WITHOUT a second n x n product: z solves 2 (P0 + rho m I) z = rhs
+// (qcqp.py:231-232), hence P0 z = rhs / 2 - rho m z and f0(z) = z.(rhs / 2 - rho m z + q0) + r0 -- exact up to the accuracy of
+// the solve (Newton-Schulz residual < 1e-10; the points, their reported objective and the final `better` are evaluated with
+// P0 itself).
 __global__ __launch_bounds__(ADMM_TPB) void admm_take_z_kernel(double *Z, const double *Znew, const double *Zlast,
-                                                           const uint8_t *act, double *dist2, int64_t n, int64_t n16, int64_t R) {
-    __shared__ double red[ADMM_TPB];
+                                                           const uint8_t *act, double *dist2, int64_t n, int64_t n16, int64_t R,
+                                                           const double *rhs, const double *q0, double r0, double rho_m, double *f0) {
+    __shared__ double red[ADMM_TPB], redf[ADMM_TPB];
     const int64_t tile = blockIdx.x;
     const int rr = threadIdx.x & 15, jl = threadIdx.x >> 4;
     const int64_t r = tile * 16 + rr;
     const bool on = r < R && act[r];
-    double acc = 0.0;
+    double acc = 0.0, accf = 0.0;
     if (on)
         for (int64_t j = jl; j < n; j += ADMM_TPB / 16) {
             const int64_t idx = (tile * n16 + j) * 16 + rr;
@@ -388,13 +393,18 @@ __global__ __launch_bounds__(ADMM_TPB) void admm_take_z_kernel(double *Z, const 
             const double d = Zlast[idx] - zn;
             acc += d * d;
             Z[idx] = zn;
+            if (rhs) accf += ((0.5 * rhs[idx] - rho_m * zn) + q0[j]) * zn;
         }
     red[threadIdx.x] = acc;
+    redf[threadIdx.x] = accf;
     __syncthreads();
     if (threadIdx.x < 16) {
-        double s = 0.0;
-        for (int g = 0; g < ADMM_TPB / 16; g++) s += red[g * 16 + threadIdx.x];
-        if (tile * 16 + threadIdx.x < R) dist2[tile * 16 + threadIdx.x] = s;
+        double s = 0.0, sf = 0.0;
+        for (int g = 0; g < ADMM_TPB / 16; g++) { s += red[g * 16 + threadIdx.x]; sf += redf[g * 16 + threadIdx.x]; }
+        if (tile * 16 + threadIdx.x < R) {
+            dist2[tile * 16 + threadIdx.x] = s;
+            if (rhs && act[tile * 16 + threadIdx.x]) f0[tile * 16 + threadIdx.x] = sf + r0;
+        }
     }
 }
 

@@ -55,9 +55,11 @@ def rho_for(funcs):
     return 50.0 * (2.0 * (1.0 - lmin) / m if lmin < 0 else 1.0 / m)
 
 
-def run_engine(eng_mod, form, bases, rho, X0, iters, unit):
+def run_engine(eng_mod, form, bases, rho, X0, iters, unit, f0_by_product=False):
     lam, Bv, qhat = bases
     e = eng_mod.Engine(form)
+    if f0_by_product:
+        e.L.qcqpmi_debug_profile(e.h, 4 << 4, None)       # debug bit 4: f0(z) of every phase-2 iterate through the product with P0
     assert e.separable
     e.admm_set_basis(lam, Bv, qhat)
     e.admm_unit_bases(unit)
@@ -114,6 +116,25 @@ def test_admm_unit_bases_vs_oracle_and_gemm_path(eng_mod, orc, name, n, R):
             assert dev.max() < 1e-9
         else:
             assert np.median(dev) < 1e-6 and dev.max() < 1e-3
+
+
+def test_admm_objective_of_the_iterates_from_the_solve(eng_mod):
+    """Phase 2 needs f0(z) of every iterate for `better` (qcqp.py:249).  z solves 2 (P0 + rho m I) z = rhs, so
+    P0 z = rhs / 2 - rho m z: the engine takes f0 from the solve's own right-hand side instead of a second n x n product per
+    iteration.  Same iterates, same bookkeeping as with the product (debug bit 4), on a family with a dense P0."""
+    from qcqp_amd.form import QCQPForm
+    for name, n, R, iters in (('bls', 100, 48, 40), ('maxcut', 60, 32, 40)):
+        funcs = family(name, n)
+        form = QCQPForm.from_arrays(funcs)
+        ub = form.unit_bases()
+        rho = rho_for(funcs)
+        X0 = np.random.RandomState(3).randn(n, R)
+        Xa, oa = run_engine(eng_mod, form, ub, rho, X0, iters, True)
+        Xb, ob = run_engine(eng_mod, form, ub, rho, X0, iters, True, f0_by_product=True)
+        d = np.max(np.abs(Xa - Xb), axis=0) / (1 + np.max(np.abs(Xb), axis=0))
+        print('\nf0 of the iterates from the solve vs through P0, %s n=%d: max|dx| %.1e, f0 %.1e' % (name, n, d.max(), rel(oa['f0'], ob['f0'])))
+        assert d.max() < 1e-9 and rel(oa['f0'], ob['f0']) < 1e-9
+        assert np.array_equal(oa['iters1'], ob['iters1']) and np.array_equal(oa['iters2'], ob['iters2'])
 
 
 def test_improve_admm_on_boolean_least_squares_through_the_api(eng_mod, orc):

@@ -1,4 +1,4 @@
 mkdir -p gpurun_out
-for w in 5 20 60; do python bench.py --steps 20 --warmup $w --no-secondary --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('warmup', r['warmup'], 'ms/step', r['ms_per_step'], 'frac', r['roofline']['frac'], 'kernel ms', r['roofline']['kernel_ms_per_launch'])"; done
+timeout 1200 python -m pytest tests/test_gpu_admm_sep.py tests/test_gpu_api.py -x -q -m gpu -s > gpurun_out/t_admm.log 2>&1; grep -E "ADMM unit|f0 of the|passed|failed|Error|^E " gpurun_out/t_admm.log | cut -c1-220
+timeout 900 python -m pytest tests/test_gpu_scale.py -x -q -m gpu -k "admm" > gpurun_out/t_admm2.log 2>&1; tail -3 gpurun_out/t_admm2.log
+BENCH_ONLY=1 timeout 600 python tools/_dbg_bench.py 2>&1 | grep -E '"value"|wall_s|frac"'
