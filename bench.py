@@ -71,7 +71,6 @@ def secondary_records(device, sdr_full=False):
     from qcqp_amd.engine import Engine
     from qcqp_amd.form import QCQPForm
     recs = []
-    only = os.environ.get("BENCH_ONLY")
     # the headline family with 4 tiles per CU: the hardware's workgroup queue refills a CU as soon as its tile of 16 restarts
     # has converged, so the 1-workgroup-per-CU straggler effect of the headline (kernel time = slowest tile) is amortised
     try:

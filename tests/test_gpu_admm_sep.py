@@ -153,6 +153,24 @@ def test_improve_admm_on_boolean_least_squares_through_the_api(eng_mod, orc):
     assert rel(xg, xa) < 1e-6
 
 
+def test_improve_admm_on_maxcut_through_the_api(eng_mod, orc):
+    """MAXCUT (maxcut.py:25-28: maximise, an indefinite objective in minimise form) through QCQP.improve(ADMM): the automatic rho
+    of improve_admm for lambda_min < 0 (qcqp.py:270-277: Lanczos on the device here, LAPACK in the reference), unit bases,
+    20 iterations per phase; the oracle runs the minimise form with the rho the handler chose."""
+    from test_gpu_api import handler
+    from qcqp_amd import ADMM, problems
+    funcs, _, _ = problems.maxcut(30, 0.5, seed=2, weighted=True)
+    q = handler(funcs, maximize=True)
+    x0 = np.random.RandomState(9).randn(30)
+    q.prob.variables()[0].value = x0.reshape(-1, 1)
+    q.improve(ADMM, num_iters=20)
+    assert q.last_stats['setup'] == 'unit bases (separable constraints)'
+    rho = q.last_stats['rho']
+    assert abs(rho - rho_for(funcs)) <= 1e-6 * rho          # Lanczos' lambda_min against LAPACK's
+    xa = orc.Problem(funcs).improve_admm(x0, num_iters=20, rho=rho)
+    assert rel(np.ravel(q.prob.variables()[0].value), xa) < 1e-6
+
+
 def test_admm_unit_bases_full_size_boolean_least_squares(eng_mod):
     """n = 1024, m = 1024 (BASELINE.json configs[1]'s problem), 512 restarts, 30 + 30 iterations: what the reference's setup
     makes of this size is 1024 LAPACK decompositions of 1024 x 1024 matrices and 8.6 GB of eigenvectors; here the bases are a
