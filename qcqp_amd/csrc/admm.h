@@ -58,6 +58,7 @@ struct AdmmArgs {
     double sec_tol;       // 1e-6 (utilities.py:149)
     int zq_planes;        // ZQ arrives as this many split-K partial planes (small kernel only; summed in a fixed order)
     int64_t zq_plane;     // doubles between two planes
+    int no_shortcut;      // 1: every step of the bisection evaluates the secular function (cross-check of the one-row shortcut)
 };
 
 // wave-wide sum on DPP (row_shr prefix sums inside the rows of 16 lanes, row_bcast across them; lanes without
@@ -218,32 +219,48 @@ __global__ __launch_bounds__(256) void admm_secular_small_kernel(AdmmArgs a) {
     // consecutive threads: the 16 restarts of a tile, then the next constraint (coalesced 128-byte rows)
     const int64_t tile = idx / (16 * a.m), rem = idx % (16 * a.m);
     const int64_t k = rem / 16, r = tile * 16 + (rem % 16);
-    if (idx >= ((a.R + 15) / 16) * 16 * a.m || r >= a.R || !a.act[r]) return;
-    const int64_t base = admm_hat_index(a, r, k * RP);
+    const bool valid = idx < ((a.R + 15) / 16) * 16 * a.m && r < a.R && a.act[r];
+    // max violation per restart: with m a multiple of 16 a workgroup is 16 constraints x the 16 restarts of ONE tile -- the maximum
+    // is taken in LDS first and one thread per restart goes to memory (a global atomic per (constraint, restart) pair -- 4 M per
+    // launch at n = m = 1024, 4096 restarts -- WAS the kernel's time: 194 us of which the bisections are a fraction)
+    __shared__ unsigned long long mvs[16];
+    const bool blockred = a.mvbits != nullptr && (a.m % 16) == 0;
+    if (blockred) {
+        if (threadIdx.x < 16) mvs[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
+    const int64_t base = valid ? admm_hat_index(a, r, k * RP) : 0;
     double *zq = a.ZQ + base;
     double *uh = a.UH + base;
-    const double *lm = a.lam + k * RP, *qh = a.qhat + k * RP;
-    const double rk = a.rk[k];
-    const int relop = a.relop[k];
+    const double *lm = a.lam + (valid ? k * RP : 0), *qh = a.qhat + (valid ? k * RP : 0);
+    const double rk = valid ? a.rk[k] : 0.0;
+    const int relop = valid ? a.relop[k] : RELOP_LE;
     double L[RP], Qh[RP], V[RP], Zq[RP], X[RP];
     double fz = 0.0, fv = 0.0;
+    if (valid) {
 #pragma unroll
-    for (int e = 0; e < RP; e++) {
-        L[e] = lm[e]; Qh[e] = qh[e];
-        double zsum = zq[e * 16];
-        for (int z = 1; z < a.zq_planes; z++) zsum += zq[e * 16 + z * a.zq_plane];
-        Zq[e] = zsum;
-        const double u = (!a.first_iter && !a.project_only) ? uh[e * 16] : 0.0;
-        V[e] = Zq[e] + u;
-        fz += L[e] * (Zq[e] * Zq[e]) + Qh[e] * Zq[e];
-        fv += L[e] * (V[e] * V[e]) + Qh[e] * V[e];
+        for (int e = 0; e < RP; e++) {
+            L[e] = lm[e]; Qh[e] = qh[e];
+            double zsum = zq[e * 16];
+            for (int z = 1; z < a.zq_planes; z++) zsum += zq[e * 16 + z * a.zq_plane];
+            Zq[e] = zsum;
+            const double u = (!a.first_iter && !a.project_only) ? uh[e * 16] : 0.0;
+            V[e] = Zq[e] + u;
+            fz += L[e] * (Zq[e] * Zq[e]) + Qh[e] * Zq[e];
+            fv += L[e] * (V[e] * V[e]) + Qh[e] * V[e];
+        }
+        fz += rk; fv += rk;
+        if (a.mvbits) {
+            const double viol = (relop == RELOP_EQ) ? fabs(fz) : (fz > 0.0 ? fz : 0.0);
+            if (blockred) atomicMax(&mvs[threadIdx.x & 15], (unsigned long long)__double_as_longlong(viol));
+            else atomicMax(&a.mvbits[r], (unsigned long long)__double_as_longlong(viol));
+        }
     }
-    fz += rk; fv += rk;
-    if (a.mvbits) {
-        const double viol = (relop == RELOP_EQ) ? fabs(fz) : (fz > 0.0 ? fz : 0.0);
-        atomicMax(&a.mvbits[r], (unsigned long long)__double_as_longlong(viol));
+    if (blockred) {
+        __syncthreads();
+        if (threadIdx.x < 16 && valid && mvs[threadIdx.x] != 0ull) atomicMax(&a.mvbits[r], mvs[threadIdx.x]);
     }
-    if (a.viol_only) return;
+    if (!valid || a.viol_only) return;
     if (relop == RELOP_LE && fv <= 0.0) {
 #pragma unroll
         for (int e = 0; e < RP; e++) X[e] = V[e];
@@ -259,14 +276,52 @@ __global__ __launch_bounds__(256) void admm_secular_small_kernel(AdmmArgs a) {
             }
             return p + rk;
         };
+        // One row (RP == 1: a constraint on ONE coordinate): the secular function is scalar,
+        //   phi(nu) = L x^2 + q x + r,  x = (2 v - nu q) / (2 (1 + nu L)),  phi' = -(2 L x + q)^2 / (2 (1 + nu L)) <= 0 on the bracket,
+        // so its root nu* is known in closed form (x* = the root of the constraint's own quadratic on v's side, nu* = 2 (v - x*) /
+        // (2 L x* + q)) and every comparison the reference's loops make (utilities.py:176-194: the doubling of the bracket, the
+        // bisection to 1e-6) is decided by the SIDE of nu* the trial value lies on -- the same outcome, without evaluating phi --
+        // unless the trial is so close to nu* that rounding could decide (then phi is evaluated like before).  ~25-60 evaluations with
+        // a division each become ~1 per solve: this kernel was 38 % of an ADMM iteration on Boolean least squares at n = 1024.
+        bool fast = false;
+        double nus = 0.0, dphi = 0.0, scale = 0.0;
+        if (RP == 1 && !a.no_shortcut) {
+            const double l = L[0], qh = Qh[0], v = V[0];
+            const double w = qh + 2.0 * l * v;                 // sign of (1 + nu L) (2 L x + q): picks the root on the bracket's branch
+            double xs = 0.0;
+            bool ok = false;
+            if (l != 0.0) {
+                const double disc = qh * qh - 4.0 * l * rk;
+                if (disc > 0.0 && w != 0.0) {
+                    const double sq = sqrt(disc);
+                    xs = (w > 0.0) ? (-qh + sq) / (2.0 * l) : (-qh - sq) / (2.0 * l);
+                    ok = true;
+                }
+            } else if (qh != 0.0) { xs = -rk / qh; ok = true; }
+            if (ok) {
+                const double den = 2.0 * l * xs + qh;
+                nus = 2.0 * (v - xs) / den;
+                const double onel = 1.0 + nus * l;
+                dphi = -(den * den) / (2.0 * onel);
+                scale = fabs(l) * xs * xs + fabs(qh * xs) + fabs(rk);
+                fast = den != 0.0 && onel > 0.0 && nus - nus == 0.0 && dphi - dphi == 0.0;
+            }
+        }
+        auto psign = [&](double nu) {      // the sign of phi(nu) (its value when it has to be evaluated)
+            if (fast) {
+                const double d = nu - nus;
+                if (fabs(d) > 1e-8 * (1.0 + fabs(nus)) && fabs(dphi * d) > 1e-10 * scale) return d < 0.0 ? 1.0 : -1.0;
+            }
+            return phi(nu);
+        };
         double s = a.slo[k], e_ = a.ehi[k];
         int guard = 0;
-        if (s == -QM_INF) { s = -1.0; while (phi(s) <= 0.0 && guard++ < 2000) s *= 2.0; }
-        if (e_ == QM_INF) { e_ = 1.0; while (phi(e_) >= 0.0 && guard++ < 4000) e_ *= 2.0; }
+        if (s == -QM_INF) { s = -1.0; while (psign(s) <= 0.0 && guard++ < 2000) s *= 2.0; }
+        if (e_ == QM_INF) { e_ = 1.0; while (psign(e_) >= 0.0 && guard++ < 4000) e_ *= 2.0; }
         int steps = 0;
         while (e_ - s > a.sec_tol && steps++ < 100000) {
             const double mid = (s + e_) / 2.0;
-            const double p = phi(mid);
+            const double p = psign(mid);
             if (p > 0.0) s = mid;
             else if (p < 0.0) e_ = mid;
             else { s = e_ = mid; break; }

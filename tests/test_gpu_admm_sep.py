@@ -55,11 +55,12 @@ def rho_for(funcs):
     return 50.0 * (2.0 * (1.0 - lmin) / m if lmin < 0 else 1.0 / m)
 
 
-def run_engine(eng_mod, form, bases, rho, X0, iters, unit, f0_by_product=False):
+def run_engine(eng_mod, form, bases, rho, X0, iters, unit, f0_by_product=False, every_step=False):
     lam, Bv, qhat = bases
     e = eng_mod.Engine(form)
-    if f0_by_product:
-        e.L.qcqpmi_debug_profile(e.h, 4 << 4, None)       # debug bit 4: f0(z) of every phase-2 iterate through the product with P0
+    if f0_by_product or every_step:
+        # debug bit 4: f0(z) of every phase-2 iterate through the product with P0; bit 8: every step of the bisection evaluates phi
+        e.L.qcqpmi_debug_profile(e.h, ((4 if f0_by_product else 0) | (8 if every_step else 0)) << 4, None)
     assert e.separable
     e.admm_set_basis(lam, Bv, qhat)
     e.admm_unit_bases(unit)
@@ -135,6 +136,24 @@ def test_admm_objective_of_the_iterates_from_the_solve(eng_mod):
         print('\nf0 of the iterates from the solve vs through P0, %s n=%d: max|dx| %.1e, f0 %.1e' % (name, n, d.max(), rel(oa['f0'], ob['f0'])))
         assert d.max() < 1e-9 and rel(oa['f0'], ob['f0']) < 1e-9
         assert np.array_equal(oa['iters1'], ob['iters1']) and np.array_equal(oa['iters2'], ob['iters2'])
+
+
+@pytest.mark.parametrize('name,n', [('bls', 100), ('box', 64), ('maxcut', 40), ('lin2', 32)])
+def test_admm_one_row_bisection_shortcut_is_the_bisection(eng_mod, name, n):
+    """admm_secular_small_kernel<1> decides the comparisons of onecons_qcqp's loops (utilities.py:176-194) by the side of the
+    closed-form root the trial multiplier lies on and evaluates the secular function only near it.  Same multipliers, same
+    points: the run with the shortcut equals the run that evaluates every step, bit for bit."""
+    from qcqp_amd.form import QCQPForm
+    funcs = family(name, n)
+    form = QCQPForm.from_arrays(funcs)
+    ub = form.unit_bases()
+    rho = rho_for(funcs)
+    X0 = np.random.RandomState(17).randn(n, 64) * 2.0
+    Xa, oa = run_engine(eng_mod, form, ub, rho, X0, 40, True)
+    Xb, ob = run_engine(eng_mod, form, ub, rho, X0, 40, True, every_step=True)
+    assert np.array_equal(Xa, Xb)
+    assert np.array_equal(oa['iters1'], ob['iters1']) and np.array_equal(oa['iters2'], ob['iters2'])
+    assert np.array_equal(oa['f0'], ob['f0'])
 
 
 def test_improve_admm_on_boolean_least_squares_through_the_api(eng_mod, orc):
