@@ -209,7 +209,10 @@ int qcqpmi_admm_run(qcqpmi_ctx *ctx, int phase1, int64_t num_iters, double tol, 
  * per tile of 16 restarts (csrc/admm_fused.hip; a tile may be shared by a cluster of 2..16 workgroups so that few restarts
  * still fill the chip), no host in the loop.  qcqpmi_admm_fused(ctx, 0) selects the multi-launch path everywhere (the
  * cross-check; same iteration, other summation order in the two products); default 1.  qcqpmi_last_admm_kernel names the
- * path the last run took ("admm_fused_kernel" / "admm_multi_launch") and the workgroups per tile it used. */
+ * path the last run took ("admm_fused_kernel" / "admm_multi_launch") and the workgroups per tile it used.
+ * enable == 2 (round 5, experiment kept as a cross-check): the same kernel with FOUR-wave workgroups, two per compute unit,
+ * twice as many workgroups per tile -- the co-resident workgroups belong to different tiles; measured equal to the
+ * eight-wave geometry at 1024 restarts and slower elsewhere, hence not the default. */
 int qcqpmi_admm_fused(qcqpmi_ctx *ctx, int enable);
 
 /* Unit bases (round 5).  When every basis vector handed to qcqpmi_admm_set_basis is +-e_i -- separable constraints

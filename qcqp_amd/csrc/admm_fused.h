@@ -7,7 +7,6 @@
 
 namespace qcqpmi {
 
-constexpr int AF_THREADS = 512;     // 8 waves per workgroup
 constexpr int AF_MAXC = 16;         // workgroups that may share one tile of restarts
 constexpr int AF_MAXRP = 8;         // columns of a reduced basis
 
@@ -28,6 +27,8 @@ struct AdmmFusedArgs {
     double tol, viol_lim, sec_tol;
     // ---- launch geometry
     int C;                          // workgroups per tile: rows of z (blocks of 16) and constraints are split C ways
+    int nt;                         // threads per workgroup: 512 (eight waves, one workgroup per CU: the default) or 256 (four waves,
+                                    // two workgroups of different tiles per CU)
     int G;                          // resident clusters; cluster g walks tiles g, g + G, ...
     // ---- population, tile-major [ntiles][n16][16]: in = x0, out = improve_admm's result
     double *X;

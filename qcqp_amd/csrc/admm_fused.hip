@@ -67,35 +67,47 @@ __device__ inline bool better_first(double f1, double v1, double f2, double v2) 
 // THREE register stages named statically (the loop is unrolled by three groups: no register rotation, hence no wait on a
 // load issued one group ago): while group i multiplies, the operands of group i + 2 are requested.  The scheduling
 // barriers keep the compiler from sinking the requests next to their uses.
-constexpr int AF_MW = 8;      // waves of a workgroup that multiply (4 = one per SIMD with 4 accumulators measured 5 % slower: the stages are bound by the L2 -> CU fragment stream, 512 B per MFMA, not by the issue slots)
-constexpr int AF_NA = 2;      // accumulators (blocks of 16 rows) a multiplying wave carries at once
+constexpr int AF_NA = 3;      // accumulators (blocks of 16 rows) a multiplying wave carries at once
+
+#ifndef AF_NS
+#define AF_NS 3          // register stages of the fragment stream (AF_NS - 1 groups of requests in flight)
+#endif
+#ifdef AF_SAMEFRAG       // experiment (results invalid): every k-step reads the first fragment, i.e. the stream comes from the L1
+#define AF_FRAG(k) 0
+#else
+#define AF_FRAG(k) ((k) * 64)
+#endif
 
 template <int NA>
 __device__ __attribute__((always_inline)) inline void af_stream(af_gcd *const (&A)[AF_NA], const double *Bs, int nks, af_v4d (&acc)[AF_NA]) {
-    constexpr int GS = NA >= 3 ? 2 : 4;          // k-steps per group: 8 MFMAs either way
-    double r[3][NA][GS], rb[3][GS];
+    constexpr int GS = NA >= 3 ? 2 : 4;          // k-steps per group: 8 MFMAs either way (6 for three accumulators)
+    constexpr int NS = AF_NS;
+    double r[NS][NA][GS], rb[NS][GS];
     const int last = nks - GS;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < NS - 1; j++) {
         const int k = GS * j < nks ? GS * j : last;
 #pragma unroll
         for (int u = 0; u < GS; u++) {
 #pragma unroll
-            for (int i = 0; i < NA; i++) r[j][i][u] = A[i][(k + u) * 64];
+            for (int i = 0; i < NA; i++) r[j][i][u] = A[i][AF_FRAG(k + u)];
             rb[j][u] = Bs[(k + u) * 64];
         }
+        // keeps the groups of requests in program order: the compiler issued group 1 BEFORE group 0, its wait-count
+        // bookkeeping then held group 0 to be the youngest at the loop header and made the first group of every pass wait for
+        // ALL requests but its own (s_waitcnt vmcnt(8) instead of vmcnt(16): one group of lead instead of two)
+        __builtin_amdgcn_sched_barrier(0);
     }
-    for (int kk = 0; kk < nks; kk += 3 * GS) {
+    for (int kk = 0; kk < nks; kk += NS * GS) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < NS; j++) {
             const int kg = kk + GS * j;
-            const int k2 = kg + 2 * GS < nks ? kg + 2 * GS : last;     // clamped: requested, never multiplied
-            constexpr int J2[3] = {2, 0, 1};
-            const int s2 = J2[j];
+            const int k2 = kg + (NS - 1) * GS < nks ? kg + (NS - 1) * GS : last;     // clamped: requested, never multiplied
+            const int s2 = (j + NS - 1) % NS;
 #pragma unroll
             for (int u = 0; u < GS; u++) {
 #pragma unroll
-                for (int i = 0; i < NA; i++) r[s2][i][u] = A[i][(k2 + u) * 64];
+                for (int i = 0; i < NA; i++) r[s2][i][u] = A[i][AF_FRAG(k2 + u)];
                 rb[s2][u] = Bs[(k2 + u) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -111,8 +123,7 @@ __device__ __attribute__((always_inline)) inline void af_stream(af_gcd *const (&
 }
 
 __device__ __attribute__((always_inline)) inline void af_stream_n(int na, af_gcd *const (&A)[AF_NA], const double *Bs, int nks, af_v4d (&acc)[AF_NA]) {
-    if (na >= 4) af_stream<4>(A, Bs, nks, acc);
-    else if (na == 3) af_stream<3>(A, Bs, nks, acc);
+    if (na >= 3) af_stream<3>(A, Bs, nks, acc);
     else if (na == 2) af_stream<2>(A, Bs, nks, acc);
     else af_stream<1>(A, Bs, nks, acc);
 }
@@ -196,8 +207,10 @@ enum { AF_EVAL0 = 0, AF_PH1 = 1, AF_EVAL1 = 2, AF_PH2 = 3, AF_DONE = 4 };
 
 // One instance of every stage inside one loop that walks EVAL0 -> PH1 iterations -> EVAL1 -> PH2 iterations (the first
 // version instantiated the stages per call site: 120 KB of code against a 64 KB instruction cache).
-template <int RP>
-__global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a) {
+template <int RP, int NT>
+__global__ __launch_bounds__(NT, 2) void admm_fused_kernel(AdmmFusedArgs a) {
+    constexpr int MW = NT / 64;          // every wave multiplies
+
     extern __shared__ double af_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = af_uni(tid >> 6);
@@ -265,11 +278,11 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
         // ================================================================ set-up of the tile
         if (tid == 0) { S.abort = 0; S.nactive = 0; }
         if (tid < 16) { S.it1[tid] = 0; S.it2[tid] = 0; S.act[tid] = 0; S.pd2[tid] = 0.0; S.pf0[tid] = 0.0; }
-        for (int idx = tid; idx < rows * 16; idx += AF_THREADS) {
+        for (int idx = tid; idx < rows * 16; idx += NT) {
             const int j = row0 + (idx >> 4);
             Zs[idx] = (j < a.n) ? Xt[(int64_t)j * 16 + (idx & 15)] : 0.0;
         }
-        for (int row = tid; row < rows; row += AF_THREADS) {
+        for (int row = tid; row < rows; row += NT) {
             const int j = row0 + row;
             Qs[row] = j < a.n ? a.q0[j] : 0.0; DIs[row] = j < a.n ? a.dinv[j] : 0.0; PDs[row] = j < a.n ? a.pdiag[j] : 0.0;
         }
@@ -285,42 +298,54 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
                 double accd = 0.0, accf = 0.0;
                 const int col = lane & 15;
                 const bool on = S.act[col] != 0;
-                for (int lb0 = wave; wave < AF_MW && lb0 < NBl; lb0 += AF_MW * AF_NA) {
+                for (int lb0 = wave; wave < MW && lb0 < NBl; lb0 += MW * AF_NA) {
                     int na = 0;
                     af_gcd *A[AF_NA];
                     af_v4d acc[AF_NA];
 #pragma unroll
                     for (int i = 0; i < AF_NA; i++) {
-                        const int lb = lb0 + AF_MW * i;
+                        const int lb = lb0 + MW * i;
                         if (lb < NBl) na = i + 1;
                         A[i] = Wp + ((int64_t)(b_lo + (lb < NBl ? lb : lb0)) * KSh) * 64 + lane;
                         acc[i] = af_v4d{0.0, 0.0, 0.0, 0.0};
                     }
+                    const long long ps0 = profiling ? (long long)__builtin_amdgcn_s_memtime() : 0;
                     af_stream_n(na, A, Ds + lane, KSh, acc);
+                    if (profiling) a.prof[10] += (long long)__builtin_amdgcn_s_memtime() - ps0;
+                    // element-wise part, free of branches: the operands of a block's four rows are requested together (the
+                    // version with a `continue` per row ran the rows one LDS round trip after the other: 4.6 k cycles per call)
 #pragma unroll
                     for (int i = 0; i < AF_NA; i++) {
                         if (i >= na) break;
-                        const int lb = lb0 + AF_MW * i;
+                        const int lb = lb0 + MW * i;
+                        double zo[4], qs[4], di[4], pd[4];
 #pragma unroll
                         for (int v = 0; v < 4; v++) {
                             const int row = lb * 16 + (lane >> 4) + 4 * v;
-                            if (!on || row0 + row >= a.n) continue;
-                            const double zold = Zs[row * 16 + col];
-                            double s = acc[i][v];
-                            s += dm * zold;                                      // S = m z + W d  (reduced basis)
+                            zo[v] = Zs[row * 16 + col];
+                            qs[v] = Qs[row]; di[v] = DIs[row]; pd[v] = PDs[row];
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; v++) {
+                            const int row = lb * 16 + (lane >> 4) + 4 * v;
+                            const bool ok = on && row0 + row < a.n;
+                            double sm = acc[i][v];
+                            sm += dm * zo[v];                                    // S = m z + W d  (reduced basis)
+                            double zn;
                             if (!ph2) {
-                                Zs[row * 16 + col] = s / dm;                     // qcqp.py:205
+                                zn = sm / dm;                                    // qcqp.py:205
                             } else {
-                                const double rhs = 2.0 * a.rho * s - Qs[row];    // qcqp.py:231
-                                const double zn = DIs[row] * rhs;
-                                const double d = zold - zn;
-                                accd += d * d;
-                                accf += (PDs[row] * zn + Qs[row]) * zn;
-                                Zs[row * 16 + col] = zn;
+                                const double rhs = 2.0 * a.rho * sm - qs[v];     // qcqp.py:231
+                                zn = di[v] * rhs;
+                                const double d = zo[v] - zn;
+                                accd += ok ? d * d : 0.0;
+                                accf += ok ? (pd[v] * zn + qs[v]) * zn : 0.0;
                             }
+                            if (ok) Zs[row * 16 + col] = zn;
                         }
                     }
                 }
+                if (profiling) a.prof[12] += (long long)__builtin_amdgcn_s_memtime() - pt;     // wave 0: product + element-wise part
                 if (ph2) {
                     accd += __shfl_xor(accd, 16); accd += __shfl_xor(accd, 32);
                     accf += __shfl_xor(accf, 16); accf += __shfl_xor(accf, 32);
@@ -328,7 +353,7 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
                     __syncthreads();
                     if (tid < 16) {
                         double d2 = 0.0, f = 0.0;
-                        for (int w = 0; w < AF_MW; w++) { d2 += S.red[w][0][tid]; f += S.red[w][1][tid]; }
+                        for (int w = 0; w < MW; w++) { d2 += S.red[w][0][tid]; f += S.red[w][1][tid]; }
                         S.pd2[tid] = d2; S.pf0[tid] = f;
                     }
                 }
@@ -337,36 +362,38 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
                 // ---- evaluation of the point in Zs: f0 partial over the own rows, sum (P0_ii z + q0) z (admm_f0_kernel)
                 const int col = tid & 15;
                 double acc = 0.0;
-                for (int row = tid >> 4; row < rows; row += AF_THREADS / 16)
+                for (int row = tid >> 4; row < rows; row += NT / 16)
                     if (row0 + row < a.n) { const double z = Zs[row * 16 + col]; acc += (PDs[row] * z + Qs[row]) * z; }
                 S.scr[tid] = acc;
                 __syncthreads();
                 if (tid < 16) {
                     double s = 0.0;
-                    for (int q = 0; q < AF_THREADS / 16; q++) s += S.scr[q * 16 + tid];
+                    for (int q = 0; q < NT / 16; q++) s += S.scr[q * 16 + tid];
                     S.pf0[tid] = s; S.pd2[tid] = 0.0;
                 }
                 __syncthreads();
             }
             AF_TICK(0)
             // ---- partial ZQ = W[rows, :]^T z[rows] -> this member's slot (hat blocks dealt to the waves, two at a time)
-            for (int mb0 = wave; wave < AF_MW && mb0 < MBh; mb0 += AF_MW * AF_NA) {
+            for (int mb0 = wave; wave < MW && mb0 < MBh; mb0 += MW * AF_NA) {
                 int na = 0;
                 af_gcd *A[AF_NA];
                 af_v4d acc[AF_NA];
 #pragma unroll
                 for (int i = 0; i < AF_NA; i++) {
-                    const int mb = mb0 + AF_MW * i;
+                    const int mb = mb0 + MW * i;
                     if (mb < MBh) na = i + 1;
                     A[i] = WT + ((int64_t)(mb < MBh ? mb : mb0) * KSn + 4 * b_lo) * 64 + lane;
                     acc[i] = af_v4d{0.0, 0.0, 0.0, 0.0};
                 }
+                const long long ps0 = profiling ? (long long)__builtin_amdgcn_s_memtime() : 0;
                 af_stream_n(na, A, Zs + lane, 4 * NBl, acc);
+                if (profiling) a.prof[11] += (long long)__builtin_amdgcn_s_memtime() - ps0;
                 // accumulator layout: register v of lane l = row (l >> 4) + 4 v of the block, column l & 15
 #pragma unroll
                 for (int i = 0; i < AF_NA; i++) {
                     if (i >= na) break;
-                    const int mb = mb0 + AF_MW * i;
+                    const int mb = mb0 + MW * i;
 #pragma unroll
                     for (int v = 0; v < 4; v++) ag_store(xb1me + ((int64_t)(mb * 16 + (lane >> 4) + 4 * v)) * 16 + (lane & 15), acc[i][v]);
                 }
@@ -376,29 +403,35 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
             ++seq;
             AF_EXCHANGE(fl1)
             AF_TICK(2)
-            // ---- sums of the C partials for the own constraints' rows (fixed order), and of the two scalars per restart;
-            // all loads of a thread are issued before the first sum waits (one round trip, not C)
+            // ---- sums of the C partials for the own constraints' rows (fixed order), and of the two scalars per restart (two
+            // more rows of the same pass).  Two items per thread and pass, all 2 C loads of a thread in flight before the first
+            // sum waits: ONE round trip to the exchange buffer for up to 2 NT items (round 5; it was one per NT items plus one
+            // for the scalars: 3 round trips with four-wave workgroups)
             {
                 const int64_t slot = (int64_t)(a.Mh16 + 2) * 16;
-                for (int idx = tid; idx < nh * 16; idx += AF_THREADS) {
-                    const int64_t off = ((int64_t)h_lo + (idx >> 4)) * 16 + (idx & 15);
-                    double pv[AF_MAXC];
+                const int nitem = nh * 16 + 32;
+                for (int i0 = tid; i0 < nitem; i0 += 2 * NT) {
+                    double pv[2][AF_MAXC];
+                    int64_t off[2];
 #pragma unroll
-                    for (int cc = 0; cc < AF_MAXC; cc++) pv[cc] = (cc < C) ? ag_load(xb1 + cc * slot + off) : 0.0;
-                    double s = pv[0];
+                    for (int u = 0; u < 2; u++) {
+                        const int i = i0 + u * NT;
+                        const bool in = i < nitem, sc = i >= nh * 16;
+                        const int j = sc ? i - nh * 16 : i;
+                        off[u] = in ? ((int64_t)(sc ? a.Mh16 : h_lo) + (j >> 4)) * 16 + (j & 15) : 0;
 #pragma unroll
-                    for (int cc = 1; cc < AF_MAXC; cc++) if (cc < C) s += pv[cc];
-                    ZQs[idx] = s;
-                }
-                if (tid < 32) {
-                    const int64_t off = ((int64_t)a.Mh16 + (tid >> 4)) * 16 + (tid & 15);
-                    double pv[AF_MAXC];
+                        for (int cc = 0; cc < AF_MAXC; cc++) pv[u][cc] = (in && cc < C) ? ag_load(xb1 + cc * slot + off[u]) : 0.0;
+                    }
 #pragma unroll
-                    for (int cc = 0; cc < AF_MAXC; cc++) pv[cc] = (cc < C) ? ag_load(xb1 + cc * slot + off) : 0.0;
-                    double s = pv[0];
+                    for (int u = 0; u < 2; u++) {
+                        const int i = i0 + u * NT;
+                        if (i >= nitem) break;
+                        double sum = pv[u][0];
 #pragma unroll
-                    for (int cc = 1; cc < AF_MAXC; cc++) if (cc < C) s += pv[cc];
-                    if (tid >> 4) S.f0z[tid & 15] = s + a.r0; else S.dist2[tid & 15] = s;
+                        for (int cc = 1; cc < AF_MAXC; cc++) if (cc < C) sum += pv[u][cc];
+                        if (i < nh * 16) ZQs[i] = sum;
+                        else { const int j = i - nh * 16; if (j >> 4) S.f0z[j & 15] = sum + a.r0; else S.dist2[j & 15] = sum; }
+                    }
                 }
                 if (tid < 16) S.mvbits[tid] = 0ull;
                 __syncthreads();
@@ -407,7 +440,7 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
             // ---- secular solves of the own (constraint, restart) pairs; operand rows and partial max violations go out
             {
                 const bool first_iter = !iter || t == 0, viol_only = !iter;
-                for (int idx = tid; idx < nk * 16; idx += AF_THREADS) {
+                for (int idx = tid; idx < nk * 16; idx += NT) {
                     const int kl = idx >> 4, r = idx & 15;
                     if (!viol_only && !S.act[r]) continue;
                     const double *zq = ZQs + (size_t)kl * RP * 16 + r;
@@ -421,24 +454,32 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
             AF_TICK(4)
             AF_EXCHANGE(fl2)
             AF_TICK(5)
-            // ---- all operand rows into LDS (iterations only), max violation per restart
+            // ---- all operand rows into LDS (iterations only) and the members' partial max violations: every load of a thread
+            // in flight at once (GU per pass: one round trip for Mh16 <= GU NT / 16 rows; it was four loads per pass)
             {
+                constexpr int GU = NT == 256 ? 10 : 6;
                 if (tid == 0) S.nactive = 0;
-                if (iter) {
-                    for (int idx0 = 0; idx0 < a.Mh16 * 16; idx0 += 4 * AF_THREADS) {     // four loads in flight per thread
-                        double pv[4];
+                const int nd = iter ? a.Mh16 * 16 : 0, ng = nd + C * 16;
+                for (int idx0 = 0; idx0 < ng; idx0 += GU * NT) {
+                    double pv[GU];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) { const int idx = idx0 + u * AF_THREADS + tid; pv[u] = (idx < a.Mh16 * 16) ? ag_load(xb2 + idx) : 0.0; }
+                    for (int u = 0; u < GU; u++) {
+                        const int idx = idx0 + u * NT + tid;
+                        pv[u] = (idx < ng) ? ag_load(xb2 + (idx < nd ? idx : a.Mh16 * 16 + (idx - nd))) : 0.0;
+                    }
 #pragma unroll
-                        for (int u = 0; u < 4; u++) { const int idx = idx0 + u * AF_THREADS + tid; if (idx < a.Mh16 * 16) Ds[idx] = pv[u]; }
+                    for (int u = 0; u < GU; u++) {
+                        const int idx = idx0 + u * NT + tid;
+                        if (idx < nd) Ds[idx] = pv[u];
+                        else if (idx < ng) S.scr[idx - nd] = pv[u];
                     }
                 }
-                if (tid < 16) {
-                    double mv = ag_load(xb2 + ((int64_t)a.Mh16) * 16 + tid);
-                    for (int cc = 1; cc < C; cc++) { const double w = ag_load(xb2 + ((int64_t)a.Mh16 + cc) * 16 + tid); mv = w > mv ? w : mv; }
-                    S.mvv[tid] = mv;
-                }
                 __syncthreads();
+                if (tid < 16) {
+                    double mv = S.scr[tid];
+                    for (int cc = 1; cc < C; cc++) { const double w = S.scr[cc * 16 + tid]; mv = w > mv ? w : mv; }
+                    S.mvv[tid] = mv;               // read below by the same thread
+                }
             }
             AF_TICK(6)
             int next = st;
@@ -467,7 +508,7 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
                 if (ph2) {
                     const int col = tid & 15;
                     if (S.take[col])
-                        for (int row = tid >> 4; row < rows; row += AF_THREADS / 16) Bt[(int64_t)(row0 + row) * 16 + col] = Zs[row * 16 + col];
+                        for (int row = tid >> 4; row < rows; row += NT / 16) Bt[(int64_t)(row0 + row) * 16 + col] = Zs[row * 16 + col];
                 }
                 t++;
                 if (profiling) a.prof[9]++;
@@ -486,7 +527,7 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
                     }
                     __syncthreads();
                     const int col = tid & 15;
-                    for (int row = tid >> 4; row < rows; row += AF_THREADS / 16) {
+                    for (int row = tid >> 4; row < rows; row += NT / 16) {
                         const int64_t gi = (int64_t)(row0 + row) * 16 + col;
                         if (S.take[col]) Zs[row * 16 + col] = (row0 + row < a.n) ? Xt[gi] : 0.0;     // x0 stays
                         else Xt[gi] = Zs[row * 16 + col];                                           // X now holds x1
@@ -497,10 +538,10 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
             }
             if (next != st && (next == AF_PH1 || next == AF_PH2)) {
                 // ---- start of a phase: xs = x0, us = 0 (S = m x0: no operand rows yet); phase 2 starts with bestx = x1
-                for (int idx = tid; idx < a.Mh16 * 16; idx += AF_THREADS) Ds[idx] = 0.0;
+                for (int idx = tid; idx < a.Mh16 * 16; idx += NT) Ds[idx] = 0.0;
                 if (tid < 16) { S.act[tid] = (tile * 16 + tid < a.R) ? 1 : 0; S.pd2[tid] = 0.0; S.pf0[tid] = 0.0; }
                 if (next == AF_PH2) {
-                    for (int idx = tid; idx < rows * 16; idx += AF_THREADS) Bt[(int64_t)row0 * 16 + idx] = Zs[idx];
+                    for (int idx = tid; idx < rows * 16; idx += NT) Bt[(int64_t)row0 * 16 + idx] = Zs[idx];
                     if (tid < 16) { S.best_f0[tid] = S.fx1[tid]; S.best_mv[tid] = S.vx1[tid]; }
                     if (a.num_iters <= 0) next = AF_DONE;
                 }
@@ -526,7 +567,7 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
         {
             const int col = tid & 15;
             if (!S.take[col])
-                for (int row = tid >> 4; row < rows; row += AF_THREADS / 16) {
+                for (int row = tid >> 4; row < rows; row += NT / 16) {
                     const int64_t gi = (int64_t)(row0 + row) * 16 + col;
                     Xt[gi] = Bt[gi];
                 }
@@ -538,19 +579,21 @@ __global__ __launch_bounds__(AF_THREADS) void admm_fused_kernel(AdmmFusedArgs a)
 }
 
 typedef void (*af_kernel_t)(AdmmFusedArgs);
-af_kernel_t af_kernel_for(int rp) {
+template <int NT>
+af_kernel_t af_kernel_nt(int rp) {
     switch (rp) {
-    case 1: return admm_fused_kernel<1>;
-    case 2: return admm_fused_kernel<2>;
-    case 3: return admm_fused_kernel<3>;
-    case 4: return admm_fused_kernel<4>;
-    case 5: return admm_fused_kernel<5>;
-    case 6: return admm_fused_kernel<6>;
-    case 7: return admm_fused_kernel<7>;
-    case 8: return admm_fused_kernel<8>;
+    case 1: return admm_fused_kernel<1, NT>;
+    case 2: return admm_fused_kernel<2, NT>;
+    case 3: return admm_fused_kernel<3, NT>;
+    case 4: return admm_fused_kernel<4, NT>;
+    case 5: return admm_fused_kernel<5, NT>;
+    case 6: return admm_fused_kernel<6, NT>;
+    case 7: return admm_fused_kernel<7, NT>;
+    case 8: return admm_fused_kernel<8, NT>;
     }
     return nullptr;
 }
+af_kernel_t af_kernel_for(int rp, int nt) { return nt == 256 ? af_kernel_nt<256>(rp) : nt == 512 ? af_kernel_nt<512>(rp) : nullptr; }
 
 }  // namespace
 
@@ -564,10 +607,10 @@ size_t admm_fused_lds_bytes(const AdmmFusedArgs &a) {
 
 int admm_fused_max_clusters(const AdmmFusedArgs &a, int device) {
     const size_t lds = admm_fused_lds_bytes(a);
-    if (!lds || !af_kernel_for(a.rp)) return 0;
-    (void)hipFuncSetAttribute((const void *)af_kernel_for(a.rp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!lds || !af_kernel_for(a.rp, a.nt)) return 0;
+    (void)hipFuncSetAttribute((const void *)af_kernel_for(a.rp, a.nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, af_kernel_for(a.rp), AF_THREADS, lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, af_kernel_for(a.rp, a.nt), a.nt, lds) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
     const int blocks = per_cu * cus;
     // block index = x + 8 (c + C y): clusters come in groups of 8
@@ -577,13 +620,13 @@ int admm_fused_max_clusters(const AdmmFusedArgs &a, int device) {
 
 int admm_fused_launch(const AdmmFusedArgs &a, hipStream_t st) {
     const size_t lds = admm_fused_lds_bytes(a);
-    if (!lds || !af_kernel_for(a.rp)) return (int)hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void *)af_kernel_for(a.rp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!lds || !af_kernel_for(a.rp, a.nt)) return (int)hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void *)af_kernel_for(a.rp, a.nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int groups = (a.G + 7) / 8;
     AdmmFusedArgs args = a;
     void *params[] = {&args};
-    e = hipLaunchCooperativeKernel((const void *)af_kernel_for(a.rp), dim3((unsigned)(8 * a.C * groups)), dim3(AF_THREADS), params, (unsigned)lds, st);
+    e = hipLaunchCooperativeKernel((const void *)af_kernel_for(a.rp, a.nt), dim3((unsigned)(8 * a.C * groups)), dim3((unsigned)a.nt), params, (unsigned)lds, st);
     return (int)e;
 }
 

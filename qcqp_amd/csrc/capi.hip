@@ -176,6 +176,7 @@ struct qcqpmi_ctx {
     char *af_work = nullptr;
     size_t af_work_cap = 0;
     bool ad_fused = true;                 // qcqpmi_admm_fused: use the fused kernel where it applies
+    int ad_fused_nt = 512;                // threads per workgroup of the fused kernel (256: qcqpmi_admm_fused(ctx, 2))
     const char *last_admm_kernel = "";    // "admm_fused_kernel" / "admm_multi_launch"
     int last_admm_C = 0;                  // workgroups per tile of the last fused run
     long long af_prof[16] = {0};          // stage cycle counters of the last fused run (when qcqpmi_debug_profile enabled them)

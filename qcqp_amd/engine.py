@@ -308,8 +308,9 @@ class Engine(object):
         return out
 
     def admm_fused(self, enable=True):
-        """Fused persistent ADMM kernel on / off (off = the multi-launch path everywhere: the cross-check)."""
-        self._chk(self.L.qcqpmi_admm_fused(self.h, 1 if enable else 0))
+        """Fused persistent ADMM kernel on / off (off = the multi-launch path everywhere: the cross-check); 2 = the fused kernel
+        with four-wave workgroups, two per compute unit (an experiment kept as a second cross-check)."""
+        self._chk(self.L.qcqpmi_admm_fused(self.h, 2 if enable == 2 else (1 if enable else 0)))
 
     def admm_unit_bases(self, enable=True):
         """Bases of unit vectors (separable constraints): gather / scatter instead of the two consensus GEMMs of an ADMM iteration

@@ -758,7 +758,7 @@ def test_admm_fused_kernel_vs_multi_launch(eng_mod, orc, nant, mh, ml, R, iters)
     e.admm_set_bracket(*eng_mod.Engine.reference_bracket(lm))
     X0 = np.random.RandomState(7).randn(n, R)
     res = []
-    for fused in (True, False):
+    for fused in (True, False, 2):        # 2: the fused kernel with four-wave workgroups, two per compute unit (round 5)
         e.admm_fused(fused)
         e.upload(X0)
         out = e.admm_run(rho, None, phase1=True, num_iters=iters)
@@ -767,7 +767,12 @@ def test_admm_fused_kernel_vs_multi_launch(eng_mod, orc, nant, mh, ml, R, iters)
         res.append((e.download(), out, cw))
         f0, mv = e.eval()
         assert rel(out['f0'], f0) < 1e-9 and np.max(np.abs(out['maxviol'] - mv)) < 1e-9
-    (Xf, of, cw), (Xm, om, _) = res
+    e.admm_fused(True)
+    (Xf, of, cw), (Xm, om, _), (X4, o4, cw4) = res
+    d4 = np.max(np.abs(X4 - Xm), axis=0) / (1 + np.max(np.abs(Xm), axis=0))
+    print('\nfour-wave workgroups (clusters of %d) vs multi-launch: max|dx| median %.2e max %.2e' % (cw4, np.median(d4), d4.max()))
+    assert np.median(d4) < 1e-9 and d4.max() < 1e-6 and rel(o4['f0'], om['f0']) < 1e-6
+    assert np.mean((o4['iters1'] == om['iters1']) & (o4['iters2'] == om['iters2'])) > 0.97
     d = np.max(np.abs(Xf - Xm), axis=0) / (1 + np.max(np.abs(Xm), axis=0))
     same_it = np.mean((of['iters1'] == om['iters1']) & (of['iters2'] == om['iters2']))
     print('\nADMM fused (clusters of %d) vs multi-launch, n=%d m=%d R=%d: max|dx| median %.2e max %.2e; identical iteration counts '

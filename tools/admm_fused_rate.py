@@ -17,7 +17,7 @@ e.admm_set_basis(lam, Bv, qhat)
 print('n=%d m=%d rp=%d R=%d num_iters=%d' % (form.n, form.m, info['rp'], R, iters))
 import ctypes as C
 prof = '--prof' in sys.argv
-for fused in (True, False, True):
+for fused in (True, False, 2):
     e.admm_fused(fused)
     e.L.qcqpmi_debug_profile(e.h, 1 if (prof and fused) else 0, None)
     for rep in range(2):
@@ -37,5 +37,7 @@ for fused in (True, False, True):
         nit = max(1, int(pr[9]))
         names = ['z-update', 'partial product', 'exchange 1', 'sums', 'secular', 'exchange 2', 'gather', 'book', 'loop top']
         tot = float(pr[:9].sum())
-        print('   per iteration (s_memtime ticks), %d iterations, total %.0f ticks = %.2f us (timer): ' % (nit, tot / nit, kms * 1e3 / nit)
+        print('   per iteration of tile 0 (s_memtime cycles), %d iterations, total %.0f cycles (launch / longest chain: %.2f us per iteration): ' % (nit, tot / nit, kms * 1e3 / max(1, int(out['iters1'].max() + out['iters2'].max())))
               + ', '.join('%s %.0f (%.0f%%)' % (nm, pr[k] / nit, 100 * pr[k] / tot) for k, nm in enumerate(names)))
+        print('   wave 0 alone: fragment stream of the z-update %.0f, z-update until its element-wise part is done %.0f, fragment stream of the partial product %.0f cycles'
+              % (pr[10] / nit, pr[12] / nit, pr[11] / nit))
