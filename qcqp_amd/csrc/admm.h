@@ -212,55 +212,11 @@ __global__ __launch_bounds__(256) void admm_secular_kernel(AdmmArgs a) {
     }
 }
 
-// The same for a reduced basis of RP <= 8 coordinates: one THREAD per (constraint, restart).
+// The projection itself (utilities.py:165-196) on the RP coordinates of a reduced basis for one (constraint, restart) pair: v -> x.
+// Shared by admm_secular_small_kernel and admm_unit_step_kernel: same expressions, same bits.
 template <int RP>
-__global__ __launch_bounds__(256) void admm_secular_small_kernel(AdmmArgs a) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // consecutive threads: the 16 restarts of a tile, then the next constraint (coalesced 128-byte rows)
-    const int64_t tile = idx / (16 * a.m), rem = idx % (16 * a.m);
-    const int64_t k = rem / 16, r = tile * 16 + (rem % 16);
-    const bool valid = idx < ((a.R + 15) / 16) * 16 * a.m && r < a.R && a.act[r];
-    // max violation per restart: with m a multiple of 16 a workgroup is 16 constraints x the 16 restarts of ONE tile -- the maximum
-    // is taken in LDS first and one thread per restart goes to memory (a global atomic per (constraint, restart) pair -- 4 M per
-    // launch at n = m = 1024, 4096 restarts -- WAS the kernel's time: 194 us of which the bisections are a fraction)
-    __shared__ unsigned long long mvs[16];
-    const bool blockred = a.mvbits != nullptr && (a.m % 16) == 0;
-    if (blockred) {
-        if (threadIdx.x < 16) mvs[threadIdx.x] = 0ull;
-        __syncthreads();
-    }
-    const int64_t base = valid ? admm_hat_index(a, r, k * RP) : 0;
-    double *zq = a.ZQ + base;
-    double *uh = a.UH + base;
-    const double *lm = a.lam + (valid ? k * RP : 0), *qh = a.qhat + (valid ? k * RP : 0);
-    const double rk = valid ? a.rk[k] : 0.0;
-    const int relop = valid ? a.relop[k] : RELOP_LE;
-    double L[RP], Qh[RP], V[RP], Zq[RP], X[RP];
-    double fz = 0.0, fv = 0.0;
-    if (valid) {
-#pragma unroll
-        for (int e = 0; e < RP; e++) {
-            L[e] = lm[e]; Qh[e] = qh[e];
-            double zsum = zq[e * 16];
-            for (int z = 1; z < a.zq_planes; z++) zsum += zq[e * 16 + z * a.zq_plane];
-            Zq[e] = zsum;
-            const double u = (!a.first_iter && !a.project_only) ? uh[e * 16] : 0.0;
-            V[e] = Zq[e] + u;
-            fz += L[e] * (Zq[e] * Zq[e]) + Qh[e] * Zq[e];
-            fv += L[e] * (V[e] * V[e]) + Qh[e] * V[e];
-        }
-        fz += rk; fv += rk;
-        if (a.mvbits) {
-            const double viol = (relop == RELOP_EQ) ? fabs(fz) : (fz > 0.0 ? fz : 0.0);
-            if (blockred) atomicMax(&mvs[threadIdx.x & 15], (unsigned long long)__double_as_longlong(viol));
-            else atomicMax(&a.mvbits[r], (unsigned long long)__double_as_longlong(viol));
-        }
-    }
-    if (blockred) {
-        __syncthreads();
-        if (threadIdx.x < 16 && valid && mvs[threadIdx.x] != 0ull) atomicMax(&a.mvbits[r], mvs[threadIdx.x]);
-    }
-    if (!valid || a.viol_only) return;
+__device__ __attribute__((always_inline)) inline void admm_small_solve(const AdmmArgs &a, int64_t k, const double (&L)[RP], const double (&Qh)[RP],
+                                                                       const double (&V)[RP], double rk, int relop, double fv, double (&X)[RP]) {
     if (relop == RELOP_LE && fv <= 0.0) {
 #pragma unroll
         for (int e = 0; e < RP; e++) X[e] = V[e];
@@ -328,12 +284,107 @@ __global__ __launch_bounds__(256) void admm_secular_small_kernel(AdmmArgs a) {
         }
         (void)phi((s + e_) / 2.0);
     }
+}
+
+// The same for a reduced basis of RP <= 8 coordinates: one THREAD per (constraint, restart).
+template <int RP>
+__global__ __launch_bounds__(256) void admm_secular_small_kernel(AdmmArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // consecutive threads: the 16 restarts of a tile, then the next constraint (coalesced 128-byte rows)
+    const int64_t tile = idx / (16 * a.m), rem = idx % (16 * a.m);
+    const int64_t k = rem / 16, r = tile * 16 + (rem % 16);
+    const bool valid = idx < ((a.R + 15) / 16) * 16 * a.m && r < a.R && a.act[r];
+    // max violation per restart: with m a multiple of 16 a workgroup is 16 constraints x the 16 restarts of ONE tile -- the maximum
+    // is taken in LDS first and one thread per restart goes to memory (a global atomic per (constraint, restart) pair -- 4 M per
+    // launch at n = m = 1024, 4096 restarts -- WAS the kernel's time: 194 us of which the bisections are a fraction)
+    __shared__ unsigned long long mvs[16];
+    const bool blockred = a.mvbits != nullptr && (a.m % 16) == 0;
+    if (blockred) {
+        if (threadIdx.x < 16) mvs[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
+    const int64_t base = valid ? admm_hat_index(a, r, k * RP) : 0;
+    double *zq = a.ZQ + base;
+    double *uh = a.UH + base;
+    const double *lm = a.lam + (valid ? k * RP : 0), *qh = a.qhat + (valid ? k * RP : 0);
+    const double rk = valid ? a.rk[k] : 0.0;
+    const int relop = valid ? a.relop[k] : RELOP_LE;
+    double L[RP], Qh[RP], V[RP], Zq[RP], X[RP];
+    double fz = 0.0, fv = 0.0;
+    if (valid) {
+#pragma unroll
+        for (int e = 0; e < RP; e++) {
+            L[e] = lm[e]; Qh[e] = qh[e];
+            double zsum = zq[e * 16];
+            for (int z = 1; z < a.zq_planes; z++) zsum += zq[e * 16 + z * a.zq_plane];
+            Zq[e] = zsum;
+            const double u = (!a.first_iter && !a.project_only) ? uh[e * 16] : 0.0;
+            V[e] = Zq[e] + u;
+            fz += L[e] * (Zq[e] * Zq[e]) + Qh[e] * Zq[e];
+            fv += L[e] * (V[e] * V[e]) + Qh[e] * V[e];
+        }
+        fz += rk; fv += rk;
+        if (a.mvbits) {
+            const double viol = (relop == RELOP_EQ) ? fabs(fz) : (fz > 0.0 ? fz : 0.0);
+            if (blockred) atomicMax(&mvs[threadIdx.x & 15], (unsigned long long)__double_as_longlong(viol));
+            else atomicMax(&a.mvbits[r], (unsigned long long)__double_as_longlong(viol));
+        }
+    }
+    if (blockred) {
+        __syncthreads();
+        if (threadIdx.x < 16 && valid && mvs[threadIdx.x] != 0ull) atomicMax(&a.mvbits[r], mvs[threadIdx.x]);
+    }
+    if (!valid || a.viol_only) return;
+    admm_small_solve<RP>(a, k, L, Qh, V, rk, relop, fv, X);
 #pragma unroll
     for (int e = 0; e < RP; e++) {
         if (a.project_only) { zq[e * 16] = X[e]; continue; }
         uh[e * 16] = V[e] - X[e];
         zq[e * 16] = 2.0 * X[e] - V[e] - Zq[e];
     }
+}
+
+// Unit bases with one row per constraint (separable constraints: p x_i^2 + q x_i + r ~ 0), round 5: gather, projection and
+// scatter of one ADMM iteration in ONE pass -- a thread per (coordinate i, restart): for every constraint h on the coordinate
+//     zq = s_h Z[i]  (admm_unit_gather_kernel),  the pair (h, restart) of admm_secular_small_kernel<1>,  S[i] += s_h d_h  (admm_unit_scatter_kernel)
+// with the same expressions in the same order, so the three-kernel path (debug bit 2) gives the same bits.  Z and the duals are read
+// once, the operand rows never go to memory: 140 us of launches per iteration at n = m = 1024, 4096 restarts become one.
+__global__ __launch_bounds__(256) void admm_unit_step_kernel(AdmmArgs a, const double *__restrict__ Z, double *__restrict__ S, const int *__restrict__ uptr,
+                                                             const int *__restrict__ ulist, const double *__restrict__ usgn, int64_t n16, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // element (tile, coordinate, column): a workgroup = 16 coordinates of ONE tile
+    __shared__ unsigned long long mvs[16];
+    if (threadIdx.x < 16) mvs[threadIdx.x] = 0ull;
+    __syncthreads();
+    const int64_t col = e & 15, i = (e >> 4) % n16, t = (e >> 4) / n16, r = t * 16 + col;
+    const bool valid = e < total && r < a.R && a.act[r];
+    double acc = 0.0;
+    if (valid) {
+        const double z = Z[e];
+        for (int q = uptr[i]; q < uptr[i + 1]; q++) {
+            const int64_t h = ulist[q];                  // hat row = constraint (one row per constraint)
+            const double sg = usgn[h];
+            double *uh = a.UH + admm_hat_index(a, r, h);
+            double L[1], Qh[1], V[1], Zq[1], X[1];
+            L[0] = a.lam[h]; Qh[0] = a.qhat[h];
+            const double rk = a.rk[h];
+            const int relop = a.relop[h];
+            Zq[0] = sg * z;
+            const double u = a.first_iter ? 0.0 : uh[0];
+            V[0] = Zq[0] + u;
+            double fz = 0.0, fv = 0.0;
+            fz += L[0] * (Zq[0] * Zq[0]) + Qh[0] * Zq[0];
+            fv += L[0] * (V[0] * V[0]) + Qh[0] * V[0];
+            fz += rk; fv += rk;
+            const double viol = (relop == RELOP_EQ) ? fabs(fz) : (fz > 0.0 ? fz : 0.0);
+            atomicMax(&mvs[threadIdx.x & 15], (unsigned long long)__double_as_longlong(viol));
+            admm_small_solve<1>(a, h, L, Qh, V, rk, relop, fv, X);
+            uh[0] = V[0] - X[0];
+            acc += sg * (2.0 * X[0] - V[0] - Zq[0]);
+        }
+    }
+    if (e < total) S[e] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16 && valid && mvs[threadIdx.x] != 0ull) atomicMax(&a.mvbits[r], mvs[threadIdx.x]);
 }
 
 // ---- per-tile kernels on the tile-major n x R arrays: 256 threads = 16 restarts x 16 row lanes ----------------------

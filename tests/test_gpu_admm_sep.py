@@ -55,12 +55,13 @@ def rho_for(funcs):
     return 50.0 * (2.0 * (1.0 - lmin) / m if lmin < 0 else 1.0 / m)
 
 
-def run_engine(eng_mod, form, bases, rho, X0, iters, unit, f0_by_product=False, every_step=False):
+def run_engine(eng_mod, form, bases, rho, X0, iters, unit, f0_by_product=False, every_step=False, three_launches=False):
     lam, Bv, qhat = bases
     e = eng_mod.Engine(form)
-    if f0_by_product or every_step:
-        # debug bit 4: f0(z) of every phase-2 iterate through the product with P0; bit 8: every step of the bisection evaluates phi
-        e.L.qcqpmi_debug_profile(e.h, ((4 if f0_by_product else 0) | (8 if every_step else 0)) << 4, None)
+    if f0_by_product or every_step or three_launches:
+        # debug bit 4: f0(z) of every phase-2 iterate through the product with P0; bit 8: every step of the bisection evaluates phi;
+        # bit 2: gather, projection and scatter of an iteration as three launches instead of admm_unit_step_kernel
+        e.L.qcqpmi_debug_profile(e.h, ((4 if f0_by_product else 0) | (8 if every_step else 0) | (2 if three_launches else 0)) << 4, None)
     assert e.separable
     e.admm_set_basis(lam, Bv, qhat)
     e.admm_unit_bases(unit)
@@ -136,6 +137,25 @@ def test_admm_objective_of_the_iterates_from_the_solve(eng_mod):
         print('\nf0 of the iterates from the solve vs through P0, %s n=%d: max|dx| %.1e, f0 %.1e' % (name, n, d.max(), rel(oa['f0'], ob['f0'])))
         assert d.max() < 1e-9 and rel(oa['f0'], ob['f0']) < 1e-9
         assert np.array_equal(oa['iters1'], ob['iters1']) and np.array_equal(oa['iters2'], ob['iters2'])
+
+
+@pytest.mark.parametrize('name,n', [('bls', 100), ('box', 64), ('maxcut', 40), ('lin2', 32)])
+def test_admm_unit_step_kernel_is_the_three_launches(eng_mod, name, n):
+    """admm_unit_step_kernel (round 5): ZQ = s Z[i] (gather), the projection of every (constraint, restart) pair
+    (onecons_qcqp, utilities.py:149-196) and S[i] = sum s D (scatter) of one ADMM iteration in one launch, a thread per
+    (coordinate, restart) -- against the three launches it replaces: the same points, objectives, violations and
+    iteration counts, bit for bit (65 restarts: a partial tile; `lin2`: two constraints on every coordinate)."""
+    from qcqp_amd.form import QCQPForm
+    funcs = family(name, n)
+    form = QCQPForm.from_arrays(funcs)
+    ub = form.unit_bases()
+    rho = rho_for(funcs)
+    X0 = np.random.RandomState(23).randn(n, 65) * 2.0
+    Xa, oa = run_engine(eng_mod, form, ub, rho, X0, 40, True)
+    Xb, ob = run_engine(eng_mod, form, ub, rho, X0, 40, True, three_launches=True)
+    assert np.array_equal(Xa, Xb)
+    assert np.array_equal(oa['iters1'], ob['iters1']) and np.array_equal(oa['iters2'], ob['iters2'])
+    assert np.array_equal(oa['f0'], ob['f0']) and np.array_equal(oa['maxviol'], ob['maxviol'])
 
 
 @pytest.mark.parametrize('name,n', [('bls', 100), ('box', 64), ('maxcut', 40), ('lin2', 32)])
