@@ -349,8 +349,13 @@ __global__ __launch_bounds__(256) void admm_secular_small_kernel(AdmmArgs a) {
 //     zq = s_h Z[i]  (admm_unit_gather_kernel),  the pair (h, restart) of admm_secular_small_kernel<1>,  S[i] += s_h d_h  (admm_unit_scatter_kernel)
 // with the same expressions in the same order, so the three-kernel path (debug bit 2) gives the same bits.  Z and the duals are read
 // once, the operand rows never go to memory: 140 us of launches per iteration at n = m = 1024, 4096 restarts become one.
-__global__ __launch_bounds__(256) void admm_unit_step_kernel(AdmmArgs a, const double *__restrict__ Z, double *__restrict__ S, const int *__restrict__ uptr,
-                                                             const int *__restrict__ ulist, const double *__restrict__ usgn, int64_t n16, int64_t total) {
+// zmode 1 (phase 1): the z-update of the iteration in front -- z = (S + m z) / m (admm_zupdate_kernel, qcqp.py:205) from the sum this
+// thread wrote in the previous iteration, written to Z before it is used; zmode 2 (phase 2, dense solve): the right-hand side of the NEXT
+// iteration's solve behind -- Y = 2 rho (S + m z) - q0 (qcqp.py:231) -- instead of S; zmode 0: S only.  Either way the z-update launch
+// and its pass over Z and S are gone; the values are those of admm_zupdate_kernel (same expressions).
+__global__ __launch_bounds__(256) void admm_unit_step_kernel(AdmmArgs a, double *Z, double *S, const int *__restrict__ uptr,
+                                                             const int *__restrict__ ulist, const double *__restrict__ usgn, int64_t n16, int64_t total,
+                                                             int zmode, int add_mz, double mm, double rho, const double *__restrict__ q0, double *Y, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // element (tile, coordinate, column): a workgroup = 16 coordinates of ONE tile
     __shared__ unsigned long long mvs[16];
     if (threadIdx.x < 16) mvs[threadIdx.x] = 0ull;
@@ -359,7 +364,13 @@ __global__ __launch_bounds__(256) void admm_unit_step_kernel(AdmmArgs a, const d
     const bool valid = e < total && r < a.R && a.act[r];
     double acc = 0.0;
     if (valid) {
-        const double z = Z[e];
+        double z = Z[e];
+        if (zmode == 1 && i < n) {
+            double sm = S[e];
+            if (add_mz) sm += mm * z;
+            z = sm / mm;                                 // qcqp.py:205
+            Z[e] = z;
+        }
         for (int q = uptr[i]; q < uptr[i + 1]; q++) {
             const int64_t h = ulist[q];                  // hat row = constraint (one row per constraint)
             const double sg = usgn[h];
@@ -381,8 +392,13 @@ __global__ __launch_bounds__(256) void admm_unit_step_kernel(AdmmArgs a, const d
             uh[0] = V[0] - X[0];
             acc += sg * (2.0 * X[0] - V[0] - Zq[0]);
         }
+        if (zmode == 2 && i < n) {
+            double sm = acc;
+            if (add_mz) sm += mm * z;
+            Y[e] = 2.0 * rho * sm - q0[i];               // qcqp.py:231
+        }
     }
-    if (e < total) S[e] = acc;
+    if (e < total && zmode != 2) S[e] = acc;
     __syncthreads();
     if (threadIdx.x < 16 && valid && mvs[threadIdx.x] != 0ull) atomicMax(&a.mvbits[r], mvs[threadIdx.x]);
 }
@@ -412,7 +428,6 @@ struct AdmmZArgs {
     int add_mz;           // reduced basis: S = m z + W D
     double m, rho;
     const double *Sp;     // [zs][tile][n16][16]
-    double *S;            // summed S (kept: phase switches reuse it)
     double *Z;            // current z (updated in place for active restarts when the solve is diagonal / phase 1)
     double *Y;            // phase 2, dense solve: rhs
     const double *q0;     // [n16]
@@ -439,7 +454,6 @@ __global__ __launch_bounds__(ADMM_TPB) void admm_zupdate_kernel(AdmmZArgs a) {
         double s = a.Sp[idx];
         for (int z = 1; z < a.zs; z++) s += a.Sp[(int64_t)z * a.plane + idx];
         if (a.add_mz) s += a.m * a.Z[idx];
-        a.S[idx] = s;
         if (!on || j >= a.n) continue;
         if (a.phase == 1) {
             a.Z[idx] = s / a.m;                              // qcqp.py:205
