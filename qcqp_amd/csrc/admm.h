@@ -558,7 +558,7 @@ struct AdmmBook {
     const double *Z;
     double *Zlast, *BEST;
     const double *dist2, *f0z;
-    const unsigned long long *mvbits;
+    unsigned long long *mvbits;
     double *best_f0, *best_mv;
     uint8_t *act;
     int64_t *iters;
@@ -592,6 +592,7 @@ __global__ __launch_bounds__(ADMM_TPB) void admm_book_kernel(AdmmBook b) {
             else { b.iters[r]++; atomicAdd(b.nactive, 1); }
             lv = 1;
         }
+        if (r < b.R) b.mvbits[r] = 0ull;      // read: the next iteration's projections start from zero (no fill launch per iteration)
         take[threadIdx.x] = tk; live[threadIdx.x] = lv;
     }
     __syncthreads();
