@@ -259,12 +259,12 @@ def secondary_records(device, sdr_full=False):
                      'setup_s': t_setup, 'setup': 'bases of unit vectors written down (the reference: 1024 LAPACK decompositions of 1024 x 1024 matrices, '
                                                   '8.6 GB of eigenvectors), (2 (P0 + rho m I))^-1 by Newton-Schulz on the device',
                      'iterations_per_restart': [i1 / R, i2 / R], 'feasible': int((out['maxviol'] < 1e-2).sum()), 'restarts': R,
-                     'roofline': {'bound': 'mfma', 'kernel': 'gemm_pk_kernel (z = Minv rhs) + gather / secular / scatter / bookkeeping kernels',
+                     'roofline': {'bound': 'mfma', 'kernel': 'gemm_pk_kernel (z = Minv rhs) + admm_unit_step_kernel (z-update, gather, projection, scatter) + take-z / bookkeeping kernels',
                                   'achieved': i2 * fl / dt / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': i2 * fl / dt / 1e12 / FP64_PEAK_TFLOPS,
                                   'algorithmic_flops_per_restart_iteration': fl,
                                   'note': 'wall clock of the whole improve_admm (phase 1: no matrix product at all with unit bases; phase 2: ONE n x n '
                                           'product per restart-iteration -- the reference also evaluates f0(z) = z^T P0 z + ... per iteration, here P0 z = rhs / 2 - rho m z '
-                                          'from the solve itself); 9 launches per iteration, not fused: the element-wise passes and the bisections are most of the time'}})
+                                          'from the solve itself); 4 launches per phase-2 iteration (solve, take-z, unit step, bookkeeping), 2 per phase-1 iteration: the replay of the reference\'s bisection steps in the unit step and the element-wise passes are most of the time'}})
         del e
     except Exception as ex:
         recs.append({'config': 'configs[1] through improve(ADMM)', 'error': repr(ex)[:300]})

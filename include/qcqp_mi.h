@@ -219,7 +219,9 @@ int qcqpmi_admm_fused(qcqpmi_ctx *ctx, int enable);
  * p x_i^2 + q x_i + r ~ 0 (Boolean least squares, MAXCUT, boxes; /root/reference/examples/boolean_least_squares.py:34-36,
  * maxcut.py:25-28), for which the eigenvectors utilities.py:160-162 takes from LAPACK are unit vectors -- qcqpmi_admm_run
  * replaces the two consensus products of an iteration (qcqp.py:204-207, 236-239 in the basis) by a gather and a scatter:
- * the same values, no n x m operator.  On by default; enable = 0 forces the GEMM path (cross-check). */
+ * the same values, no n x m operator.  With one row per constraint the z-update, the gather, the projections
+ * (onecons_qcqp, utilities.py:149-196) and the scatter of an iteration are ONE launch (admm_unit_step_kernel; the same bits
+ * as the separate launches).  On by default; enable = 0 forces the GEMM path (cross-check). */
 int qcqpmi_admm_unit_bases(qcqpmi_ctx *ctx, int enable);
 const char *qcqpmi_last_admm_kernel(qcqpmi_ctx *ctx, int *workgroups_per_tile);
 
