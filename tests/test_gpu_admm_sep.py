@@ -242,3 +242,17 @@ def test_admm_unit_bases_full_size_boolean_least_squares(eng_mod):
     d = np.max(np.abs(outs[0] - outs[1]), axis=0) / (1 + np.max(np.abs(outs[1]), axis=0))
     print('\nADMM unit bases at n = 1024, m = 1024, R = %d: vs the GEMM path max|dx| median %.2e max %.2e' % (R, np.median(d), d.max()))
     assert d.max() < 1e-9
+
+
+def test_admm_kernels_random_shapes():
+    """tools/fuzz_admm.py with a fixed seed: admm_fused_kernel in both geometries against the multi-launch path (1e-6, equal
+    iteration counts) on random beamforming shapes, admm_unit_step_kernel against the launches it replaces (bit for bit) on
+    random separable problems -- 12 + 12 cases beyond the fixed shapes of the tests above (improve_admm, qcqp.py:254-285)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_admm.py'), '12', '7'], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert 'mismatches: 0' in p.stdout, p.stdout[-3000:]
+    assert p.stdout.count('\nB ') + p.stdout.startswith('B ') == 12 and 'identical' in p.stdout
