@@ -25,7 +25,10 @@ step waits for the slowest restart of the previous one; then one selection launc
 all steps.  `two` (rounds 2 / 3): two contexts per GPU, one phase-2 launch per step, the preparation of step k + 1 in the tail of
 launch k.  `auto`: stream, and on one GPU the same steps through `two` as well (`schemes` in the line; same best point).
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0: a compact record (< 4 KB, strict JSON), alone on the real stdout and last -- everything else
+(RCCL's banner included) goes to stderr.  `--secondary` (the other BASELINE.json configurations, ~2.5 minutes) and `--compare`
+(the other scheme / the other lifecycle kernel on the same steps) write a sidecar file (gpurun_out/bench_secondary.json) instead
+of growing the line.
 """
 import argparse
 import json
@@ -60,6 +63,78 @@ def profiled_counters(kernel_name):
                             source='profiles/' + name, profile_commit=d.get('git_commit'), profile_date=d.get('date'),
                             kernel=d.get('kernel'), launch=d.get('launch'))
     return best
+
+
+
+# ------------------------------------------------------------------------------------- the one line
+HEADLINE_LIMIT = 4000       # bytes; the driver parses the LAST stdout line (BENCH_r05: a 20 KB line followed by RCCL's banner was not parsed)
+
+
+def claim_stdout():
+    """File descriptor 1 is kept for the ONE line: from here on everything else this process (Python or a C library -- RCCL prints
+    its version banner through C stdio when the communicator is created, and stdio flushes it at exit, i.e. AFTER anything Python
+    printed) writes to "stdout" lands on stderr.  Returns the descriptor the line is written to."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return keep
+
+
+def _finite(o):
+    """Strict JSON: non-finite floats become null, numpy scalars become Python numbers."""
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, (np.floating, float)):
+        f = float(o)
+        return f if np.isfinite(f) else None
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.bool_,)):
+        return bool(o)
+    return o
+
+
+def headline_line(res):
+    """The compact record (< HEADLINE_LIMIT bytes, strict JSON, one line): optional keys are dropped, least important first,
+    should a field ever grow -- the contract's keys never are."""
+    res = _finite(res)
+    optional = ['phase1', 'timed_region_note', 'sidecar']
+    line = json.dumps(res, allow_nan=False, separators=(',', ':'))
+    while len(line) >= HEADLINE_LIMIT and optional:
+        res.pop(optional.pop(0), None)
+        line = json.dumps(res, allow_nan=False, separators=(',', ':'))
+    if len(line) >= HEADLINE_LIMIT:
+        for key in ('roofline', 'cpu_baseline', 'config', 'best'):
+            for sub in [k for k, v in res.get(key, {}).items() if isinstance(v, str) and len(v) > 80]:
+                res[key][sub] = res[key][sub][:77] + '...'
+        line = json.dumps(res, allow_nan=False, separators=(',', ':'))
+    return line
+
+
+def emit_line(fd, line):
+    """The line, alone, as the last thing on the real stdout."""
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # C stdio buffers (RCCL's banner) go where descriptor 1 points now: stderr
+    except Exception:
+        pass
+    data = (line + '\n').encode()
+    while data:
+        data = data[os.write(fd, data):]
+
+
+def write_sidecar(path, payload):
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(_finite(payload), f, indent=1, allow_nan=False)
+        return True
+    except Exception as ex:
+        sys.stderr.write('bench: sidecar %s not written: %r\n' % (path, ex))
+        return False
 
 
 # ------------------------------------------------------------------------------------- secondary records
@@ -648,9 +723,16 @@ def main():
                          'auto (default): stream, and on one GPU the same steps through `two` as well (in the line under `schemes`; the best point '
                          'must be the same)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-secondary', action='store_true', help='skip the bounded records of the other BASELINE.json configs')
+    ap.add_argument('--secondary', action='store_true',
+                    help='also measure the bounded records of the other BASELINE.json configs (about 2.5 minutes): written to '
+                         '--secondary-out as a sidecar JSON file, never into the headline line')
+    ap.add_argument('--secondary-out', default=os.path.join(REPO, 'gpurun_out', 'bench_secondary.json'))
+    ap.add_argument('--compare', action='store_true',
+                    help='run the same K steps through scheme `two` and through the other lifecycle kernel as well (sidecar file)')
+    ap.add_argument('--no-secondary', action='store_true', help='(default since round 6; accepted for old command lines)')
     ap.add_argument('--sdr-full', action='store_true', help='add the SDP relaxation of configs[4] at FULL size (137.6 GB, about 100 s) to the secondary records')
     args = ap.parse_args()
+    line_fd = claim_stdout()
 
     from qcqp_amd import dist, problems
     from qcqp_amd.engine import E_UNSUPPORTED, Engine, EngineError
@@ -805,17 +887,10 @@ def main():
     if rank == 0:
         achieved = (p2_flops / 1e12) / (p2_ms / 1e3) if p2_ms > 0 else 0.0      # rank 0's GPU, its own launches (HIP events)
         pmc = profiled_counters(kernel_name)
-        overlap_text = {
-            'stream': 'ONE persistent launch of the lifecycle kernel per GPU for all %d steps: a workgroup owns 16 restart slots, a slot that becomes '
-                      'free draws the next restart index of the run (steps in order) and runs that restart\'s whole step itself -- keyed normals, '
-                      'phase 1, gate, phase 2 to convergence, objective and max violation -- so the matrix pipes work on live restarts across step '
-                      'boundaries; no preparation kernels, no second stream, no CU partition; per step the best point is selected on the device, '
-                      'then ONE exchange over the ranks (two all-reduces) for all steps; results per restart do not depend on the scheduling' % K,
-            'two': ('two contexts per GPU: suggest + phase 1 + evaluation + gate of step k+1 run in a second stream while the phase-2 kernel of '
-                    'step k finishes; phase-2 kernels never overlap each other') if (scheme == 'stream' or contexts > 1) else 'none (steps strictly one after the other)'}
+        side = {}                       # everything that is not the headline: the sidecar file
+        # ---- the headline record: short strings only (DESIGN.md section 6 has the prose)
         res = {
-            'metric': 'restarts x coord-sweeps / sec (improve COORD_DESCENT, phase-2 coordinate sweeps of 2 n^2 flops; '
-                      'suggest + phase 1 + gate + phase 2 to convergence + selection inside the timed step)',
+            'metric': 'restarts x coord-sweeps / sec (improve COORD_DESCENT phase-2 sweeps, 2n^2 flops each; whole step timed)',
             'value': sweeps2_all / dt,
             'unit': 'restart-sweeps/s',
             'n_gpus': world,
@@ -833,36 +908,64 @@ def main():
                                                                     'per GPU' if args.scaling == 'weak' else 'in total'),
                        'restarts_per_gpu': R, 'num_iters': 1000, 'viol_tol': 1e-2, 'tol': 1e-4,
                        'sharding': 'restarts by global index, replicas of P',
-                       'scheme': scheme, 'step_overlap': overlap_text[scheme]},
+                       'scheme': scheme,
+                       'step': 'suggest(RANDOM) + phase 1 + gate + phase 2 to convergence + best-point selection'
+                               + (', all K steps in ONE persistent launch per GPU' if scheme == 'stream' else '')},
             'phase2_sweeps_per_restart': sweeps2_all / (K * world * max(R, 1)),
             'phase1': {'restart_sweeps_per_s_incl': (sweeps1_all + sweeps2_all) / dt,
                        'sweeps_per_restart': sweeps1_all / (K * world * max(R, 1)),
-                       'kernel_ms_per_launch': None if scheme == 'stream' else p1_ms / K,
-                       'note': 'phase 1 is element-wise for separable constraints (objective identically 0, '
-                               'qcqp.py:114): not counted in value' + ('; it runs inside the lifecycle launch' if scheme == 'stream' else '')},
+                       'note': 'element-wise for separable constraints: not counted in value'},
             'best': {'objective': best[1], 'max_violation': best[2], 'global_restart_index': best[0],
                      'step': best_step},
             'roofline': {'bound': 'mfma', 'kernel': kernel_name or 'cd_general_kernel', 'achieved': achieved,
                          'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_PEAK_TFLOPS,
                          'traffic': pmc['traffic'] if pmc else None,
-                         'traffic_provenance': ({k: pmc[k] for k in ('source', 'profile_commit', 'profile_date', 'kernel', 'launch')}
-                                                if pmc else None),
+                         'traffic_source': pmc['source'] if pmc else None,
                          'mfma_busy': pmc['mfma_busy'] if pmc else None,
                          'algorithmic_flops_per_restart_sweep': 2.0 * n * n,
                          'algorithmic_flops_per_launch': p2_flops if scheme == 'stream' else p2_flops / K,
-                         'algorithmic_flops_per_step': p2_flops / K,
                          'kernel_ms_per_launch': p2_ms if scheme == 'stream' else p2_ms / K,
                          'launches': 1 if scheme == 'stream' else K,
-                         'timing': ('HIP events on the engine stream around the ONE launch that runs all %d timed steps (everything a step does '
-                                    'happens inside it except the %d one-workgroup selection launches and the copies of the results): flops of '
-                                    'the phase-2 visits / that duration; the wall clock of the timed region is %.4f s' % (K, K, dt))
-                                   if scheme == 'stream' else 'HIP events on the engine stream around every phase-2 launch of the timed steps'},
+                         'timing': 'HIP events on the engine stream around ' +
+                                   ('the ONE launch that runs all %d timed steps' % K if scheme == 'stream' else 'every phase-2 launch')},
         }
+        if pmc:
+            side['traffic_provenance'] = {k: pmc[k] for k in ('source', 'profile_commit', 'profile_date', 'kernel', 'launch')}
         if world > 1:
             res['roofline']['kernel_ms_per_launch_max_over_ranks'] = p2_ms_max if scheme == 'stream' else p2_ms_max / K
             res['roofline']['achieved_all_gpus'] = (flops_all / 1e12) / (p2_ms_max / 1e3) if p2_ms_max > 0 else 0.0
-        if world == 1 and args.scheme == 'auto' and scheme == 'stream':
+        if world == 1 and not args.no_cpu_baseline:      # a reported baseline of rank 0 at N = 1 only
+            cores = args.cpu_cores or min(effective_cores(), 32)
+            # the winning restart of the winning step again on the CPU: the cross-check of `best`
+            wseed = args.seed + best_step
+            port, wall_port, opt, wall_opt, win = cpu_baseline(n, args.m_rows, wseed, int(best[0]), cores)
+            sw_port = sum(p['sweeps2'] for p in port)
+            res['best']['oracle_objective'] = win['f0']
+            res['best']['oracle_max_violation'] = win['mv']
+            res['best']['oracle_rel_err'] = abs(win['f0'] - best[1]) / (1.0 + abs(win['f0']))
+            res['best']['oracle_viol_err'] = abs(win['mv'] - best[2])
+            res['cpu_baseline'] = {
+                'value': sw_port / wall_port, 'unit': 'restart-sweeps/s', 'cores': cores, 'kind': 'port',
+                'per_core': sum(p['sweeps2'] / p['dt'] for p in port) / len(port),
+                'sample': '2 phase-2 sweeps per core through oracle/ (C restatement, reference call structure), one process per '
+                          'core: %.1f sweeps in %.1f s wall' % (sw_port, wall_port),
+                'host_cpu_count': os.cpu_count(),
+                'optimised': {'value': sum(o['sweeps2'] for o in opt) / wall_opt, 'cores': cores,
+                              'kind': 'port with incremental gradient, O(n) per accepted move',
+                              'per_core': sum(o['sweeps2'] / o['dt'] for o in opt) / len(opt)},
+                # BASELINE.md section 3 (tools/calibrate_baseline.py, build container): the true reference's loop body is
+                # 35.6x slower than this C port on identical coordinates (0.0124 vs 0.441 restart-sweeps/s/core)
+                'true_reference': {'port_over_reference_speed': 35.6,
+                                   'estimated_value': sw_port / wall_port / 35.6,
+                                   'source': 'BASELINE.md section 3'},
+            }
+        # ---- the line is final here; what follows (opt-in, minutes) only fills the sidecar file and cannot change or lose it
+        line = headline_line(res)
+        if world == 1 and (args.compare or args.secondary):
+            side['headline'] = json.loads(line)
+            write_sidecar(args.secondary_out, side)
+        if world == 1 and args.compare and args.scheme == 'auto' and scheme == 'stream':
             # the same K steps (same seeds) through the scheme of rounds 2 / 3, for comparison: the best point must be the same one
             try:
                 acc = measure_two()
@@ -870,20 +973,18 @@ def main():
                 b2 = acc['best']
                 same_best = (int(b2[0]) == int(best[0]) and acc['best_step'] == best_step
                              and abs(b2[1] - best[1]) <= 1e-9 * (1.0 + abs(best[1])) and float(np.max(np.abs(np.asarray(b2[3]) - np.asarray(best[3])))) <= 1e-9)
-                res['schemes'] = {'reported': 'stream',
-                                  'two': {'value': acc['sweeps2'] / acc['dt'], 'ms_per_step': 1e3 * acc['dt'] / K, 'timed_region_s': acc['dt'],
-                                          'roofline': {'kernel': acc['kernel'], 'achieved': ach2, 'frac': ach2 / FP64_PEAK_TFLOPS,
-                                                       'kernel_ms_per_launch': acc['p2_ms'] / K,
-                                                       'timing': 'HIP events around every phase-2 launch (the launches own the chip; preparation and '
-                                                                 'selection are outside them)'},
-                                          'best': {'objective': b2[1], 'max_violation': b2[2], 'global_restart_index': b2[0], 'step': acc['best_step']},
-                                          'same_best_point_as_stream': bool(same_best), 'contexts': acc['contexts'],
-                                          'step_overlap': overlap_text['two'] if acc['contexts'] > 1 else 'none (steps strictly one after the other)'}}
+                side['schemes'] = {'reported': 'stream',
+                                   'two': {'value': acc['sweeps2'] / acc['dt'], 'ms_per_step': 1e3 * acc['dt'] / K, 'timed_region_s': acc['dt'],
+                                           'roofline': {'kernel': acc['kernel'], 'achieved': ach2, 'frac': ach2 / FP64_PEAK_TFLOPS,
+                                                        'kernel_ms_per_launch': acc['p2_ms'] / K,
+                                                        'timing': 'HIP events around every phase-2 launch (the launches own the chip; preparation and '
+                                                                  'selection are outside them)'},
+                                           'best': {'objective': b2[1], 'max_violation': b2[2], 'global_restart_index': b2[0], 'step': acc['best_step']},
+                                           'same_best_point_as_stream': bool(same_best), 'contexts': acc['contexts']}}
             except Exception as ex:
-                res['schemes'] = {'reported': 'stream', 'two': {'error': repr(ex)[:400]}}
-        if world == 1 and scheme == 'stream':
-            # the same K steps (same seeds) through the OTHER lifecycle kernel: qcqpmi_cd_stream_run picks the faster one for the
-            # shape (the round-4 kernel for the Boolean family at n >= 960, cd_life_kernel everywhere else); both are in the line
+                side['schemes'] = {'reported': 'stream', 'two': {'error': repr(ex)[:400]}}
+        if world == 1 and args.compare and scheme == 'stream' and hasattr(eng, 'cd_life_version'):
+            # the same K steps (same seeds) through the OTHER lifecycle kernel (qcqpmi_cd_life_version: a debug switch)
             try:
                 other = 2 if not (kernel_name or '').startswith('cd_life_kernel') else 1
                 eng.cd_life_version(other)
@@ -896,60 +997,34 @@ def main():
                 sw_o = float(oo['visits2'].sum()) / n
                 ach_o = sw_o * 2.0 * n * n / 1e12 / (ms_o / 1e3)
                 bs_o = min(range(K), key=lambda k: dist.better_key(keys_o[k][1], keys_o[k][2], keys_o[k][0]) + (k,))
-                res.setdefault('schemes', {'reported': 'stream'})['other_lifecycle_kernel'] = {
+                side.setdefault('schemes', {'reported': 'stream'})['other_lifecycle_kernel'] = {
                     'kernel': eng.last_cd_kernel(), 'value': sw_o / dt_o, 'ms_per_step': 1e3 * dt_o / K, 'kernel_ms_per_launch': ms_o,
                     'roofline_frac': ach_o / FP64_PEAK_TFLOPS,
                     'same_best_point': bool(bs_o == best_step and int(keys_o[bs_o][0]) == int(best[0]) and
-                                            float(np.max(np.abs(np.asarray(X_o[bs_o]) - np.asarray(best[3])))) <= 1e-9),
-                    'note': 'qcqpmi_cd_stream_run dispatches by shape (qcqpmi_cd_life_version 0): cd_life_kernel (round 5: four-wave workgroups, '
-                            'two per CU; any n <= 2304, box / MAXCUT families) everywhere except the Boolean family at n >= 960, where the '
-                            'round-4 kernel is faster (profiles/r05_life_vs_round4.md)'}
+                                            float(np.max(np.abs(np.asarray(X_o[bs_o]) - np.asarray(best[3])))) <= 1e-9)}
             except Exception as ex:
-                res.setdefault('schemes', {'reported': 'stream'})['other_lifecycle_kernel'] = {'error': repr(ex)[:300]}
+                side.setdefault('schemes', {'reported': 'stream'})['other_lifecycle_kernel'] = {'error': repr(ex)[:300]}
             finally:
                 eng.cd_life_version(0)
-        if world == 1 and not args.no_secondary:
-            res['secondary'] = secondary_records(local_rank, sdr_full=args.sdr_full)
-        if world == 1 and not args.no_cpu_baseline:      # a reported baseline of rank 0 at N = 1 only
-            cores = args.cpu_cores or min(effective_cores(), 32)
-            if res.get('secondary'):
+        if world == 1 and args.secondary:
+            try:
+                side['secondary'] = secondary_records(local_rank, sdr_full=args.sdr_full)
+            except Exception as ex:
+                side['secondary'] = [{'error': repr(ex)[:400]}]
+            write_sidecar(args.secondary_out, side)
+            if not args.no_cpu_baseline:
                 try:
-                    extra = secondary_cpu_baselines(cores)
-                    for rec in res['secondary']:
+                    extra = secondary_cpu_baselines(args.cpu_cores or min(effective_cores(), 32))
+                    for rec in side['secondary']:
                         for key, val in extra.items():
                             if str(rec.get('config', '')).startswith(key):
                                 rec['cpu_baseline'] = val
                 except Exception as ex:
                     sys.stderr.write('bench: CPU baselines of the secondary records failed: %r\n' % (ex,))
-            # the winning restart of the winning step again on the CPU: the cross-check of `best`
-            wseed = args.seed + best_step
-            port, wall_port, opt, wall_opt, win = cpu_baseline(n, args.m_rows, wseed, int(best[0]), cores)
-            sw_port = sum(p['sweeps2'] for p in port)
-            res['best']['oracle_objective'] = win['f0']
-            res['best']['oracle_max_violation'] = win['mv']
-            res['best']['oracle_rel_err'] = abs(win['f0'] - best[1]) / (1.0 + abs(win['f0']))
-            res['best']['oracle_viol_err'] = abs(win['mv'] - best[2])
-            res['cpu_baseline'] = {
-                'value': sw_port / wall_port, 'unit': 'restart-sweeps/s', 'cores': cores, 'kind': 'port',
-                'per_core': sum(p['sweeps2'] / p['dt'] for p in port) / len(port),
-                'sample': '2 phase-2 sweeps per core from x0 = sign(xi)(1 + 2e-5 u) through oracle/ (C restatement, '
-                          'reference-faithful per-call structure), one process per usable core: %.1f sweeps in %.1f s wall'
-                          % (sw_port, wall_port),
-                'host_cpu_count': os.cpu_count(),
-                'optimised': {'value': sum(o['sweeps2'] for o in opt) / wall_opt, 'unit': 'restart-sweeps/s',
-                              'cores': cores, 'kind': 'port (incremental gradient, O(n) per accepted move)',
-                              'per_core': sum(o['sweeps2'] / o['dt'] for o in opt) / len(opt),
-                              'sample': '8 phase-2 runs per core from x0 = sign(xi)(1 + 2e-5 u), %.1f sweeps in %.2f s wall'
-                                        % (sum(o['sweeps2'] for o in opt), wall_opt)},
-                # BASELINE.md section 3 (tools/calibrate_baseline.py, build container): the true reference's loop body is
-                # 35.6x slower than this C port on identical coordinates (0.0124 vs 0.441 restart-sweeps/s/core)
-                'true_reference': {'port_over_reference_speed': 35.6,
-                                   'estimated_value': sw_port / wall_port / 35.6,
-                                   'measured_in_build_container_per_core': 0.0124,
-                                   'source': 'BASELINE.md section 3, tools/calibrate_baseline.py'},
-            }
-        print(json.dumps(res))
-        sys.stdout.flush()
+        if side and world == 1 and (args.compare or args.secondary):
+            if write_sidecar(args.secondary_out, side):
+                sys.stderr.write('bench: secondary records and comparisons: %s\n' % (args.secondary_out,))
+        emit_line(line_fd, line)
     if boot is not None:
         boot.close()
     rc = dist.wait_children(kids) if kids else 0

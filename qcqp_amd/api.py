@@ -281,6 +281,8 @@ class QCQP(object):
             # same points either way (tests/test_gpu_life.py); problems the kernel does not take fall back to qcqpmi_cd_run.
             stream = kwargs.get('stream', None)
             if stream is False:
+                if batches is not None:       # the resident batches' global restart indices: same keyed draws as the streamed path
+                    first_index = int(batches[2])
                 batches = None
             elif batches is None and not kwargs.get('reference_order', False) and (stream or self.engine.pop_size >= STREAM_MIN):
                 batches = (1, self.engine.pop_size, first_index)

@@ -214,12 +214,17 @@ class FileRendezvous(object):
         self.dir = _private_dir(os.path.join(_rdzv_root(), key))
         self.epoch = _job_epoch()
         self.seq = 0
-        if self.rank == 0 and self.epoch > 0.0:
-            # leftovers of a dead job with the same key: remove what no rank of this job can have written
+        # leftovers of a dead job with the same key: rank 0 removes what NO rank of this job can have written, i.e. what is older
+        # than the launcher all ranks share -- not what is older than rank 0's own epoch: a rank 0 that starts more than
+        # RANK_START_WINDOW after another rank (sequential shell launch, slow scheduler) would delete that rank's live messages
+        # and the job would hang instead of running.  (Such a late rank 0 still REJECTS those messages as stale: the reader's
+        # timeout below then names the window.)
+        launcher = 0.0 if os.environ.get(RDZV_ENV) else _proc_start_time(os.getppid())
+        if self.rank == 0 and launcher > 0.0:
             for name in os.listdir(self.dir):
                 path = os.path.join(self.dir, name)
                 try:
-                    if os.lstat(path).st_mtime < self.epoch:
+                    if os.lstat(path).st_mtime < launcher - 2.0:
                         os.remove(path)
                 except OSError:
                     pass
@@ -247,7 +252,11 @@ class FileRendezvous(object):
         delay = 0.0005
         while not self._fresh(path):
             if time.time() - t0 > self.timeout:
-                raise RuntimeError('rendezvous timeout waiting for %s (rank %d of %d)' % (path, self.rank, self.world))
+                stale = os.path.exists(path)
+                raise RuntimeError('rendezvous timeout waiting for %s (rank %d of %d)%s' % (path, self.rank, self.world,
+                                   '; the file exists but is older than this rank accepts: all ranks of a job must start within '
+                                   '%.0f s of each other (RANK_START_WINDOW), or set %s to a per-job key' % (RANK_START_WINDOW, RDZV_ENV)
+                                   if stale else ''))
             time.sleep(delay)
             delay = min(delay * 1.5, 0.05)
         with open(path, 'rb') as f:

@@ -694,7 +694,19 @@ def test_bench_two_ranks_control_flow(tmp_path, launch):
         out = outs[0][0].decode()
     lines = [l for l in out.splitlines() if l.startswith('{')]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert out.rstrip('\n').splitlines()[-1] == lines[0]              # the line is the LAST thing on stdout
+    assert len(lines[0]) < 4096                                       # compact: BENCH_r05's 20 KB line was not parsed by the driver
+
+    def no_constants(name):
+        raise AssertionError('non-strict JSON constant %s in the bench line' % name)
+    d = json.loads(lines[0], parse_constant=no_constants)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'best'):
+        assert key in d, key
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_ms_per_launch'):
+        assert key in d['roofline'], key
+    assert 'secondary' not in d and 'schemes' not in d
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['config']['scheme'] == 'stream' and d['scaling'] == 'weak'
     # both ranks ran 3 steps of 16 restarts with 10 sweeps each: the whole-job value counts both
     assert abs(d['value'] * d['timed_region_s'] - 2 * 3 * 16 * 10) < 1e-6
@@ -709,6 +721,40 @@ def test_bench_two_ranks_control_flow(tmp_path, launch):
             cand = (float(f[p * 16 + i]), 16 * rank + i, p)
             best = cand if best is None or cand[0] < best[0] else best
     assert abs(d['best']['objective'] - best[0]) < 1e-12 and d['best']['global_restart_index'] == best[1] and d['best']['step'] == best[2]
+
+
+def test_bench_line_is_compact_strict_json_and_last_on_stdout(tmp_path):
+    """bench.headline_line / claim_stdout / emit_line: non-finite floats become null, a record that grew is cut back below the
+    limit without losing a contract key, and whatever a C library printed through stdio (RCCL's banner at communicator creation,
+    flushed at exit) cannot follow the line on the real stdout."""
+    import json
+    import subprocess
+    sys.path.insert(0, REPO)
+    import bench
+    rec = {'metric': 'm', 'value': 1.0, 'unit': 'u', 'n_gpus': 1, 'steps': 2, 'warmup': 1, 'ms_per_step': float('nan'),
+           'config': {'workload': 'w' * 300, 'note': 'x' * 3000}, 'roofline': {'frac': np.float64(0.5), 'timing': 't' * 2000, 'traffic': float('inf')},
+           'cpu_baseline': {'value': np.float32(2.0), 'sample': 's' * 1500}, 'best': {'objective': 1.0, 'index': np.int64(3)},
+           'phase1': {'note': 'p' * 500}}
+    line = bench.headline_line(rec)
+    assert len(line) < bench.HEADLINE_LIMIT and '\n' not in line
+    d = json.loads(line, parse_constant=lambda name: (_ for _ in ()).throw(AssertionError(name)))
+    assert d['ms_per_step'] is None and d['roofline']['traffic'] is None and d['roofline']['frac'] == 0.5 and d['best']['index'] == 3
+    assert all(k in d for k in ('metric', 'value', 'unit', 'config', 'roofline', 'cpu_baseline', 'best'))
+    prog = tmp_path / 'emit.py'
+    prog.write_text('''
+import ctypes, os, sys
+sys.path.insert(0, %r)
+import bench
+fd = bench.claim_stdout()
+libc = ctypes.CDLL(None)
+libc.puts(b"RCCL version : banner through C stdio")      # buffered by stdio until exit
+print("python chatter")
+bench.emit_line(fd, '{"value": 1}')
+''' % REPO)
+    pr = subprocess.run([sys.executable, str(prog)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert pr.returncode == 0, pr.stderr.decode()[-1500:]
+    assert pr.stdout.decode() == '{"value": 1}\n'
+    assert b'banner' in pr.stderr and b'chatter' in pr.stderr
 
 
 def test_build_units_cover_every_source_file():
