@@ -723,6 +723,11 @@ def main():
                          'auto (default): stream, and on one GPU the same steps through `two` as well (in the line under `schemes`; the best point '
                          'must be the same)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--comm', choices=['rccl', 'file'], default='rccl',
+                    help='transport of the best-point exchange: RCCL (default), or the job\'s file rendezvous -- for ranks that share '
+                         'one device (RCCL refuses duplicate devices; tests: two real engines on the one GPU of a test box)')
+    ap.add_argument('--device', type=int, default=-1, help='HIP device of EVERY rank (default: LOCAL_RANK)')
+    ap.add_argument('--best-out', default='', help='rank 0 saves the global best point of every timed step (K x n, .npy)')
     ap.add_argument('--secondary', action='store_true',
                     help='also measure the bounded records of the other BASELINE.json configs (about 2.5 minutes): written to '
                          '--secondary-out as a sidecar JSON file, never into the headline line')
@@ -748,8 +753,12 @@ def main():
 
     funcs, _, _ = problems.boolean_least_squares(n, args.m_rows, seed=1)
     form = QCQPForm.from_arrays(funcs)
+    if args.device >= 0:
+        local_rank = args.device
+    if args.comm == 'file' and args.scheme == 'auto':
+        args.scheme = 'stream'                     # (scheme `two` selects through RCCL inside the library)
     eng = Engine(form, device=local_rank)
-    boot = dist.init_rccl(eng, rank, world)
+    boot = dist.init_file_comm(eng, rank, world) if args.comm == 'file' else dist.init_rccl(eng, rank, world)
     K = max(args.steps, 1)
 
     def allreduce_sum(a):
@@ -1024,6 +1033,8 @@ def main():
         if side and world == 1 and (args.compare or args.secondary):
             if write_sidecar(args.secondary_out, side):
                 sys.stderr.write('bench: secondary records and comparisons: %s\n' % (args.secondary_out,))
+        if args.best_out and scheme == 'stream':
+            np.save(args.best_out, np.asarray(Xbest))
         emit_line(line_fd, line)
     if boot is not None:
         boot.close()

@@ -345,6 +345,38 @@ def init_rccl(engine, rank, world, bootstrap=None):
     return bootstrap
 
 
+def init_file_comm(engine, rank, world, bootstrap=None):
+    """The collectives bench.py needs -- barrier, all-reduce (max / sum) of float64 vectors, all-gather of raw arrays -- over the
+    job's file rendezvous instead of RCCL, attached to `engine` under the names of its RCCL methods.  For ranks that SHARE a device
+    (RCCL refuses a communicator with duplicate devices): two real engines in two processes on the one GPU of a test box exchange
+    exactly what two GPUs would (tests/test_gpu_life.py).  Float64 values travel as their IEEE bytes: results are the bits RCCL's
+    sum / max over two ranks would give (a + b is commutative; more than two ranks: summed in rank order)."""
+    boot = bootstrap or (FileRendezvous(rank, world) if world > 1 else None)
+    engine._world = int(world)
+
+    def allgather(arr):
+        a = np.ascontiguousarray(arr)
+        if world == 1:
+            return a.reshape((1,) + a.shape).copy()
+        parts = boot.allgather(a.tobytes())
+        return np.stack([np.frombuffer(p_, dtype=a.dtype).reshape(a.shape) for p_ in parts])
+
+    def allreduce(values, op='max'):
+        v = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)))
+        parts = allgather(v)
+        out = parts[0].copy()
+        for k in range(1, parts.shape[0]):
+            out = np.maximum(out, parts[k]) if op == 'max' else out + parts[k]
+        v[...] = out
+        return v
+
+    def barrier():
+        if world > 1:
+            boot.barrier()
+    engine.comm_allgather, engine.comm_allreduce, engine.comm_barrier = allgather, allreduce, barrier
+    return boot
+
+
 def global_best_host(bootstrap, local_key, local_x):
     """CPU transport of the final exchange (tests only): all-gather the keys, take the minimum,
     winner's x is broadcast.  Mirrors qcqpmi_comm_select_best."""

@@ -61,9 +61,14 @@ def funcs_from_npz(z):
 
 def oracle_map(fn, items):
     """Independent oracle runs side by side (the C oracle runs without the GIL; the GPU box offers 16 host cores)."""
+    import os
     from concurrent.futures import ThreadPoolExecutor
     items = list(items)
-    with ThreadPoolExecutor(max_workers=max(1, min(8, len(items)))) as ex:
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    with ThreadPoolExecutor(max_workers=max(1, min(16, cores, len(items)))) as ex:
         return list(ex.map(fn, items))
 
 

@@ -123,10 +123,14 @@ def test_dense_path_scale_dispatch_vs_oracle(eng_mod, orc, R):
     sample = [0, R // 2, R - 1]
     same = 0
     spread = np.percentile(f0, 90) - np.percentile(f0, 10)
-    for r in sample:
+
+    def oracle_restart(r):
         rng = orc.Rng(orc.RNG_KEYED, seed)
         rng.set_restart(first + r)
-        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+        return prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+    trajectories = dict(zip(sample, oracle_map(oracle_restart, sample)))      # 25 s of oracle each: side by side, and once
+    for r in sample:
+        x, s1, s2 = trajectories[r]
         d = np.max(np.abs(X[:, r] - x))
         same += d < 1e-6 * (1 + np.max(np.abs(x)))
         fo, mo = prob.eval(0, x), prob.max_violation(x)
@@ -146,9 +150,7 @@ def test_dense_path_scale_dispatch_vs_oracle(eng_mod, orc, R):
         assert e.last_cd_kernel() == 'cd_general_kernel'
         Xr = e.download()
         for r in sample:
-            rng = orc.Rng(orc.RNG_KEYED, seed)
-            rng.set_restart(first + r)
-            x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+            x, s1, s2 = trajectories[r]
             assert rel(Xr[:, r], x) < 1e-9, (r, np.max(np.abs(Xr[:, r] - x)))
             assert outr['sweeps1'][r] == s1[0] and outr['visits2'][r] == s2[1] and outr['accepted2'][r] == s2[2], r
             assert abs(outr['f0'][r] - prob.eval(0, x)) <= 1e-9 * (1 + abs(outr['f0'][r]))
@@ -196,11 +198,14 @@ def test_population_best_vs_oracle(eng_mod, orc, family):
     f0, mv = e.eval()
     assert rel(out['f0'], f0) < 1e-9 and np.max(np.abs(out['maxviol'] - mv)) < 1e-9
     Xo, fo, mo = np.zeros_like(X), np.zeros(R), np.zeros(R)
-    for r in range(R):
+
+    def oracle_restart(r, x0=None):
         rng = orc.Rng(orc.RNG_KEYED, seed)
         rng.set_restart(first + r)
-        x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
-        Xo[:, r], fo[r], mo[r] = x, prob.eval(0, x), prob.max_violation(x)
+        x = prob.improve_cd(X0[:, r] if x0 is None else x0, num_iters=iters, rng=rng)[0]
+        return x, prob.eval(0, x), prob.max_violation(x)
+    for r, (x, f_, m_) in enumerate(oracle_map(oracle_restart, range(R))):      # (the C oracle runs without the GIL)
+        Xo[:, r], fo[r], mo[r] = x, f_, m_
 
     def best(f, v):
         feas = np.where(v < 1e-2)[0]
@@ -240,10 +245,7 @@ def test_population_best_vs_oracle(eng_mod, orc, family):
     # profiles/r04_reference_sensitivity.md for the same experiment with /root/reference)
     Rs = min(R, 96)
     dref = np.zeros(Rs)
-    for r in range(Rs):
-        rng = orc.Rng(orc.RNG_KEYED, seed)
-        rng.set_restart(first + r)
-        xp = prob.improve_cd(np.nextafter(X0[:, r], np.inf), num_iters=iters, rng=rng)[0]
+    for r, (xp, _, _) in enumerate(oracle_map(lambda r: oracle_restart(r, np.nextafter(X0[:, r], np.inf)), range(Rs))):
         dref[r] = np.max(np.abs(xp - Xo[:, r])) / (1 + np.max(np.abs(Xo[:, r])))
     off_ref = float(np.mean(dref > 1e-6))
     print('%s: the oracle against itself under one ulp of x0: %.1f %% of %d restarts leave the trajectory (1e-6); the MFMA path against the '

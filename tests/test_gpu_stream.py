@@ -6,6 +6,8 @@ the oracle.  Run with `-m gpu` on an MI355X."""
 import numpy as np
 import pytest
 
+from conftest import oracle_map
+
 pytestmark = pytest.mark.gpu
 
 
@@ -67,6 +69,7 @@ def test_cd_stream_run_equals_serial_runs(eng_mod, orc, n, m_rows, R, K, iters):
     f0e, mve = es.eval()        # fresh evaluation of all final points by the evaluation kernel
     assert rel(o['f0'], f0e) < 1e-11 and np.max(np.abs(o['maxviol'] - mve)) < 1e-12
     prob = orc.Problem(funcs)
+    jobs = []
     for p in range(K):
         sd, fi = seed0 + p * sstride, first0 + p * fstride
         e.randn(R, seed=sd, first_index=fi)
@@ -82,10 +85,15 @@ def test_cd_stream_run_equals_serial_runs(eng_mod, orc, n, m_rows, R, K, iters):
         idx, fb, vb, xb = e.select_best(1e-4)
         assert o['best_index'][p] == idx and o['best_f0'][p] == o['f0'][sl][idx] and o['best_maxviol'][p] == o['maxviol'][sl][idx]
         assert np.array_equal(o['best_x'][p], X[:, p * R + idx])
-        for r in (0, R - 1):
-            rng = orc.Rng(orc.RNG_KEYED, sd)
-            rng.set_restart(fi + r)
-            x, s1, s2 = prob.improve_cd(X0[:, r], num_iters=iters, rng=rng)
+        jobs += [(p, r, sd, fi, X0[:, r].copy()) for r in (0, R - 1)]
+
+    def oracle_restart(job):
+        p, r, sd, fi, x0 = job
+        rng = orc.Rng(orc.RNG_KEYED, sd)
+        rng.set_restart(fi + r)
+        return prob.improve_cd(x0, num_iters=iters, rng=rng)
+    for (p, r, sd, fi, x0), (x, s1, s2) in zip(jobs, oracle_map(oracle_restart, jobs)):      # the oracle trajectories side by side
+        if True:
             assert rel(X[:, p * R + r], x) < 1e-9, (p, r)
             # (a restart that phase 1 cannot improve any further stops after its first sweep without an update; the reference
             #  burns all num_iters sweeps on the same point: documented deviation 4)

@@ -659,13 +659,13 @@ engine_mod.Engine = FakeEngine
 dist.init_rccl = fake_init_rccl
 sys.argv = [os.path.abspath(__file__), '--gpus', '2', '--steps', '3',      # (the self-spawned rank 1 re-runs THIS script)
              '--warmup', '1', '--n', '32', '--m-rows', '8', '--restarts', '16',
-            '--no-secondary', '--no-cpu-baseline']
+            '--no-secondary', '--no-cpu-baseline'] + %(extra)r
 import bench
 sys.exit(bench.main())
 '''
 
 
-@pytest.mark.parametrize('launch', ['self_spawn', 'launcher'])
+@pytest.mark.parametrize('launch', ['self_spawn', 'launcher', 'self_spawn_file_comm'])
 def test_bench_two_ranks_control_flow(tmp_path, launch):
     """bench.py --gpus 2 with a FAKE engine (no GPU here): the self-spawn of rank 1 -- or two processes started the way the
     driver's `python -m torch.distributed.run --nproc-per-node 2` starts them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
@@ -676,9 +676,11 @@ def test_bench_two_ranks_control_flow(tmp_path, launch):
     import json
     import subprocess
     script = tmp_path / 'bench_worker.py'
-    script.write_text(BENCH_WORKER % dict(repo=REPO))
+    # (self_spawn_file_comm: `--comm file` -- qcqp_amd.dist.init_file_comm for real: the all-gather / all-reduce / barrier the engine
+    #  methods are replaced with travel through the job's file rendezvous, as in the two-engines-one-GPU test of tests/test_gpu_life.py)
+    script.write_text(BENCH_WORKER % dict(repo=REPO, extra=(['--comm', 'file', '--device', '0'] if launch == 'self_spawn_file_comm' else [])))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'QCQP_AMD_RDZV')}
-    if launch == 'self_spawn':
+    if launch.startswith('self_spawn'):
         pr = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=str(tmp_path))
         assert pr.returncode == 0, pr.stderr.decode()[-2000:]
         out = pr.stdout.decode()
