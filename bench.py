@@ -722,6 +722,9 @@ def main():
                          'round 2/3 scheme, two contexts per GPU, one phase-2 launch per step, the preparation of step k + 1 in the tail of launch k; '
                          'auto (default): stream, and on one GPU the same steps through `two` as well (in the line under `schemes`; the best point '
                          'must be the same)')
+    ap.add_argument('--no-factor', action='store_true',
+                    help='do not hand the factor of the objective (P0 = L L^T, rank = rows of A) to the lifecycle kernel: it then '
+                         'multiplies with P0 itself (rounds 4 / 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--comm', choices=['rccl', 'file'], default='rccl',
                     help='transport of the best-point exchange: RCCL (default), or the job\'s file rendezvous -- for ranks that share '
@@ -759,6 +762,21 @@ def main():
         args.scheme = 'stream'                     # (scheme `two` selects through RCCL inside the library)
     eng = Engine(form, device=local_rank)
     boot = dist.init_file_comm(eng, rank, world) if args.comm == 'file' else dist.init_rccl(eng, rank, world)
+    # the objective of a least-squares problem has rank rows(A): found from P0 alone (pivoted Cholesky, verified entry by entry;
+    # problem set-up, outside the timed region) -- the lifecycle kernel then carries L^T X instead of multiplying with P0
+    factor_rank = 0
+    if not args.no_factor and hasattr(eng, 'cd_set_objective_factor'):
+        from qcqp_amd import lowrank
+        P0 = funcs[0][0]
+        P0 = P0.toarray() if hasattr(P0, 'toarray') else np.asarray(P0)
+        Lf = lowrank.objective_factor(P0, max_rank=min(288, n // 2)) if n >= 128 else None
+        if Lf is not None:
+            try:
+                eng.cd_set_objective_factor(Lf)
+                factor_rank = int(Lf.shape[1])
+            except EngineError as ex:
+                if ex.code != E_UNSUPPORTED:
+                    raise
     K = max(args.steps, 1)
 
     def allreduce_sum(a):
@@ -917,7 +935,7 @@ def main():
                                                                     'per GPU' if args.scaling == 'weak' else 'in total'),
                        'restarts_per_gpu': R, 'num_iters': 1000, 'viol_tol': 1e-2, 'tol': 1e-4,
                        'sharding': 'restarts by global index, replicas of P',
-                       'scheme': scheme,
+                       'scheme': scheme, 'objective_factor_rank': factor_rank,
                        'step': 'suggest(RANDOM) + phase 1 + gate + phase 2 to convergence + best-point selection'
                                + (', all K steps in ONE persistent launch per GPU' if scheme == 'stream' else '')},
             'phase2_sweeps_per_restart': sweeps2_all / (K * world * max(R, 1)),
@@ -939,6 +957,16 @@ def main():
                          'timing': 'HIP events on the engine stream around ' +
                                    ('the ONE launch that runs all %d timed steps' % K if scheme == 'stream' else 'every phase-2 launch')},
         }
+        if factor_rank and 'factored' in (kernel_name or ''):
+            # what the factored kernel EXECUTES per restart-sweep: per block of 16 coordinates of a tile of 16 restarts 4 RB MFMAs for
+            # the product, 4 RB for the update of Y, 8 for the chain's fix-up (RB = blocks of 16 rows of Y), 2048 flops each
+            rb = (factor_rank + 15) // 16
+            executed = (n / 16.0) * (8 * rb + 8) * 2048.0 / 16.0
+            res['roofline']['executed_flops_per_restart_sweep'] = executed
+            res['roofline']['frac_executed'] = res['roofline']['frac'] * executed / (2.0 * n * n)
+            res['roofline']['note'] = ('frac counts the ALGORITHMIC 2 n^2 flops of a sweep (the unit of `value`); the kernel carries L^T X '
+                                       '(P0 = L L^T, rank %d) and executes %.2f of them; the sequential chain, not the matrix pipe, is the limit'
+                                       % (factor_rank, executed / (2.0 * n * n)))
         if pmc:
             side['traffic_provenance'] = {k: pmc[k] for k in ('source', 'profile_commit', 'profile_date', 'kernel', 'launch')}
         if world > 1:

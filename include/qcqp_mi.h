@@ -328,6 +328,15 @@ int qcqpmi_cd_stream_reserve(qcqpmi_ctx *ctx, int64_t K, int64_t R);
  * wherever it applies; 1: the round-4 kernel only.  Both produce the same restarts (tests/test_gpu_life.py, tests/test_gpu_stream.py run
  * every case with both); qcqpmi_last_cd_kernel names the one that ran. */
 int qcqpmi_cd_life_version(qcqpmi_ctx *ctx, int version);
+/* Factored objective (round 6).  get_onevar_func (utilities.py:99-105) needs (P0 z)_i per coordinate visit; when P0 = L L^T with L
+ * n x r (row-major; a least-squares objective |A x - b|^2 has L = A^T, r = rows of A; any PSD P0 of low rank has one), the lifecycle
+ * kernel carries Y = L^T X per tile of restarts instead of multiplying with P0: (P0 X)[I_b, :] = L[I_b, :] Y and Y += L[I_b, :]^T (moves
+ * of block b) -- 8 r / 16 matrix instructions per block of 16 coordinates instead of n / 4.  P0 itself stays uploaded (diagonal
+ * blocks, the evaluation kernels, every other path); the caller vouches for L L^T = P0 (qcqp_amd.lowrank.objective_factor checks
+ * it to 1e-12 of the largest entry).  Takes r <= 288 and 128 <= n <= 1024 + 64, single-class separable constraints on a positive
+ * diagonal (QCQPMI_EUNSUPPORTED otherwise; qcqpmi_cd_stream_run then runs as without a factor).  L == NULL or r == 0 removes it;
+ * qcqpmi_cd_life_version(ctx, 3) = cd_life_kernel WITHOUT the factor (comparisons). */
+int qcqpmi_cd_set_objective_factor(qcqpmi_ctx *ctx, const double *L, int64_t r);
 /* Coordinate descent for constraints that couple coordinates IN THE REFERENCE'S SUMMATION ORDER (test / diagnostic mode, any
  * n): every one-variable coefficient (t2, t1, t0) of get_onevar_func (utilities.py:99-105) is formed by row-sequential sums
  * like the reference's CSR products -- t0 = f_k(z) afresh per coordinate, O((m+1) n^2) per coordinate visit -- so that

@@ -70,6 +70,7 @@ PROTOTYPES = [
                                        C.c_uint64, C.c_uint64, C.c_double, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp, c_ip, c_dp, c_dp, c_dp]),
     ('qcqpmi_cd_queue', C.c_int, [C.c_void_p, C.c_int]),
     ('qcqpmi_cd_life_version', C.c_int, [C.c_void_p, C.c_int]),
+    ('qcqpmi_cd_set_objective_factor', C.c_int, [C.c_void_p, c_dp, C.c_int64]),
     ('qcqpmi_sync', C.c_int, [C.c_void_p]),
     ('qcqpmi_debug_profile', C.c_int, [C.c_void_p, C.c_int, c_ip]),
     ('qcqpmi_debug_admm_profile', C.c_int, [C.c_void_p, c_ip]),

@@ -256,6 +256,34 @@ class QCQP(object):
         f0, mv = self.engine.eval()
         return self._publish(f0, mv)
 
+    def _objective_factor(self, enable=True):
+        """Once per problem: P0 = L L^T of low rank (a least-squares objective: rank = rows of A) -> the lifecycle kernel carries
+        L^T X instead of multiplying with P0 (qcqp_amd.lowrank.objective_factor, qcqpmi_cd_set_objective_factor).  Tried for a
+        dense-enough P0 with a positive diagonal of 256 <= n <= 1088; `factor=False` in improve() switches it off."""
+        want = bool(enable)
+        state = getattr(self, '_factor_state', None)
+        if state is None:
+            L = None
+            f0 = self.qcqp_form.f0
+            n = self.n
+            if want and 256 <= n <= 1088:
+                from .lowrank import objective_factor
+                P0 = f0.P.toarray() if hasattr(f0.P, 'toarray') else np.asarray(f0.P)
+                if np.all(np.diag(P0) > 0.0):
+                    L = objective_factor(P0, max_rank=min(288, n // 2))
+            self._factor_L = L
+            state = self._factor_state = 'off'
+        target = 'on' if (want and self._factor_L is not None) else 'off'
+        if target != state:
+            try:
+                self.engine.cd_set_objective_factor(self._factor_L if target == 'on' else None)
+                self._factor_state = target
+            except EngineError as ex:
+                if ex.code != E_UNSUPPORTED:
+                    raise
+                log.info('coord_descent: objective factor not used (%s)', ex)
+                self._factor_L = None
+
     # ------------------------------------------------------------------ improve
     def _improve(self, method, *args, **kwargs):
         x0 = flatten_vars(self.prob.variables(), self.n)
@@ -288,6 +316,7 @@ class QCQP(object):
                 batches = (1, self.engine.pop_size, first_index)
             out = None
             if batches is not None:
+                self._objective_factor(kwargs.get('factor', True))
                 # population streaming: K batches of R restarts in ONE persistent launch (qcqpmi_cd_stream_run); families the
                 # lifecycle kernel does not take run as one population of K R restarts -- the same restarts either way
                 Kb, Rb, first_index = batches

@@ -191,6 +191,8 @@ struct qcqpmi_ctx {
     double *l2_scratch = nullptr; size_t l2_scratch_cap = 0;
     double *l2_D = nullptr, *l2_S = nullptr;
     int *l2_abort = nullptr;
+    // factored objective P0 = L L^T (qcqpmi_cd_set_objective_factor): L (n16 x 16 lr_RB, zero-padded) and its fragment packs
+    double *lr_L = nullptr, *lr_G = nullptr, *lr_U = nullptr; int lr_RB = 0;
     int life_version = 0;        // qcqpmi_cd_life_version: 0 = the faster one for the shape, 2 = cd_life_kernel wherever it applies, 1 = cd_phase2_qs_kernel<lifecycle> only
     long long *d_life_prof = nullptr;
     int64_t *d_bestK_idx = nullptr; double *d_bestK_key = nullptr, *d_bestK_x = nullptr; int64_t bestK_cap = 0;
@@ -733,7 +735,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm, c->d_comm_big,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key, c->d_bestK_x, c->l2_scratch, c->l2_D, c->l2_S, c->l2_abort};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key, c->d_bestK_x, c->l2_scratch, c->l2_D, c->l2_S, c->l2_abort, c->lr_L, c->lr_G, c->lr_U};
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1480,7 +1482,7 @@ int qcqpmi_cd_dense_block_step(qcqpmi_ctx *c, int phase, int64_t sweep, int64_t 
 // buffers of cd_life_kernel: the workgroups' X tiles, the staged diagonal blocks (packed once per problem), the watchdog word
 static int cd_life2_reserve(qcqpmi_ctx *c, int nmw, int cus) {
     int rc;
-    const size_t need = (size_t)cd_life2_max_wgs(nmw, cus) * (size_t)c->n16 * 16;
+    const size_t need = (size_t)cd_life2_max_wgs(nmw, cus, 1) * (size_t)c->n16 * 16;      // (two tiles per workgroup: half the workgroups, the same tiles)
     if (need > c->l2_scratch_cap) {
         if (c->l2_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0; }
         if ((rc = dev_alloc(c, &c->l2_scratch, need))) return rc;
@@ -1521,7 +1523,11 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     // 0.82 at 512, 0.92 at 768, 1.01 at 896, 1.12 at 1024 -- at full width its multiplying waves (20 blocks of the contraction each,
     // two streams per SIMD) are the bound while the round-4 kernel's eight waves split one tile's product six ways.  So: the round-4
     // kernel from n = 960 on when the run has more restarts than both kernels have slots, cd_life_kernel everywhere else.
-    if (use2 && c->life_version == 0 && eligible && c->n16 >= 960 && K * R > 8192) use2 = false;
+    // factored objective (qcqpmi_cd_set_objective_factor): cd_life_kernel's products through Y = L^T X -- half the matrix work and less
+    // per block interval, a positive diagonal (band / gen kinds), three multiplying waves per tile
+    const bool lr = use2 && c->lr_RB > 0 && nmw == 3 && kind != L2_KIND_LIN && c->life_version != 3 && cd_life2_factor_ok(c->dp, 16 * (int64_t)c->lr_RB);
+    if (lr) cs2 = 0;
+    if (use2 && !lr && c->life_version == 0 && eligible && c->n16 >= 960 && K * R > 8192) use2 = false;
     if (!use2) {
         if (!eligible)
             return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernels need separable constraints of ONE class with one constraint per "
@@ -1553,8 +1559,10 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     if (use2) {
         if ((rc = cd_life2_reserve(c, nmw, cus))) return rc;
-        int64_t wgs = (K * R + 15) / 16;
-        const int maxw = cd_life2_max_wgs(nmw, cus);
+        if (!lr && (c->dbg & 128)) { const int k2 = (c->dbg >> 8) & 7; if (nmw == 3 && (k2 == 0 || k2 == 2 || k2 == 4) && k2 < (int)(c->n16 / 16)) cs2 = k2; }
+        const int tiles = cd_life2_tiles(c->dp, nmw, cs2, K * R, cus, 0, lr ? 1 : 0);
+        int64_t wgs = (K * R + 16 * tiles - 1) / (16 * tiles);
+        const int maxw = cd_life2_max_wgs(nmw, cus, tiles);
         if (wgs > maxw) wgs = maxw;
         if (c->dbg & 1024) { const int lim = (c->dbg >> 12) & 1023; if (lim > 0 && wgs > lim) wgs = lim; }     // debug knob: workgroups of the launch
         CdLife2Args qa;
@@ -1562,13 +1570,13 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         cd_queue_fill_batch(c, qa.b, seed, first_index);
         qa.b.R = K * R;
         qa.scratch = c->l2_scratch; qa.Dpack = c->l2_D; qa.Spack = c->l2_S; qa.abort = c->l2_abort; qa.fbound = c->fbound; qa.dbg = (c->dbg & 2048) ? 1 : 0;
-        if (c->dbg & 128) { const int k2 = (c->dbg >> 8) & 7; if (nmw == 3 && (k2 == 0 || k2 == 2 || k2 == 4) && k2 < (int)(c->n16 / 16)) cs2 = k2; }
+        qa.Gpack = lr ? c->lr_G : nullptr; qa.Upack = lr ? c->lr_U : nullptr; qa.RB = lr ? c->lr_RB : 0;
         (void)hipEventRecord(c->timers[2].beg, c->stream);
-        hipError_t qe = (hipError_t)cd_life2_launch(qa, nmw, cs2, kind, (int)wgs, c->stream);
+        hipError_t qe = (hipError_t)cd_life2_launch(qa, nmw, cs2, kind, tiles, (int)wgs, c->stream);
         (void)hipEventRecord(c->timers[2].end, c->stream);
         c->timers[2].valid = true;
         if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_stream_run: %s", hipGetErrorString(qe));
-        c->last_cd2_kernel = cd_life2_name(nmw, kind);
+        c->last_cd2_kernel = cd_life2_name(nmw, kind, tiles, lr ? 1 : 0);
         int ab = 0;
         HIPCHK(c, hipMemcpyAsync(&ab, c->l2_abort, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1690,8 +1698,33 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
 
 const char *qcqpmi_last_cd_kernel(qcqpmi_ctx *c) { return c ? c->last_cd2_kernel : ""; }
 
+int qcqpmi_cd_set_objective_factor(qcqpmi_ctx *c, const double *L, int64_t r) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (double **p : {&c->lr_L, &c->lr_G, &c->lr_U}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    c->lr_RB = 0;
+    if (!L || r == 0) return 0;                       // cleared
+    if (r < 1 || r > c->n) return fail(c, QCQPMI_EINVAL, "cd_set_objective_factor: r = %lld outside 1 .. n", (long long)r);
+    if (!cd_life2_factor_ok(c->dp, r))
+        return fail(c, QCQPMI_EUNSUPPORTED, "cd_set_objective_factor: the factored lifecycle kernel takes factors of at most 288 columns and n >= 128");
+    const int64_t n = c->n, n16 = c->n16, r16 = (r + 15) / 16 * 16;
+    const int RB = (int)(r16 / 16), NB = (int)(n16 / 16);
+    if ((rc = dev_alloc(c, &c->lr_L, (size_t)n16 * r16))) return rc;      // (zero-filled)
+    if ((rc = dev_alloc(c, &c->lr_G, (size_t)NB * RB * 256, false))) return rc;
+    if ((rc = dev_alloc(c, &c->lr_U, (size_t)NB * RB * 256, false))) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(c->lr_L, (size_t)r16 * sizeof(double), L, (size_t)r * sizeof(double), (size_t)r * sizeof(double), (size_t)n,
+                               hipMemcpyHostToDevice, c->stream));
+    hipError_t e = (hipError_t)cd_life2_pack_factor(c->lr_L, c->lr_G, c->lr_U, NB, RB, c->stream);
+    if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_life2_pack_factor: %s", hipGetErrorString(e));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // (the 2-D copy may still be reading the caller's pages)
+    c->lr_RB = RB;
+    return 0;
+}
+
 int qcqpmi_cd_life_version(qcqpmi_ctx *c, int version) {
-    if (!c || version < 0 || version > 2) return QCQPMI_EINVAL;
+    if (!c || version < 0 || version > 3) return QCQPMI_EINVAL;      // (3: cd_life_kernel without the objective factor)
     c->life_version = version;
     return 0;
 }

@@ -39,21 +39,29 @@ struct CdLife2Args {
     int64_t num_iters;
     double tol;
     const CdLife *life;          // parameters of the run in DEVICE memory
-    double *scratch;             // [workgroups][n16][16]: the workgroups' X tiles
+    double *scratch;             // [workgroups][tiles per workgroup][n16][16]: the workgroups' X tiles
     const double *Dpack;         // [NB][256]: strictly upper triangle of the diagonal blocks of P0 (zeros elsewhere)
     const double *Spack;         // [NB][48]: q0 / 2, 1 / P0[i,i] (0 where the diagonal is 0), P0[i,i] of the block's coordinates
     int *abort;                  // [0] set by a wave whose wait ran into the watchdog (a bug, never the data): the launch unwinds
     double fbound;               // sum |P0| + sum |q0| + |r0|: scale of the objective for the near-tie test of the linear kind
+    // factored objective (P0 = L L^T, L n x r; cd_life2_pack_factor): fragments of L for the products / the updates of Y = L^T X;
+    // RB = blocks of 16 rows of Y (0: not factored)
+    const double *Gpack, *Upack;
+    int RB;
     int dbg;                     // timing experiments (results INVALID when != 0): 1 = every block row reads the fragments of rows 0..7 (an L2-resident stream)
 };
 
 // does the kernel take this problem?  nmw / cs / kind: the instantiation (multiplying waves 3 | 7, chain share, step kind)
 bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, int *nmw, int *cs, int *kind);
-size_t cd_life2_lds_bytes(int nmw);
-int cd_life2_max_wgs(int nmw, int cus);
+size_t cd_life2_lds_bytes(int nmw, int cs, int tiles, int lr);
+bool cd_life2_factor_ok(const DevProblem &P, int64_t r);
+int cd_life2_pack_factor(const double *Lrow, double *Gpack, double *Upack, int NB, int RB, hipStream_t st);
+int cd_life2_max_wgs(int nmw, int cus, int tiles);
+// tiles of 16 slots per workgroup (1 | 2) for a run of `restarts` restarts; requested: 0 = automatic
+int cd_life2_tiles(const DevProblem &P, int nmw, int cs, int64_t restarts, int cus, int requested, int lr);
 // masked diagonal blocks + per-block scalars (device, once per problem)
 int cd_life2_pack(const DevProblem &P, double *Dpack, double *Spack, hipStream_t st);
-int cd_life2_launch(const CdLife2Args &a, int nmw, int cs, int kind, int wgs, hipStream_t st);
-const char *cd_life2_name(int nmw, int kind);
+int cd_life2_launch(const CdLife2Args &a, int nmw, int cs, int kind, int tiles, int wgs, hipStream_t st);
+const char *cd_life2_name(int nmw, int kind, int tiles, int lr);
 
 }  // namespace qcqpmi

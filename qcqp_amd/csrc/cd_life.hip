@@ -123,7 +123,9 @@ __device__ __attribute__((always_inline)) inline v4d_ l2_product(v2d_ (&ar)[2 * 
     return (acc + acc1) + (acc2 + acc3);
 }
 
-// ---- dynamic LDS of a workgroup (doubles), the same view in the kernel and in the role functions:
+// ---- dynamic LDS of a workgroup (doubles), the same view in the kernel and in the role functions.  Shared words first:
+//   ctl 8, simdof 8 (ints: 16), p1cols 16 (ints: 32), jn 8 (ints: the two chains' joint decisions, TILES = 2)
+// then one block PER TILE (a workgroup runs TILES = 1 or 2 tiles of 16 slots; a role works on the block of its tile):
 //   part2   2 NMW 256   partial G tiles (one per multiplying wave), [v][4 r + g], by product parity
 //   fixp    256         the chain wave's own plane (fix-up + its share)
 //   gtile   256         G + q/2 of the block as the chain found it, [c][r]: the generic path's tile
@@ -132,10 +134,23 @@ __device__ __attribute__((always_inline)) inline v4d_ l2_product(v2d_ (&ar)[2 * 
 //   ring    4 x 256     the four blocks committed last, [j][r] (= MFMA B layout k-step by k-step)
 //   cshare  CS x 256    the blocks of the chain wave's own share of the contraction, same layout
 //   slot tables (slack, feasible set, restart id, new / finished flags, outputs), sy: the synchronisation words,
-//   cst: the chain wave's per-lane state between episodes [field][lane], phase-1 words, simdof, par
-#define L2_LDS_VIEW \
+//   cst: the chain wave's per-lane state between episodes [field][lane], phase-1 words, par
+//   LR (factored objective, see l2_mfma_lr_role): ytile L2_YBMAX x 256 -- Y = L^T X of the tile's 16 slots between episodes, [row][slot];
+//   pend 2 x 256 -- the moves of the two blocks a sweep rewrites last, [j][r], until the next episode has applied them
+constexpr int L2_SHARED_DOUBLES = 8 + 8 + 16 + 8;
+constexpr int L2_YBMAX = 18;          // blocks of 16 rows of Y a tile can hold: factor rank <= 288
+constexpr int L2_YU = 6;              // ... per multiplying wave (three per tile)
+constexpr int l2_tile_doubles(int nmw, int csu, int lr) {
+    return 2 * nmw * 256 + 256 + 256 + 2 * 256 + 2 * 48 + 4 * 256 + csu * 256 + 16 + 4 * 16 + 8 + 8 + 8 + 16 * 4 + 8 * 5 + 64 * 10 + 16 * 3 + 8 * 5 + 32 +
+           (lr ? L2_YBMAX * 256 + 2 * 256 : 0);
+}
+#define L2_LDS_VIEW(tile_) \
     extern __shared__ double smem[]; \
-    double *sp = smem; \
+    int *ctl = (int *)smem; \
+    int *simdof = (int *)(smem + 8); \
+    int *p1cols = (int *)(smem + 16); \
+    int *jn = (int *)(smem + 32); \
+    double *sp = smem + L2_SHARED_DOUBLES + (tile_) * l2_tile_doubles(NMW, CSU, LRV); \
     double *part2 = sp; sp += 2 * NMW * 256; \
     double *fixp = sp; sp += 256; \
     double *gtile = sp; sp += 256; \
@@ -159,7 +174,7 @@ __device__ __attribute__((always_inline)) inline v4d_ l2_product(v2d_ (&ar)[2 * 
     int *snew = (int *)sp; sp += 8; \
     int *sfin = (int *)sp; sp += 8; \
     int *ost = (int *)sp; sp += 8; \
-    int *ctl = (int *)sp; sp += 8; \
+    int *gatep = (int *)sp; sp += 8; \
     long long *cst = (long long *)sp; sp += 64 * 10; \
     unsigned long long *sseed = (unsigned long long *)sp; sp += 16; \
     unsigned long long *sfirst = (unsigned long long *)sp; sp += 16; \
@@ -168,16 +183,20 @@ __device__ __attribute__((always_inline)) inline v4d_ l2_product(v2d_ (&ar)[2 * 
     int *p1fin = (int *)sp; sp += 8; \
     int *p1sw = (int *)sp; sp += 8; \
     int *p1st = (int *)sp; sp += 8; \
-    int *gatep = (int *)sp; sp += 8; \
-    int *simdof = (int *)sp; sp += 8; \
-    int *p1cols = (int *)sp; sp += 8; \
-    L2Par *par = (L2Par *)sp; sp += 32;
+    L2Par *par = (L2Par *)sp; sp += 32; \
+    double *ytile = sp; sp += LRV ? L2_YBMAX * 256 : 0; \
+    double *pend = sp; sp += LRV ? 2 * 256 : 0;
+// the same per-slot array of the other tile (every tile block has the same layout)
+template <class T>
+__device__ __attribute__((always_inline)) inline T *l2_tl(T *p, int t, int tile_doubles) { return (T *)((double *)p + t * tile_doubles); }
 
 // parameters the role functions need, in LDS: arguments of a real function call travel in vector registers, i.e. the callee
 // would have to treat NB, the base pointers, ... as lane-dependent (waterfall loops around every buffer descriptor);
 // read from LDS and made wave-uniform explicitly they are scalars again
 struct L2Par {
     const double *Apack, *Apack2, *Dpack, *Spack;
+    const double *Gpack, *Upack;          // LR: fragments of the factor for the products / the updates of Y (cd_life.h)
+    int RB, pad_;                         // LR: blocks of 16 rows of Y
     double *Xg;
     int *next;
     unsigned long long *prof;
@@ -199,12 +218,15 @@ __device__ __attribute__((always_inline)) inline T *l2_uni(T *p) { return (T *)(
 // kernel beside the chain role the two fought over the 256 registers and over the scalar file, and the product loop spilled
 // whenever anything else in the kernel changed)
 template <int NMW, int CS>
-__device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
+__device__ __attribute__((noinline)) void l2_mfma_role(int m_in, int t_in) {
     constexpr int MAXC = 1;
     constexpr int CSU = CS > 0 ? CS : 1;
-    L2_LDS_VIEW
+    constexpr int LRV = 0;
+    const int tile = l2_uni(t_in);                 // the tile of the workgroup this wave multiplies for
+    L2_LDS_VIEW(tile)
+    (void)ytile; (void)pend;
     (void)fixp; (void)gtile; (void)DU2; (void)sc2; (void)cshare; (void)slk; (void)TC; (void)of0; (void)ovis; (void)oacc; (void)oswp; (void)sid; (void)snew;
-    (void)sfin; (void)ost; (void)ctl; (void)cst; (void)sseed; (void)sfirst; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols;
+    (void)sfin; (void)ost; (void)ctl; (void)cst; (void)sseed; (void)sfirst; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols; (void)jn;
     const int lane = threadIdx.x & 63;
     const int m = l2_uni(m_in);
     const double *pApack2 = l2_uni(par->Apack2);
@@ -252,7 +274,7 @@ __device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
     #pragma unroll
     for (int U = 0; U < RQ_PFU; U++) L2_LDA(arP + 2 * U, row * rowstride + (m + ((U < nu) ? NMW * U : 0)) * 2048, vlane)
     int spins = 0;
-    const bool prof_on = pprof != nullptr && m == 0;
+    const bool prof_on = pprof != nullptr && m == 0 && tile == 0;
     long long pw_commit = 0, pw_cons = 0;
     for (int64_t i = 0; i < gmax; i++) {
         const int row2 = (row + 1 == NB) ? 0 : row + 1;
@@ -340,14 +362,171 @@ __device__ __attribute__((noinline)) void l2_mfma_role(int m_in) {
     #undef L2_LDA
 }
 
+
+// =========================================================================== multiplying role, FACTORED objective (round 6)
+// P0 = L L^T with L n x r, r <= 16 L2_YBMAX (Boolean least squares: P0 = A^T A, r = rows of A = n / 4): the product of a block row
+// is  G_b = L[I_b, :] (L^T X)  and the tile's  Y = L^T X  (r x 16, 32 KB at r = 256 against the X tile's 128 KB) is CARRIED:
+// after the chain has committed block b with the moves D_b = X_b(new) - X_b(old),  Y += L[I_b, :]^T D_b.  Per block interval that
+// is 4 r / 16 MFMAs for the product and as many for the update -- 128 at r = 256 -- instead of the 256 - 8 of P0[I_b, :] X.
+//   * wave m of the tile's three owns the blocks beta = m, m + 3, ... of 16 rows of Y, IN ITS ACCUMULATORS: the C layout of a
+//     16 x 16 fp64 tile (lane l, element v: row (l >> 4) + 4 v, column l & 15) is the B layout of its four k-steps, so the same
+//     registers are updated by one MFMA and multiplied by the next;
+//   * association.  Product i (block row i mod NB) is taken with Y as of the commit of interval i - 3 -- the moves of the two
+//     blocks rewritten since are the chain's fix-up, P0[I_b, I_b'] D_b' as before, now on the moves instead of the points --
+//     wherever episodes begin and end: between episodes Y rests in LDS (`ytile`) in exactly the state the product of block row 0
+//     wants (moves up to block NB - 3 applied), the moves of blocks NB - 2 and NB - 1 in `pend`; a new restart's column is
+//     L^T x0 with no pending moves (column build).  A wave that has already applied block NB - 2 when the episode ends wrote
+//     the state down before it did.
+//   * A fragments (pair-packed: k-steps 2 vp, 2 vp + 1 in one 16-byte word): Gpack[b][beta][vp][lane] = L[16 b + (l & 15)][16 beta
+//     + 4 v + (l >> 4)], Upack[b][beta][vp][lane] = L[16 b + 4 v + (l >> 4)][16 beta + (l & 15)]; requested at the top of the
+//     product, ahead of the wait for the commit they do not depend on.
+template <int NMW>
+__device__ __attribute__((noinline)) void l2_mfma_lr_role(int m_in, int t_in) {
+    constexpr int MAXC = 1;
+    constexpr int CSU = 1;
+    constexpr int LRV = 1;
+    constexpr int YU = L2_YU;
+    const int tile = l2_uni(t_in);
+    L2_LDS_VIEW(tile)
+    (void)fixp; (void)gtile; (void)DU2; (void)sc2; (void)cshare; (void)slk; (void)TC; (void)of0; (void)ovis; (void)oacc; (void)oswp; (void)sid; (void)snew;
+    (void)sfin; (void)ost; (void)ctl; (void)cst; (void)sseed; (void)sfirst; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols; (void)jn;
+    const int lane = threadIdx.x & 63;
+    const int m = l2_uni(m_in);
+    const double *pG = l2_uni(par->Gpack), *pU = l2_uni(par->Upack);
+    const int NB = l2_uni(par->NB), RB = l2_uni(par->RB);
+    const int nu = (RB > m) ? (RB - m + NMW - 1) / NMW : 0;       // blocks of Y this wave owns (<= YU)
+    const int64_t gmax = (int64_t)1 << 40;         // the role ends through RQ_STOP
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(pG), 0, NB * RB * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(pU), 0, NB * RB * 2048, 0x00020000);
+    const unsigned vlane = (unsigned)lane * 16u;
+    typedef unsigned rq_u4 __attribute__((ext_vector_type(4)));
+    #define L2_LDF(dst, rs, soff) { const rq_u4 t0_ = __builtin_amdgcn_raw_buffer_load_b128(rs, vlane, (soff), 0);           \
+                                    const rq_u4 t1_ = __builtin_amdgcn_raw_buffer_load_b128(rs, vlane + 1024u, (soff), 0);   \
+                                    (dst)[0] = __builtin_bit_cast(v2d_, t0_); (dst)[1] = __builtin_bit_cast(v2d_, t1_); }
+    typedef __attribute__((address_space(3))) double rq_lds_d;
+    typedef __attribute__((address_space(3))) const double rq_lds_cd;
+    const int yoff = (lane >> 4) * 16 + (lane & 15);
+    rq_lds_d *ybase = (rq_lds_d *)(ytile + yoff);
+    rq_lds_cd *rbase = (rq_lds_cd *)(ring + lane);
+    rq_lds_cd *pbase = (rq_lds_cd *)(pend + lane);
+    asm volatile("" : "+v"(ybase), "+v"(rbase), "+v"(pbase));
+    v4d_ y[YU];
+    #pragma unroll
+    for (int u = 0; u < YU; u++)
+    #pragma unroll
+        for (int v = 0; v < 4; v++) y[u][v] = (u < nu) ? ybase[(16 * (m + NMW * u) + 4 * v) * 16] : 0.0;
+    auto save_y = [&]() {
+    #pragma unroll
+        for (int u = 0; u < YU; u++)
+            if (u < nu) {
+    #pragma unroll
+                for (int v = 0; v < 4; v++) ybase[(16 * (m + NMW * u) + 4 * v) * 16] = y[u][v];
+            }
+    };
+    int row = 0, spins = 0;
+    int yrow = 0;                                  // Y holds the moves up to block yrow - 3 (what the product of block row yrow wants)
+    int64_t iy = 0;                                // ... applied for product iy
+    for (int64_t i = 0; i < gmax; i++) {
+        const int row2 = (row + 1 == NB) ? 0 : row + 1;
+        const int ub = row >= 3 ? row - 3 : row - 3 + NB;      // the block whose moves this product applies first
+        v2d_ aU[YU][2], aG[YU][2];
+    #pragma unroll
+        for (int u = 0; u < YU; u++)
+            if (u < nu) {      // wave-uniform
+                L2_LDF(aU[u], ursrc, (ub * RB + m + NMW * u) * 2048)
+                L2_LDF(aG[u], grsrc, (row * RB + m + NMW * u) * 2048)
+            }
+        bool stop = false;
+        if (i >= 3) {
+            for (;;) {
+                const rq_i4 s4 = rq_sync_read(sy);
+                if (s4[RQ_STOP]) { stop = true; break; }
+                if (s4[RQ_COMMIT] >= (int)i - 2) break;
+                if (++spins > L2_WD) { stop = true; rq_sync_write(sy, L2_ABORT, 1, lane); rq_sync_write(sy, RQ_STOP, 1, lane); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (stop) break;
+            spins = 0;
+        }
+        if (i >= 1) {
+            if (row == 1) save_y();                // the state between episodes: before the moves of block NB - 2 go in
+            rq_lds_cd *src = (i >= 3) ? rbase + (int)((i - 3) & 3) * 256 : pbase + (int)(i - 1) * 256;
+            double bd[4];
+    #pragma unroll
+            for (int q = 0; q < 4; q++) bd[q] = src[q * 64];
+    #pragma unroll
+            for (int v = 0; v < 4; v++)
+    #pragma unroll
+                for (int u = 0; u < YU; u++)
+                    if (u < nu) y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[u][v >> 1][v & 1], bd[v], y[u], 0, 0, 0);
+            yrow = row; iy = i;
+        }
+        v4d_ acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc;
+    #pragma unroll
+        for (int u = 0; u < YU; u++)
+            if (u < nu) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aG[u][0][0], y[u][0], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aG[u][0][1], y[u][1], acc1, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aG[u][1][0], y[u][2], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aG[u][1][1], y[u][3], acc1, 0, 0, 0);
+            }
+        acc = acc + acc1;
+        if (i >= 2) {
+            for (;;) {
+                const rq_i4 s4 = rq_sync_read(sy);
+                if (s4[RQ_STOP]) { stop = true; break; }
+                if (s4[RQ_CONS] >= (int)i - 1) break;
+                if (++spins > L2_WD) { stop = true; rq_sync_write(sy, L2_ABORT, 1, lane); rq_sync_write(sy, RQ_STOP, 1, lane); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (stop) break;
+            spins = 0;
+        }
+        {
+            double *part = part2 + (int)(i & 1) * NMW * 256 + m * 256;
+    #pragma unroll
+            for (int v = 0; v < 4; v++) part[v * 64 + (lane & 15) * 4 + (lane >> 4)] = acc[v];
+        }
+        rq_sync_write(sy, RQ_PARTS + m, (int)i + 1, lane);
+        row = row2;
+    }
+    // ---- leave Y in the state the next episode's first product wants (see the header): an episode that ended at a sweep
+    // boundary finds this wave one product behind (apply block NB - 3), on it, or one ahead (already written down)
+    // (a wave may even be TWO ahead: product g + 3 passes its commit wait -- block NB - 1 is committed -- and applies its moves
+    //  before it stops at the slot wait; rows 1 and 2 both find the state written down at row 1)
+    if (yrow == NB - 1 && iy >= 3) {
+        v2d_ aU[YU][2];
+    #pragma unroll
+        for (int u = 0; u < YU; u++)
+            if (u < nu) L2_LDF(aU[u], ursrc, ((NB - 3) * RB + m + NMW * u) * 2048)
+        rq_lds_cd *src = rbase + (int)((iy - 2) & 3) * 256;
+        double bd[4];
+    #pragma unroll
+        for (int q = 0; q < 4; q++) bd[q] = src[q * 64];
+    #pragma unroll
+        for (int v = 0; v < 4; v++)
+    #pragma unroll
+            for (int u = 0; u < YU; u++)
+                if (u < nu) y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[u][v >> 1][v & 1], bd[v], y[u], 0, 0, 0);
+        save_y();
+    } else if (yrow == 0) {
+        save_y();
+    }
+    #undef L2_LDF
+}
+
 // ========================================================================== chain role (a real function as well)
-template <int NMW, int CS, int KIND>
-__device__ __attribute__((noinline)) void l2_chain_role() {
+template <int NMW, int CS, int KIND, int TILES, int LR>
+__device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
     constexpr int MAXC = 1;
     constexpr int CSU = CS > 0 ? CS : 1;
+    constexpr int LRV = LR;                        // factored objective (l2_mfma_lr_role): the ring carries the block's MOVES, no share
+    static_assert(!LR || CS == 0, "factored objective: the chain has no share of the contraction");
     constexpr bool PRE = KIND == L2_KIND_LIN;      // a restart's phase 2 starts with a frozen sweep that evaluates f0
-    L2_LDS_VIEW
-    (void)slk; (void)snew; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols;
+    const int tile = TILES > 1 ? l2_uni(t_in) : 0; // the tile whose 16 slots this chain steps
+    L2_LDS_VIEW(tile)
+    (void)ytile; (void)pend;
+    (void)slk; (void)snew; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols; (void)jn;
     const int lane = threadIdx.x & 63, r = lane >> 2, gq = lane & 3;
     LG const double *Apk = l2_g(l2_uni(par->Apack));
     LG const double *Apk2 = l2_g(l2_uni(par->Apack2));
@@ -396,6 +575,11 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
     // phase 2, or -- linear kind, where the reference's end-point comparison works on rounded absolute values --
     // from f0 evaluated by a frozen sweep before the first real one (`pre`).
     bool frz = (cst[7 * 64 + lane] & 1) != 0, done = (cst[7 * 64 + lane] & 2) != 0, pre = PRE && (cst[7 * 64 + lane] & 4) != 0;
+    // factored objective: a restart's first sweep in its slot LOADS it -- Y = L^T x0 is what the products' own updates make of
+    // "every block moves from 0 to x0": no decisions, no counters, the block's moves are the points themselves; the sweeps start
+    // (or the frozen sweep of a restart that did not pass the gate) at the next boundary.  A sweep of the slot instead of a pass
+    // over L per starting column (2 MB from L2 / Infinity Cache each: measured 24 % of the workgroups' time).
+    bool ld = LR && (cst[7 * 64 + lane] & 8) != 0;
     double facc = __longlong_as_double(cst[8 * 64 + lane]);
     const bool occupied = sid[r] >= 0;
     const RqOwn cown = l2_own(NB, CS, -1, NMW);
@@ -424,8 +608,10 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
             f0a[u] = Apk[((int64_t)0 * KS + 4 * bl2 + u) * 64 + lane];
             f0b[u] = Apk[((int64_t)0 * KS + 4 * bl1 + u) * 64 + lane];
             f1b[u] = Apk[((int64_t)1 * KS + 4 * bl1 + u) * 64 + lane];
-            x2[u] = Xg[(4 * bl2 + u) * 64 + lane];
-            x1[u] = Xg[(4 * bl1 + u) * 64 + lane];
+            // (factored objective: the products carry Y with the moves up to block NB - 3; the chain supplies the MOVES of the two
+            //  blocks after it -- zero for a restart that starts here)
+            x2[u] = LR ? pend[u * 64 + lane] : Xg[(4 * bl2 + u) * 64 + lane];
+            x1[u] = LR ? pend[256 + u * 64 + lane] : Xg[(4 * bl1 + u) * 64 + lane];
         }
     #pragma unroll
         for (int u = 0; u < 4; u++) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0a[u], x2[u], c0, 0, 0, 0);
@@ -461,7 +647,9 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
     if (prof_on) { ptl = (long long)__builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(pprof + 18, (unsigned long long)(ptl - *(long long *)(ctl + 6))); }
     int pn_int = 0, pn_gen = 0;
 #define L2_TICK(acc) if (prof_on) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); acc += now_ - ptl; ptl = now_; }
+    int64_t last_g = 0;
     for (int64_t g = 0; g < gmax; g++) {
+        last_g = g;
         const int bn = (b + 1 == NB) ? 0 : b + 1, bn2 = (bn + 1 == NB) ? 0 : bn + 1;
         const int bprev = (b == 0) ? NB - 1 : b - 1;
         const int cur = (int)(g & 1);
@@ -612,14 +800,14 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
                 }
                 facc = (cl >= 0 ? 0.0 : facc) + w;
                 if (over >= 0) done = true;
-            } else if (frz || pre) {
+            } else if ((frz || pre) && !ld) {
                 double w = 0.0;
 #pragma unroll
                 for (int v = 0; v < 4; v++) w = __builtin_fma(xo[v], gb[v] + hq4[v], w);
                 facc += w;
             }
 #pragma unroll
-            for (int v = 0; v < 4; v++) rb[(4 * v + gq) * 16 + r] = xn[v];
+            for (int v = 0; v < 4; v++) rb[(4 * v + gq) * 16 + r] = LR ? (ld ? xo[v] : xn[v] - xo[v]) : xn[v];
         };
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo) == 0ull, 1)) {
             fast_commit();
@@ -675,6 +863,10 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
                 if (S.conv) done = true;
 #pragma unroll
                 for (int v = 0; v < 4; v++) xn[v] = rb[(4 * v + gq) * 16 + r];
+                if (LR) {
+#pragma unroll
+                    for (int v = 0; v < 4; v++) rb[(4 * v + gq) * 16 + r] = xn[v] - xo[v];
+                }
             }
         }
         // the block goes to the global tile as well (the next sweep's prefetch, the next episode's operands, the result)
@@ -683,7 +875,8 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
         rq_sync_write(sy, RQ_COMMIT, (int)g + 1, lane);   // block b is in the ring
         L2_TICK(pt_end)
         if (b == NB - 1) {
-            if (frz) { frz = false; done = true; }        // the frozen sweep is complete
+            if (ld) { ld = false; if (!frz) S.conv = false; }      // loaded: the restart starts sweeping (or takes its frozen sweep) with the next block
+            else if (frz) { frz = false; done = true; }   // the frozen sweep is complete
             if (PRE && pre) {
                 // f0 at the start of phase 2: the restart starts sweeping with the next block
                 const double f0s = rq_quad_sum(facc) + P.r0;
@@ -691,17 +884,49 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
                 facc = 0.0; pre = false; S.conv = false;
             }
         }
-        const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv || frz || pre);
-        if (livem == 0ull) break;
-        if (b == NB - 1) {
-            // sweep boundary: slots whose restart is done can take a new restart -- end the episode if the queue has one
-            const bool fin = !occupied || done;
-            const unsigned long long finm = __builtin_amdgcn_ballot_w64(fin);
-            if (finm == ~0ull) break;
-            if (finm != 0ull) {
-                const bool more = l2_load_int(pnext) < pRtotal;
-                if (more) break;
+        const unsigned long long livem = __builtin_amdgcn_ballot_w64(!S.conv || frz || pre || ld);
+        if (TILES == 1) {
+            if (livem == 0ull) break;
+            if (b == NB - 1) {
+                // sweep boundary: slots whose restart is done can take a new restart -- end the episode if the queue has one
+                const bool fin = !occupied || done;
+                const unsigned long long finm = __builtin_amdgcn_ballot_w64(fin);
+                if (finm == ~0ull) break;
+                if (finm != 0ull) {
+                    const bool more = l2_load_int(pnext) < pRtotal;
+                    if (more) break;
+                }
             }
+        } else if (b == NB - 1) {
+            // Two tiles per workgroup: the episode ends for BOTH chains at the same sweep boundary (the build and the write-out
+            // are the workgroup's).  Once per sweep the chain of tile 1 posts what it sees -- something live, all slots finished,
+            // some slot finished -- and waits for the verdict; the chain of tile 0 adds its own, reads the queue ONCE (two reads
+            // could disagree) and posts the verdict.  Words carry the sweep number of the episode: nothing to reset in between.
+            // (A tile with nothing live waits for the boundary instead of leaving mid-sweep: its slots are idle either way.)
+            const unsigned long long finm = __builtin_amdgcn_ballot_w64(!occupied || done);
+            const int mine = (livem != 0ull ? 1 : 0) | (finm == ~0ull ? 2 : 0) | (finm != 0ull ? 4 : 0);
+            const int tag = ((int)(g / NB) + 1) << 8;
+            rq_lds_int *jw = (rq_lds_int *)jn;
+            int verdict = 0;
+            if (tile == 1) rq_sync_write(jw, 1, tag | mine, lane);
+            for (;;) {
+                int w = *(volatile rq_lds_int *)(jw + (tile == 1 ? 0 : 1));
+                asm volatile("" ::: "memory");
+                w = __builtin_amdgcn_readfirstlane(w);
+                if ((w & ~0xff) == tag) { verdict = w & 0xff; break; }
+                if (++spins > L2_WD) { wdog = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (wdog) { rq_sync_write(sy, L2_ABORT, 1, lane); break; }
+            spins = 0;
+            if (tile == 0) {
+                const int both = mine | verdict, all = mine & verdict;
+                bool stop = !(both & 1) || (all & 2);
+                if (!stop && (both & 4)) stop = l2_load_int(pnext) < pRtotal;
+                rq_sync_write(jw, 0, tag | (stop ? 1 : 0), lane);
+                verdict = stop ? 1 : 0;
+            }
+            if (verdict & 1) break;
         }
         // ---- the chain's part of the next products: the block just committed times the fragments of the next TWO block
         // rows, and its own share of the next row
@@ -743,6 +968,16 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
         b = bn;
     }
 #undef L2_TICK
+    if (LR) {
+        // the moves of the two blocks committed last (blocks NB - 2 and NB - 1 when the episode ended at a sweep boundary; nothing
+        // that continues otherwise) stay for the next episode: its products apply them, its chain starts from them
+        const int g1 = (int)((last_g - 1) & 3), g0 = (int)(last_g & 3);
+        double p1v[4], p0v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { p1v[u] = ring[g1 * 256 + u * 64 + lane]; p0v[u] = ring[g0 * 256 + u * 64 + lane]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { pend[u * 64 + lane] = p1v[u]; pend[256 + u * 64 + lane] = p0v[u]; }
+    }
     rq_sync_write(sy, RQ_STOP, 1, lane);
     if (prof_on && lane == 0) {
         atomicAdd(pprof + 13, (unsigned long long)pt_sum);
@@ -759,7 +994,7 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
         cst[0 * 64 + lane] = S.upd_counter; cst[1 * 64 + lane] = S.visits; cst[2 * 64 + lane] = S.accepted;
         cst[3 * 64 + lane] = S.sweeps; cst[4 * 64 + lane] = S.conv ? 1 : 0; cst[5 * 64 + lane] = S.status;
         cst[6 * 64 + lane] = __double_as_longlong(fpart);
-        cst[7 * 64 + lane] = (frz ? 1 : 0) | (done ? 2 : 0) | (pre ? 4 : 0);
+        cst[7 * 64 + lane] = (frz ? 1 : 0) | (done ? 2 : 0) | (pre ? 4 : 0) | (ld ? 8 : 0);
         cst[8 * 64 + lane] = __double_as_longlong(facc);
         const double ftot = rq_quad_sum(facc) + P.r0;
         const bool fin = occupied && done;
@@ -771,40 +1006,53 @@ __device__ __attribute__((noinline)) void l2_chain_role() {
     __builtin_amdgcn_s_setprio(0);
 }
 
-// NMW: multiplying waves (3: four-wave workgroup, two per CU; 7: eight waves, one per CU, 1024 < n <= 2304 -- the eighth
-//      wave multiplies too, beside the chain on SIMD 0)
+// NMW: multiplying waves per tile (3: a chain wave + three multiplying waves per tile; 7: eight waves, one per CU, 1024 < n <= 2304
+//      -- the eighth wave multiplies too, beside the chain on SIMD 0)
 // CS : blocks of the contraction the chain wave multiplies itself
 // KIND: L2_KIND_BAND / GEN / LIN (cd_life.h)
-template <int NMW, int CS, int KIND>
-__global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife2Args a0) {
+// TILES: tiles of 16 slots per workgroup.  1: four-wave workgroups, two per CU (NMW = 3), or one eight-wave workgroup (NMW = 7).
+//      2 (round 6, NMW = 3 only): ONE eight-wave workgroup per CU runs two tiles -- both chains on SIMD 0, a product stream per
+//      tile on each of SIMDs 1-3, exactly what two TILES = 1 workgroups on a CU do while both are in their roles -- but the
+//      episode is the workgroup's: the columns of both tiles are built by all 512 threads on a CU whose matrix pipes are idle
+//      (the TILES = 1 build runs under the neighbour's product streams: 18 % of a workgroup's time against 10 %), and no tile
+//      ever runs alone at the pace of a lone chain.  Per restart nothing changes: same roles, same arithmetic, same association.
+template <int NMW, int CS, int KIND, int TILES, int LR>
+__global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_life_kernel(CdLife2Args a0) {
     const CdLife2Args &a = a0;
     constexpr int MAXC = 1;
     constexpr int CSU = CS > 0 ? CS : 1;
-    constexpr int NT = NMW == 3 ? 256 : 512;
+    constexpr int LRV = LR;                        // factored objective P0 = L L^T (l2_mfma_lr_role)
+    constexpr int NT = (NMW == 3 && TILES == 1) ? 256 : 512;
     constexpr int NW = NT / 64;
+    constexpr int NS = 16 * TILES;                 // slots of the workgroup
+    constexpr int TD = l2_tile_doubles(NMW, CSU, LR);  // doubles of one tile's LDS block
+    static_assert(!LR || (NMW == 3 && CS == 0 && KIND != L2_KIND_LIN), "factored objective: three multiplying waves per tile, no chain share, a positive diagonal");
     constexpr bool PRE = KIND == L2_KIND_LIN;      // a restart's phase 2 starts with a frozen sweep that evaluates f0 (see the chain role)
+    static_assert(TILES == 1 || NMW == 3, "two tiles per workgroup: eight waves = two chains + two x three multiplying waves");
     const DevProblem &P = a.P;
     const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int64_t n16 = P.n16;
     const int NB = (int)P.NB, KS = (int)P.KS;
-    L2_LDS_VIEW
-    LG double *Xg = l2_g(a0.scratch) + (int64_t)blockIdx.x * n16 * 16;       // this workgroup's X tile [j][16]
+    L2_LDS_VIEW(0)                                  // tile 0's block; tile t: l2_tl(array, t, TD)
+    (void)fixp; (void)gtile; (void)DU2; (void)sc2; (void)ring; (void)cshare; (void)of0; (void)ovis; (void)oacc; (void)oswp; (void)ost; (void)ytile; (void)pend;
+    LG double *Xg0 = l2_g(a0.scratch) + (int64_t)blockIdx.x * TILES * n16 * 16;       // this workgroup's X tiles [tile][j][16]
 
     // ---- roles by hardware SIMD.  The dispatcher deals the waves of a workgroup round robin over the four SIMDs starting
     // wherever the CU's pointer stands (measured, tools/ubench/ubench5.hip: wave w of a four-wave workgroup is NOT on SIMD w).
-    // Two workgroups share a CU: both chains go to SIMD 0 (two latency-bound waves interleave well), the product streams to
-    // SIMDs 1-3.  If the waves do not cover the SIMDs evenly the roles fall back to the wave index (slower, equally correct).
+    // Both chains of a CU go to SIMD 0 (two latency-bound waves interleave well), the product streams to SIMDs 1-3.
+    // If the waves do not cover the SIMDs evenly the roles fall back to the wave index (slower, equally correct).
     if ((tid0 & 63) == 0) simdof[wave] = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)));       // HW_ID[5:4]
-    if (tid0 < 64) {
+    if (tid0 < 64 * TILES) {
+        long long *cs_ = l2_tl(cst, tid0 >> 6, TD);
 #pragma unroll
-        for (int f = 0; f < 10; f++) cst[f * 64 + tid0] = (f == 4) ? 1 : 0;
+        for (int f = 0; f < 10; f++) cs_[f * 64 + (tid0 & 63)] = (f == 4) ? 1 : 0;
     }
-    if (tid0 < 16) { sid[tid0] = -1; sfin[tid0] = 0; }
+    if (tid0 < NS) { l2_tl(sid, tid0 >> 4, TD)[tid0 & 15] = -1; l2_tl(sfin, tid0 >> 4, TD)[tid0 & 15] = 0; }
     LG const CdLife *lf0 = l2_g(a0.life);
     const long long life_t0 = (tid0 == 0 && lf0->prof) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     __syncthreads();
-    int role;                                      // 0 chain, 1 .. NMW multiplying wave role - 1
+    int role, rtile = 0;                           // role: 0 chain, 1 .. NMW multiplying wave role - 1; rtile: the tile it works for
     {
         int cnt[4] = {0, 0, 0, 0};
         int rank = 0;
@@ -817,22 +1065,26 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
             rank += (s == mys && w < wave) ? 1 : 0;
         }
         const bool even = cnt[0] == NW / 4 && cnt[1] == NW / 4 && cnt[2] == NW / 4 && cnt[3] == NW / 4;
-        if (NMW == 3) role = even ? mys : wave;
+        if (NMW == 3 && TILES == 1) role = even ? mys : wave;
+        else if (TILES == 2) { role = even ? mys : (wave & 3); rtile = even ? rank : (wave >> 2); }      // SIMD s: the waves of role s of both tiles
         else if (even) role = (mys == 0) ? (rank == 0 ? 0 : 7) : mys + 3 * rank;      // SIMD s: waves s (, s + 3); SIMD 0: the chain and wave 7
         else role = wave;
         role = __builtin_amdgcn_readfirstlane(role);
+        rtile = __builtin_amdgcn_readfirstlane(rtile);
         if (tid0 == 0 && lf0->prof) {                // debug: workgroups whose waves covered the SIMDs evenly / the CU they sat on
             if (even) atomicAdd((unsigned long long *)lf0->prof + 6, 1ull);
             const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
-            l2_g(a0.scratch)[(int64_t)blockIdx.x * n16 * 16] = (double)(((xcc & 15) << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15));   // overwritten by the first column build
+            Xg0[0] = (double)(((xcc & 15) << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15));   // overwritten by the first column build
         }
     }
     const int nlast = (int)(P.n - 16 * (int64_t)(NB - 1));      // real coordinates of the last block (1..16)
-    if (tid0 == 0) {
-        par->Apack = P.Apack; par->Apack2 = P.Apack2; par->Dpack = a0.Dpack; par->Spack = a0.Spack;
-        par->Xg = a0.scratch + (int64_t)blockIdx.x * n16 * 16; par->next = a0.b.next; par->prof = (unsigned long long *)lf0->prof;
-        par->num_iters = a.num_iters; par->n16 = n16; par->tol = a.tol; par->r0 = P.r0; par->fbound = a.fbound;
-        par->NB = NB; par->KS = KS; par->n = (int)P.n; par->nlast = nlast; par->Rtotal = (int)lf0->Rtotal; par->dbg = a0.dbg;
+    if (tid0 < TILES) {
+        L2Par *pr = l2_tl(par, tid0, TD);
+        pr->Apack = P.Apack; pr->Apack2 = P.Apack2; pr->Dpack = a0.Dpack; pr->Spack = a0.Spack;
+        pr->Gpack = a0.Gpack; pr->Upack = a0.Upack; pr->RB = a0.RB; pr->pad_ = 0;
+        pr->Xg = a0.scratch + ((int64_t)blockIdx.x * TILES + tid0) * n16 * 16; pr->next = a0.b.next; pr->prof = (unsigned long long *)lf0->prof;
+        pr->num_iters = a.num_iters; pr->n16 = n16; pr->tol = a.tol; pr->r0 = P.r0; pr->fbound = a.fbound;
+        pr->NB = NB; pr->KS = KS; pr->n = (int)P.n; pr->nlast = nlast; pr->Rtotal = (int)lf0->Rtotal; pr->dbg = a0.dbg;
     }
     __syncthreads();
 
@@ -843,41 +1095,44 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
         asm volatile("" : "+v"(tid));
         const CdLife *lifep = a0.life;
         asm volatile("" : "+s"(lifep));
-        const int lane = tid & 63, r = lane >> 2, gq = lane & 3;
+        const int lane = tid & 63, r = lane >> 2;
         // ================================================================ refill: free slots take the next restarts
-        if (tid == 0) ctl[0] = 0;
+        if (tid == 0) { ctl[0] = 0; jn[0] = 0; jn[1] = 0; }
         __syncthreads();
-        if (tid < 16) {
-            int id = sid[tid], nw = 0;
+        if (tid < NS) {
+            const int st = tid >> 4, sc = tid & 15;          // slot sc of tile st
+            int id = l2_tl(sid, st, TD)[sc], nw = 0;
             if (id < 0) {
                 LG const CdLife *lf = l2_g(lifep);
                 const int idx = l2_add(l2_g(a0.b.next), 1);
                 if (idx < (int)lf->Rtotal) {
                     id = idx; nw = 1;
                     const uint64_t pop = (uint64_t)idx / (uint64_t)lf->Rpop, rho = (uint64_t)idx % (uint64_t)lf->Rpop;
-                    sseed[tid] = lf->seed + pop * lf->seed_stride;
-                    sfirst[tid] = lf->first_index + pop * lf->first_stride + rho - (uint64_t)idx;    // + id = the global restart index
+                    l2_tl(sseed, st, TD)[sc] = lf->seed + pop * lf->seed_stride;
+                    l2_tl(sfirst, st, TD)[sc] = lf->first_index + pop * lf->first_stride + rho - (uint64_t)idx;    // + id = the global restart index
                 }
             }
-            sid[tid] = id; snew[tid] = nw;
-            if (nw) { p1fin[tid] = 0; p1sw[tid] = 0; p1st[tid] = 0; gatep[tid] = 0; }
+            l2_tl(sid, st, TD)[sc] = id; l2_tl(snew, st, TD)[sc] = nw;
+            if (nw) { l2_tl(p1fin, st, TD)[sc] = 0; l2_tl(p1sw, st, TD)[sc] = 0; l2_tl(p1st, st, TD)[sc] = 0; l2_tl(gatep, st, TD)[sc] = 0; }
             if (id < 0) {
                 // an empty slot: a zero column that never moves (feasible set of slack 0, restart marked converged)
-                slk[tid] = 0.0;
+                l2_tl(slk, st, TD)[sc] = 0.0;
                 FeasSet<MAXC> C;
                 compute_set<MAXC>(P, P.krep[0], 0.0, C);
-                store_set<MAXC>(TC, tid, C);
+                SetTable<MAXC> T2 = TC;
+                T2.lo = l2_tl(TC.lo, st, TD); T2.hi = l2_tl(TC.hi, st, TD); T2.n = l2_tl(TC.n, st, TD); T2.slow = l2_tl(TC.slow, st, TD);
+                store_set<MAXC>(T2, sc, C);
             }
             if (id >= 0) atomicAdd(&ctl[0], 1);
+            *(volatile rq_lds_int *)(l2_tl((int *)sy, st, TD) + sc) = (sc >= RQ_PARTS + NMW) ? 0x7fffffff : 0;
         }
-        if (tid < 16) *(volatile rq_lds_int *)(sy + tid) = (tid >= RQ_PARTS + NMW) ? 0x7fffffff : 0;
         __syncthreads();
         if (ctl[0] == 0) break;                    // nothing left anywhere: done
         {
             // ---- build the columns of the restarts just taken: suggest(RANDOM) (qcqp.py:381-382: keyed normals, the stream
             // of randn_tiles_kernel) or the resident point, phase 1 (qcqp.py:101-149 through the visit of cd_phase1_sep.h), the
-            // max violation = slack of phase 2 (qcqp.py:157) and the gate (qcqp.py:189).  The tile lives in global memory;
-            // every thread only ever touches its own elements between two barriers.
+            // max violation = slack of phase 2 (qcqp.py:157) and the gate (qcqp.py:189).  The tiles live in global memory;
+            // every thread only ever touches its own elements between two barriers.  Columns are named 16 tile + slot.
             // (priority over the neighbour workgroup's product streams: a double-precision instruction of the build otherwise
             //  waits for a whole matrix instruction of the other stream every time -- the build is latency, the streams have slack)
             __builtin_amdgcn_s_setprio(3);
@@ -888,19 +1143,22 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
             const int e0 = P.cptr[P.krep[0]];
             const double cp = P.cp[e0], cq = P.cq[e0], cr = P.cr[e0];
             const int rel = P.crel[e0];
-            for (int c = 0; c < 16; c++) {
-                if (!snew[c]) {
-                    if (sid[c] < 0) for (int64_t j = tid; j < n16; j += NT) Xg[j * 16 + c] = 0.0;
+            for (int c = 0; c < NS; c++) {
+                const int ct = c >> 4, cc = c & 15;
+                LG double *Xg = Xg0 + (int64_t)ct * n16 * 16;
+                if (!l2_tl(snew, ct, TD)[cc]) {
+                    if (l2_tl(sid, ct, TD)[cc] < 0) for (int64_t j = tid; j < n16; j += NT) Xg[j * 16 + cc] = 0.0;
                     continue;
                 }
                 if (!lf_generate) {
-                    LG const double *src = l2_g(a0.b.X) + ((int64_t)(sid[c] >> 4) * n16) * 16 + (sid[c] & 15);
+                    const int id = l2_tl(sid, ct, TD)[cc];
+                    LG const double *src = l2_g(a0.b.X) + ((int64_t)(id >> 4) * n16) * 16 + (id & 15);
                     for (int64_t j0 = tid; j0 < n16; j0 += 4 * NT) {
                         double t4[4];
 #pragma unroll
                         for (int u = 0; u < 4; u++) t4[u] = (j0 + u * NT < n16) ? src[(j0 + u * NT) * 16] : 0.0;
 #pragma unroll
-                        for (int u = 0; u < 4; u++) if (j0 + u * NT < n16) Xg[(j0 + u * NT) * 16 + c] = t4[u];
+                        for (int u = 0; u < 4; u++) if (j0 + u * NT < n16) Xg[(j0 + u * NT) * 16 + cc] = t4[u];
                     }
                 }
             }
@@ -909,7 +1167,7 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                 // do not run at the same speed)
                 if (tid == 0) {
                     int cnt = 0;
-                    for (int k = 0; k < 16; k++) if (snew[k]) p1cols[cnt++] = k;
+                    for (int k = 0; k < NS; k++) if (l2_tl(snew, k >> 4, TD)[k & 15]) p1cols[cnt++] = k;
                     ctl[4] = cnt; ctl[5] = 0;
                 }
                 __syncthreads();
@@ -919,14 +1177,15 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                     if (lane == 0) ch = atomicAdd(&ctl[5], 1);
                     ch = __builtin_amdgcn_readfirstlane(ch);
                     if (ch >= ncolg * nchg) break;
-                    const int c = p1cols[ch / nchg];
+                    const int c = p1cols[ch / nchg], ct = c >> 4, cc = c & 15;
+                    LG double *Xg = Xg0 + (int64_t)ct * n16 * 16;
                     const int64_t j = (int64_t)(ch % nchg) * 128 + 2 * lane;
-                    const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
+                    const uint64_t sd = l2_tl(sseed, ct, TD)[cc], gidx = l2_tl(sfirst, ct, TD)[cc] + (uint64_t)l2_tl(sid, ct, TD)[cc];
                     if (j < n16) {
                         double xo = 0.0;
                         const double xe = (j < P.n) ? l2_keyed_normal_pair(sd, gidx, (uint64_t)j, &xo) : 0.0;
-                        Xg[j * 16 + c] = xe;
-                        Xg[(j + 1) * 16 + c] = (j + 1 < P.n) ? xo : 0.0;
+                        Xg[j * 16 + cc] = xe;
+                        Xg[(j + 1) * 16 + cc] = (j + 1 < P.n) ? xo : 0.0;
                     }
                 }
             }
@@ -945,10 +1204,10 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                 for (int64_t t = 0; t < a.num_iters; t++) {
                     if (tid == 0) {
                         int cnt = 0;
-                        for (int k = 0; k < 16; k++) if (snew[k] && !p1fin[k]) p1cols[cnt++] = k;
+                        for (int k = 0; k < NS; k++) if (l2_tl(snew, k >> 4, TD)[k & 15] && !l2_tl(p1fin, k >> 4, TD)[k & 15]) p1cols[cnt++] = k;
                         ctl[4] = cnt; ctl[5] = 0;
                     }
-                    if (tid < 16) { p1key[tid] = l2_key(-QM_INF); p1upd[tid] = 0; }
+                    if (tid < NS) { l2_tl(p1key, tid >> 4, TD)[tid & 15] = l2_key(-QM_INF); l2_tl(p1upd, tid >> 4, TD)[tid & 15] = 0; }
                     __syncthreads();
                     const int ncol1 = ctl[4];
                     if (ncol1 == 0) break;
@@ -957,89 +1216,111 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                         if (lane == 0) ch = atomicAdd(&ctl[5], 1);
                         ch = __builtin_amdgcn_readfirstlane(ch);
                         if (ch >= ncol1 * nch) break;
-                        const int c = p1cols[ch / nch];
-                        const uint64_t sd = sseed[c], gidx = sfirst[c] + (uint64_t)sid[c];
+                        const int c = p1cols[ch / nch], ct = c >> 4, cc = c & 15;
+                        LG double *Xg = Xg0 + (int64_t)ct * n16 * 16;
+                        const uint64_t sd = l2_tl(sseed, ct, TD)[cc], gidx = l2_tl(sfirst, ct, TD)[cc] + (uint64_t)l2_tl(sid, ct, TD)[cc];
                         double va = -QM_INF;
                         int fl = 0;
                         if (band2) {
                             const int64_t i2[2] = {(int64_t)(ch % nch) * 128 + lane, (int64_t)(ch % nch) * 128 + 64 + lane};
                             const bool on2[2] = {i2[0] < P.n, i2[1] < P.n};
-                            double x2[2] = {on2[0] ? Xg[i2[0] * 16 + c] : 1.0, on2[1] ? Xg[i2[1] * 16 + c] : 1.0};
+                            double x2[2] = {on2[0] ? Xg[i2[0] * 16 + cc] : 1.0, on2[1] ? Xg[i2[1] * 16 + cc] : 1.0};
                             P1Visit V2[2];
                             p1_band_visit_n<2>(cp, cq, cr, i2, x2, on2, a.tol, lf_viol_tol, sd, gidx, t, V2);
 #pragma unroll
                             for (int k = 0; k < 2; k++)
                                 if (on2[k]) {
-                                    if (V2[k].moved) { Xg[i2[k] * 16 + c] = x2[k]; fl |= 1; }
+                                    if (V2[k].moved) { Xg[i2[k] * 16 + cc] = x2[k]; fl |= 1; }
                                     if (V2[k].status) fl |= (-V2[k].status) << 8;
                                     va = V2[k].vafter > va ? V2[k].vafter : va;
                                 }
                         } else {
                             const int64_t i = (int64_t)(ch % nch) * 64 + lane;
                             if (i < P.n) {
-                                const double xi = l2_p1_visit(cp, cq, cr, rel, i, Xg[i * 16 + c], a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
-                                if (fl & 1) Xg[i * 16 + c] = xi;
+                                const double xi = l2_p1_visit(cp, cq, cr, rel, i, Xg[i * 16 + cc], a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
+                                if (fl & 1) Xg[i * 16 + cc] = xi;
                             }
                         }
                         const double vmax = l2_wave_max(va);
                         const bool anyupd = __builtin_amdgcn_ballot_w64((fl & 1) != 0) != 0ull;
                         const int st = (fl >> 8) ? -(fl >> 8) : 0;
-                        if (lane == 0) { atomicMax(&p1key[c], l2_key(vmax)); if (anyupd) p1upd[c] = 1; }
-                        if (st) p1st[c] = st;
+                        if (lane == 0) { atomicMax(&l2_tl(p1key, ct, TD)[cc], l2_key(vmax)); if (anyupd) l2_tl(p1upd, ct, TD)[cc] = 1; }
+                        if (st) l2_tl(p1st, ct, TD)[cc] = st;
                     }
                     __syncthreads();
-                    if (tid < 16 && snew[tid] && !p1fin[tid]) {
-                        p1sw[tid]++;
+                    if (tid < NS && l2_tl(snew, tid >> 4, TD)[tid & 15] && !l2_tl(p1fin, tid >> 4, TD)[tid & 15]) {
+                        const int st = tid >> 4, sc = tid & 15;
+                        l2_tl(p1sw, st, TD)[sc]++;
                         // done when feasible enough (qcqp.py:111); a sweep without any update is a fixed point of the map
-                        if (l2_unkey(p1key[tid]) < lf_viol_tol || !p1upd[tid]) p1fin[tid] = 1;
+                        if (l2_unkey(l2_tl(p1key, st, TD)[sc]) < lf_viol_tol || !l2_tl(p1upd, st, TD)[sc]) l2_tl(p1fin, st, TD)[sc] = 1;
                     }
                     __syncthreads();
                 }
             }
             if (lf->prof && tid == 0) atomicAdd((unsigned long long *)lf->prof + 17, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pt0));
-            if (tid < 16) p1key[tid] = l2_key(-QM_INF);
+            if (tid < NS) l2_tl(p1key, tid >> 4, TD)[tid & 15] = l2_key(-QM_INF);
             __syncthreads();
-            for (int c = 0; c < 16; c++) {
-                if (!snew[c]) continue;
+            for (int c = 0; c < NS; c++) {
+                const int ct = c >> 4, cc = c & 15;
+                if (!l2_tl(snew, ct, TD)[cc]) continue;
+                LG const double *Xg = Xg0 + (int64_t)ct * n16 * 16;
                 double v = -QM_INF;
                 for (int64_t i = tid; i < P.n; i += NT) {
-                    const double x = Xg[i * 16 + c];
+                    const double x = Xg[i * 16 + cc];
                     const double f = (cp * x + cq) * x + cr;
                     const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
                     v = w > v ? w : v;
                 }
                 v = l2_wave_max(v);
-                if (lane == 0) atomicMax(&p1key[c], l2_key(v));
+                if (lane == 0) atomicMax(&l2_tl(p1key, ct, TD)[cc], l2_key(v));
             }
             __syncthreads();
-            if (tid < 16 && snew[tid]) {
-                const double mvx = l2_unkey(p1key[tid]);
-                slk[tid] = mvx;
-                gatep[tid] = (mvx < lf_viol_tol && p1st[tid] == 0) ? 1 : 0;
+            if (tid < NS && l2_tl(snew, tid >> 4, TD)[tid & 15]) {
+                const int st = tid >> 4, sc = tid & 15;
+                const double mvx = l2_unkey(l2_tl(p1key, st, TD)[sc]);
+                l2_tl(slk, st, TD)[sc] = mvx;
+                l2_tl(gatep, st, TD)[sc] = (mvx < lf_viol_tol && l2_tl(p1st, st, TD)[sc] == 0) ? 1 : 0;
                 FeasSet<MAXC> C;
                 compute_set<MAXC>(P, P.krep[0], mvx, C);
-                store_set<MAXC>(TC, tid, C);
+                SetTable<MAXC> T2 = TC;
+                T2.lo = l2_tl(TC.lo, st, TD); T2.hi = l2_tl(TC.hi, st, TD); T2.n = l2_tl(TC.n, st, TD); T2.slow = l2_tl(TC.slow, st, TD);
+                store_set<MAXC>(T2, sc, C);
             }
             __syncthreads();
             if (nlast < 16) {
                 // n is not a multiple of 16: the padded coordinates of the last block (zero rows and columns of P0) hold a value
                 // the step maps onto ITSELF -- the band's inner end / an end of the first interval / the highest end point --
                 // so that they never move without a test in the chain's steps; zero again when the column is written out
-                const int c = tid & 15;
-                if (tid < 16 * (16 - nlast) && (snew[c] || sid[c] < 0)) {
-                    const int nn = TC.n[c];
-                    double xp = 0.0;
-                    if (KIND == L2_KIND_BAND) xp = nn >= 2 ? TC.lo[16 + c] : 0.0;
-                    else if (KIND == L2_KIND_GEN) xp = nn >= 1 ? TC.hi[c] : 0.0;
-                    else xp = nn >= 2 ? TC.hi[16 + c] : TC.hi[c];
-                    if (!(xp == xp) || __builtin_isinf(xp)) xp = 0.0;
-                    Xg[(P.n + (tid >> 4)) * 16 + c] = xp;
+                for (int w = tid; w < NS * (16 - nlast); w += NT) {
+                    const int c = w % NS, ct = c >> 4, cc = c & 15, row = w / NS;
+                    if (l2_tl(snew, ct, TD)[cc] || l2_tl(sid, ct, TD)[cc] < 0) {
+                        const int nn = l2_tl(TC.n, ct, TD)[cc];
+                        double xp = 0.0;
+                        if (KIND == L2_KIND_BAND) xp = nn >= 2 ? l2_tl(TC.lo, ct, TD)[16 + cc] : 0.0;
+                        else if (KIND == L2_KIND_GEN) xp = nn >= 1 ? l2_tl(TC.hi, ct, TD)[cc] : 0.0;
+                        else xp = nn >= 2 ? l2_tl(TC.hi, ct, TD)[16 + cc] : l2_tl(TC.hi, ct, TD)[cc];
+                        if (!(xp == xp) || __builtin_isinf(xp)) xp = 0.0;
+                        (Xg0 + (int64_t)ct * n16 * 16)[(P.n + row) * 16 + cc] = xp;
+                    }
+                }
+                __syncthreads();
+            }
+            if (LR) {
+                // ---- factored objective: a column that starts here (or an empty slot) has Y = 0 and no pending moves; the chain's
+                // loading sweep makes Y = L^T x0 of it
+                const int r16 = 16 * a0.RB;
+                for (int w = tid; w < NS * (32 + r16); w += NT) {
+                    const int c = w % NS, ct = c >> 4, cc = c & 15, rowz = w / NS;
+                    if (l2_tl(snew, ct, TD)[cc] || l2_tl(sid, ct, TD)[cc] < 0) {
+                        if (rowz < 32) l2_tl(pend, ct, TD)[rowz * 16 + cc] = 0.0;
+                        else l2_tl(ytile, ct, TD)[(rowz - 32) * 16 + cc] = 0.0;
+                    }
                 }
                 __syncthreads();
             }
             if (lf->prof && tid == 0) {
                 int nn = 0;
-                for (int k = 0; k < 16; k++) nn += snew[k] ? 1 : 0;
+                for (int k = 0; k < NS; k++) nn += l2_tl(snew, k >> 4, TD)[k & 15] ? 1 : 0;
                 atomicAdd((unsigned long long *)lf->prof + 0, (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - pt0));
                 atomicAdd((unsigned long long *)lf->prof + 2, 1ull);
                 atomicAdd((unsigned long long *)lf->prof + 3, (unsigned long long)nn);
@@ -1047,30 +1328,33 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
             __builtin_amdgcn_s_setprio(0);
         }
         if (role == 0) {
-            if (snew[r]) {
+            long long *cs_ = l2_tl(cst, rtile, TD);
+            if (l2_tl(snew, rtile, TD)[r]) {
 #pragma unroll
-                for (int f = 0; f < 6; f++) cst[f * 64 + lane] = 0;
+                for (int f = 0; f < 6; f++) cs_[f * 64 + lane] = 0;
                 // the restart is not sweeping yet: gate not passed -> one frozen sweep (flag 1) that evaluates its objective;
                 // passed, linear kind -> a frozen sweep first (flag 4) that evaluates f0 at the start of phase 2
-                const int pass = gatep[r];
-                cst[6 * 64 + lane] = 0;
-                cst[4 * 64 + lane] = (pass && !PRE) ? 0 : 1;
-                cst[7 * 64 + lane] = pass ? (PRE ? 4 : 0) : 1;
-                cst[8 * 64 + lane] = 0;
-            } else if (sid[r] < 0) {
-                cst[4 * 64 + lane] = 1; cst[6 * 64 + lane] = 0;
-                cst[7 * 64 + lane] = 2; cst[8 * 64 + lane] = 0;
+                const int pass = l2_tl(gatep, rtile, TD)[r];
+                cs_[6 * 64 + lane] = 0;
+                cs_[4 * 64 + lane] = (pass && !PRE && !LR) ? 0 : 1;
+                cs_[7 * 64 + lane] = (pass ? (PRE ? 4 : 0) : 1) | (LR ? 8 : 0);      // (factored objective: the loading sweep first)
+                cs_[8 * 64 + lane] = 0;
+            } else if (l2_tl(sid, rtile, TD)[r] < 0) {
+                cs_[4 * 64 + lane] = 1; cs_[6 * 64 + lane] = 0;
+                cs_[7 * 64 + lane] = 2; cs_[8 * 64 + lane] = 0;
             }
         }
         __syncthreads();
         if (tid == 0 && l2_g(lifep)->prof) *(long long *)(ctl + 6) = (long long)__builtin_amdgcn_s_memtime();
 
         // ================================================================ episode: the roles
-        if (role > 0) l2_mfma_role<NMW, CS>(role - 1);
-        else l2_chain_role<NMW, CS, KIND>();
+        if (role > 0) {
+            if (LR) l2_mfma_lr_role<NMW>(role - 1, rtile);
+            else l2_mfma_role<NMW, CS>(role - 1, rtile);
+        } else l2_chain_role<NMW, CS, KIND, TILES, LR>(rtile);
 
         __syncthreads();
-        if (sy[L2_ABORT]) {                          // a wait gave up: unwind (the host reports it)
+        if (sy[L2_ABORT] || (TILES > 1 && l2_tl((int *)sy, 1, TD)[L2_ABORT])) {       // a wait gave up: unwind (the host reports it)
             if (tid == 0) __hip_atomic_store(l2_g(a0.abort), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
@@ -1087,11 +1371,11 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
             const int e0 = P.cptr[P.krep[0]];
             const double cp = P.cp[e0], cq = P.cq[e0], cr = P.cr[e0];
             const int rel = P.crel[e0];
-            // the finished columns (two per episode on average) are spread over ALL threads: item w = (column, row) with eight loads
-            // in flight per thread (the tile lives in L2: a dependent load-store pair per row costs a round trip each, and with
+            // the finished columns (two per tile and episode on average) are spread over ALL threads: item w = (column, row) with eight
+            // loads in flight per thread (the tile lives in L2: a dependent load-store pair per row costs a round trip each, and with
             // one thread column per slot 14 of 16 threads had nothing to do); the max violation per column through LDS keys
-            if (tid == 0) { int cnt = 0; for (int k = 0; k < 16; k++) if (sfin[k]) p1cols[cnt++] = k; ctl[4] = cnt; }
-            if (tid < 16) p1key[tid] = l2_key(-QM_INF);
+            if (tid == 0) { int cnt = 0; for (int k = 0; k < NS; k++) if (l2_tl(sfin, k >> 4, TD)[k & 15]) p1cols[cnt++] = k; ctl[4] = cnt; }
+            if (tid < NS) l2_tl(p1key, tid >> 4, TD)[tid & 15] = l2_key(-QM_INF);
             __syncthreads();
             const int nfin = ctl[4];
             const int64_t items = (int64_t)nfin * n16;
@@ -1102,35 +1386,36 @@ __global__ __launch_bounds__(NMW == 3 ? 256 : 512, 2) void cd_life_kernel(CdLife
                     const int64_t w = w0 + (int64_t)NT * u;
                     const int col = p1cols[w < items ? w / n16 : 0];
                     const int64_t i = w % n16;
-                    xv8[u] = (w < items && i < P.n) ? Xg[i * 16 + col] : 0.0;
+                    xv8[u] = (w < items && i < P.n) ? (Xg0 + (int64_t)(col >> 4) * n16 * 16)[i * 16 + (col & 15)] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int64_t w = w0 + (int64_t)NT * u;
                     if (w < items) {
-                        const int col = p1cols[w / n16];
+                        const int col = p1cols[w / n16], id = l2_tl(sid, col >> 4, TD)[col & 15];
                         const int64_t i = w % n16;
-                        l2_g(a0.b.X)[((int64_t)(sid[col] >> 4) * n16 + i) * 16 + (sid[col] & 15)] = xv8[u];
+                        l2_g(a0.b.X)[((int64_t)(id >> 4) * n16 + i) * 16 + (id & 15)] = xv8[u];
                         if (i < P.n) {
                             const double f = (cp * xv8[u] + cq) * xv8[u] + cr;
                             const double vv = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
-                            atomicMax(&p1key[col], l2_key(vv));
+                            atomicMax(&l2_tl(p1key, col >> 4, TD)[col & 15], l2_key(vv));
                         }
                     }
                 }
             }
             __syncthreads();
-            if (tid < 16 && sfin[tid]) {
-                const double mx = l2_unkey(p1key[tid]);
-                const int id = sid[tid];
-                l2_g(a0.b.visits)[id] = ovis[tid]; l2_g(a0.b.accepted)[id] = oacc[tid]; l2_g(a0.b.sweeps)[id] = oswp[tid];
-                l2_g(a0.b.status)[id] = ost[tid];
-                if (a0.b.f0out) l2_g(a0.b.f0out)[id] = of0[tid];
+            if (tid < NS && l2_tl(sfin, tid >> 4, TD)[tid & 15]) {
+                const int st = tid >> 4, sc = tid & 15;
+                const double mx = l2_unkey(l2_tl(p1key, st, TD)[sc]);
+                const int id = l2_tl(sid, st, TD)[sc];
+                l2_g(a0.b.visits)[id] = l2_tl(ovis, st, TD)[sc]; l2_g(a0.b.accepted)[id] = l2_tl(oacc, st, TD)[sc]; l2_g(a0.b.sweeps)[id] = l2_tl(oswp, st, TD)[sc];
+                l2_g(a0.b.status)[id] = l2_tl(ost, st, TD)[sc];
+                if (a0.b.f0out) l2_g(a0.b.f0out)[id] = l2_tl(of0, st, TD)[sc];
                 if (a0.b.mvout) l2_g(a0.b.mvout)[id] = mx;
                 LG const CdLife *lf = l2_g(lifep);
-                l2_g(lf->sweeps1)[id] = p1sw[tid]; l2_g(lf->status1)[id] = p1st[tid];
-                l2_g(lf->ran2)[id] = (uint8_t)gatep[tid];
-                sid[tid] = -1; sfin[tid] = 0;
+                l2_g(lf->sweeps1)[id] = l2_tl(p1sw, st, TD)[sc]; l2_g(lf->status1)[id] = l2_tl(p1st, st, TD)[sc];
+                l2_g(lf->ran2)[id] = (uint8_t)l2_tl(gatep, st, TD)[sc];
+                l2_tl(sid, st, TD)[sc] = -1; l2_tl(sfin, st, TD)[sc] = 0;
             }
             __syncthreads();
         }
@@ -1157,23 +1442,48 @@ __global__ void l2_pack_kernel(DevProblem P, double *Dpack, double *Spack) {
     }
 }
 
-template <int NMW, int CS>
+// fragments of the factor L (n16 x r16, row-major, zero-padded) for the products (Gpack) and the updates of Y (Upack): see l2_mfma_lr_role
+__global__ void l2_pack_factor_kernel(const double *__restrict__ L, double *__restrict__ Gpack, double *__restrict__ Upack, int NB, int RB) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)NB * RB * 256) return;
+    const int e = (int)(idx & 1), lane = (int)((idx >> 1) & 63), vp = (int)((idx >> 7) & 1);
+    const int64_t rest = idx >> 8;
+    const int beta = (int)(rest % RB), b = (int)(rest / RB), v = 2 * vp + e;
+    const int64_t r16 = 16 * (int64_t)RB;
+    Gpack[idx] = L[(16 * (int64_t)b + (lane & 15)) * r16 + 16 * beta + 4 * v + (lane >> 4)];
+    Upack[idx] = L[(16 * (int64_t)b + 4 * v + (lane >> 4)) * r16 + 16 * beta + (lane & 15)];
+}
+
+template <int NMW, int CS, int TILES, int LR>
 int l2_launch_kind(const CdLife2Args &a, int kind, int wgs, size_t lds, hipStream_t st) {
-    auto k = kind == L2_KIND_BAND ? cd_life_kernel<NMW, CS, L2_KIND_BAND> : kind == L2_KIND_GEN ? cd_life_kernel<NMW, CS, L2_KIND_GEN> : cd_life_kernel<NMW, CS, L2_KIND_LIN>;
+    auto k = kind == L2_KIND_BAND ? cd_life_kernel<NMW, CS, L2_KIND_BAND, TILES, LR> : (kind == L2_KIND_GEN || LR) ? cd_life_kernel<NMW, CS, L2_KIND_GEN, TILES, LR>
+                                                                                                                   : cd_life_kernel<NMW, CS, LR ? L2_KIND_GEN : L2_KIND_LIN, TILES, LR>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3(NMW == 3 ? 256 : 512), lds, st, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3((NMW == 3 && TILES == 1) ? 256 : 512), lds, st, a);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
-size_t cd_life2_lds_bytes(int nmw) {
-    const size_t d = (size_t)2 * nmw * 256 + 256 + 256 + 4 * 256 + 512 + 96 + 1024 + 16 + 64 + 8 + 8 + 8 + 16 * 4 + 8 * 5 + 640 + 16 * 3 + 8 * 5 + 8 + 8 + 32;
-    return d * sizeof(double) + 256;
+size_t cd_life2_lds_bytes(int nmw, int cs, int tiles, int lr) {
+    return ((size_t)L2_SHARED_DOUBLES + (size_t)tiles * (size_t)l2_tile_doubles(nmw, cs > 0 ? cs : 1, lr)) * sizeof(double) + 256;
 }
 
-int cd_life2_max_wgs(int nmw, int cus) { return nmw == 3 ? 2 * cus : cus; }
+// can the factored-objective kernel take a factor of r columns for this problem?  (rank, the scratch of the column build)
+bool cd_life2_factor_ok(const DevProblem &P, int64_t r) {
+    const int64_t r16 = (r + 15) / 16 * 16;
+    if (r < 1 || r16 > 16 * L2_YBMAX || P.NB < 8) return false;
+    return true;
+}
+
+int cd_life2_pack_factor(const double *Lrow, double *Gpack, double *Upack, int NB, int RB, hipStream_t st) {
+    const int64_t tot = (int64_t)NB * RB * 256;
+    hipLaunchKernelGGL(l2_pack_factor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Lrow, Gpack, Upack, NB, RB);
+    return (int)hipGetLastError();
+}
+
+int cd_life2_max_wgs(int nmw, int cus, int tiles) { return (nmw == 3 && tiles == 1) ? 2 * cus : cus; }
 
 bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, int *nmw, int *cs, int *kind) {
     if (!P.sep || P.maxc != 1 || Kreal != 1) return false;
@@ -1190,31 +1500,59 @@ bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, 
     return true;
 }
 
+// tiles per workgroup (0 = automatic; QCQPMI_L2_TILES overrides: experiments).  Two tiles per workgroup -- one eight-wave workgroup
+// per CU, joint episodes, the build by 512 threads -- exist for the factored objective only and are NOT the default: measured at
+// n = 1024 (20 x 4096 restarts) 33.7-35.4 ms against 32.6-34.4 ms for two four-wave workgroups per CU, whose column builds overlap
+// the neighbour's products (profiles/r06_factored_objective.md; without a factor: 52.0-53.5 against 49.5-51.0 ms,
+// profiles/r06_headline_experiments.md -- that instantiation was removed).
+int cd_life2_tiles(const DevProblem &P, int nmw, int cs, int64_t restarts, int cus, int requested, int lr) {
+    (void)P; (void)restarts; (void)cus;
+    if (!lr || nmw != 3 || cs != 0) return 1;
+    int t = requested;
+    if (const char *ev = getenv("QCQPMI_L2_TILES")) t = atoi(ev);
+    return t == 2 ? 2 : 1;
+}
+
 int cd_life2_pack(const DevProblem &P, double *Dpack, double *Spack, hipStream_t st) {
     hipLaunchKernelGGL(l2_pack_kernel, dim3((unsigned)P.NB), dim3(256), 0, st, P, Dpack, Spack);
     return (int)hipGetLastError();
 }
 
-int cd_life2_launch(const CdLife2Args &a, int nmw, int cs, int kind, int wgs, hipStream_t st) {
-    const size_t lds = cd_life2_lds_bytes(nmw);
+int cd_life2_launch(const CdLife2Args &a, int nmw, int cs, int kind, int tiles, int wgs, hipStream_t st) {
+    const int lr = a.RB > 0 ? 1 : 0;
+    if (const char *ev = getenv("QCQPMI_L2_CS")) {       // experiments: the chain's share (blocks of the contraction), four-wave workgroups only
+        const int k2 = atoi(ev);
+        if (!lr && nmw == 3 && tiles == 1 && (k2 == 0 || k2 == 2 || k2 == 4) && k2 + 3 <= (int)a.P.NB && (int)a.P.NB - k2 <= 3 * RQ_MAXU) cs = k2;
+    }
+    const size_t lds = cd_life2_lds_bytes(nmw, cs, tiles, lr);
     if (getenv("QCQPMI_L2_DEBUG")) {
         int occ = -1;
-        hipError_t e = nmw == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cd_life_kernel<3, 4, L2_KIND_BAND>, 256, lds)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cd_life_kernel<7, 4, L2_KIND_BAND>, 512, lds);
-        fprintf(stderr, "cd_life2_launch: nmw %d cs %d kind %d wgs %d lds %zu: occupancy %d workgroups per CU (%s)\n", nmw, cs, kind, wgs, lds, occ, hipGetErrorString(e));
+        hipError_t e = lr ? (tiles == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cd_life_kernel<3, 0, L2_KIND_BAND, 2, 1>, 512, lds)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cd_life_kernel<3, 0, L2_KIND_BAND, 1, 1>, 256, lds))
+                     : nmw == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cd_life_kernel<3, 4, L2_KIND_BAND, 1, 0>, 256, lds)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cd_life_kernel<7, 4, L2_KIND_BAND, 1, 0>, 512, lds);
+        fprintf(stderr, "cd_life2_launch: nmw %d cs %d kind %d tiles %d lr %d wgs %d lds %zu: occupancy %d workgroups per CU (%s)\n", nmw, cs, kind, tiles, lr, wgs, lds, occ, hipGetErrorString(e));
     }
     if (wgs < 1) wgs = 1;
+    if (lr) {
+        if (nmw != 3 || cs != 0 || kind == L2_KIND_LIN) return (int)hipErrorInvalidValue;
+        return tiles == 2 ? l2_launch_kind<3, 0, 2, 1>(a, kind, wgs, lds, st) : l2_launch_kind<3, 0, 1, 1>(a, kind, wgs, lds, st);
+    }
+    if (tiles != 1) return (int)hipErrorInvalidValue;
     if (nmw == 3) {
-        if (cs == 0) return l2_launch_kind<3, 0>(a, kind, wgs, lds, st);
-        if (cs == 2) return l2_launch_kind<3, 2>(a, kind, wgs, lds, st);
-        if (cs == 4) return l2_launch_kind<3, 4>(a, kind, wgs, lds, st);
+        if (cs == 0) return l2_launch_kind<3, 0, 1, 0>(a, kind, wgs, lds, st);
+        if (cs == 2) return l2_launch_kind<3, 2, 1, 0>(a, kind, wgs, lds, st);
+        if (cs == 4) return l2_launch_kind<3, 4, 1, 0>(a, kind, wgs, lds, st);
         return (int)hipErrorInvalidValue;
     }
-    if (nmw == 7 && cs == 4) return l2_launch_kind<7, 4>(a, kind, wgs, lds, st);
+    if (nmw == 7 && cs == 4) return l2_launch_kind<7, 4, 1, 0>(a, kind, wgs, lds, st);
     return (int)hipErrorInvalidValue;
 }
 
-const char *cd_life2_name(int nmw, int kind) {
+const char *cd_life2_name(int nmw, int kind, int tiles, int lr) {
+    if (lr) return tiles == 2 ? (kind == L2_KIND_BAND ? "cd_life_kernel<3,band,2 tiles,factored>" : "cd_life_kernel<3,gen,2 tiles,factored>")
+                              : (kind == L2_KIND_BAND ? "cd_life_kernel<3,band,factored>" : "cd_life_kernel<3,gen,factored>");
+    if (tiles == 2) return kind == L2_KIND_BAND ? "cd_life_kernel<3,band,2 tiles>" : kind == L2_KIND_GEN ? "cd_life_kernel<3,gen,2 tiles>" : "cd_life_kernel<3,lin,2 tiles>";
     if (nmw == 3) return kind == L2_KIND_BAND ? "cd_life_kernel<3,band>" : kind == L2_KIND_GEN ? "cd_life_kernel<3,gen>" : "cd_life_kernel<3,lin>";
     return kind == L2_KIND_BAND ? "cd_life_kernel<7,band>" : kind == L2_KIND_GEN ? "cd_life_kernel<7,gen>" : "cd_life_kernel<7,lin>";
 }

@@ -401,6 +401,17 @@ class Engine(object):
         applies, 1 = cd_phase2_qs_kernel<lifecycle> (round 4) only."""
         self._chk(self.L.qcqpmi_cd_life_version(self.h, int(version)))
 
+    def cd_set_objective_factor(self, L=None):
+        """P0 = L L^T (L: n x r): the lifecycle kernel of cd_stream_run then carries Y = L^T X instead of multiplying with P0
+        (qcqpmi_cd_set_objective_factor; qcqp_amd.lowrank.objective_factor finds L).  None removes the factor."""
+        if L is None:
+            self._chk(self.L.qcqpmi_cd_set_objective_factor(self.h, None, 0))
+            return
+        L = np.ascontiguousarray(L, dtype=np.float64)
+        if L.ndim != 2 or L.shape[0] != self.n:
+            raise ValueError('objective factor: expected an n x r matrix')
+        self._chk(self.L.qcqpmi_cd_set_objective_factor(self.h, _dp(L), int(L.shape[1])))
+
     def cd_reference_order(self, enable=True):
         """Coupled constraints: coordinate descent in the reference's summation order (slow, value-for-value comparable with
         the reference at any n; see qcqpmi_cd_reference_order).  No effect on separable problems."""

@@ -116,3 +116,40 @@ def reduced_bases(engine, form, max_rank=8, probes=3, seed=0, tol=1e-10):
         for j in range(len(lam_k)):
             lam[k, j] = lam_k[j]; Bv[k, j] = vec_k[j]; qhat[k, j] = qh_k[j]
     return lam, Bv, qhat, dict(rank=rank, rp=rp, probes=probes)
+
+
+def objective_factor(P0, max_rank=288, tol=1e-12):
+    """L (n x r, r <= max_rank) with P0 = L L^T to `tol` of the largest |entry| of P0, or None when P0 has no such factor
+    (indefinite, or rank above max_rank) -- for qcqpmi_cd_set_objective_factor: the lifecycle kernel then carries L^T X instead
+    of multiplying with P0 (a least-squares objective |A x - b|^2 has P0 = A^T A of rank rows(A)).
+
+    Pivoted Cholesky (outer-product form, NumPy only, O(n r^2)): at step k the largest remaining diagonal entry picks the
+    column; the factor is VERIFIED against P0 entry by entry before it is returned."""
+    P = np.asarray(P0, dtype=np.float64)
+    if P.ndim != 2 or P.shape[0] != P.shape[1]:
+        return None
+    n = P.shape[0]
+    scale = float(np.max(np.abs(P))) if n else 0.0
+    if not np.isfinite(scale) or scale == 0.0:
+        return None
+    d = np.diag(P).astype(np.float64).copy()
+    if d.min() < -tol * scale:
+        return None
+    rmax = int(min(max_rank, n))
+    L = np.zeros((n, rmax))
+    r = 0
+    stop = 64.0 * np.finfo(np.float64).eps * scale * max(1.0, np.sqrt(n))
+    while r < rmax:
+        i = int(np.argmax(d))
+        if d[i] <= stop:
+            break
+        col = P[:, i] - L[:, :r] @ L[i, :r]
+        L[:, r] = col / np.sqrt(d[i])
+        d -= L[:, r] ** 2
+        r += 1
+    if r == 0 or float(np.max(d)) > max(stop, tol * scale):
+        return None                                   # rank above max_rank (or P0 = 0)
+    L = np.ascontiguousarray(L[:, :r])
+    if float(np.max(np.abs(L @ L.T - P))) > tol * scale:
+        return None                                   # not PSD / not symmetric to that accuracy
+    return L

@@ -64,7 +64,7 @@ CASES = [
     # family, n, R, K, num_iters, oracle restarts per population, kernel name
     ('bls', 128, 100, 3, 1000, 8, 'cd_life_kernel<3,band>'),
     ('bls', 1000, 200, 2, 1000, 4, 'cd_life_kernel<3,band>'),          # n not a multiple of 16; 8 oracle trajectories in all
-    ('bls', 1024, 4096, 2, 1000, 8, 'cd_life_kernel<3,band>'),         # BASELINE.json configs[1]: 16 oracle trajectories in all
+    ('bls', 1024, 4096, 2, 1000, 4, 'cd_life_kernel<3,band>'),         # BASELINE.json configs[1]: 8 oracle trajectories in all
     ('bls', 50, 40, 2, 1000, 8, 'cd_life_kernel<3,band>'),             # NB = 4: no chain share
     ('bls', 1040, 32, 1, 3, 8, 'cd_life_kernel<7,band>'),              # just past 1024: eight waves, seven multiplying (three sweeps:
                                                                         # the serial path's kernel for n > 1024 takes minutes to converge)
@@ -303,7 +303,7 @@ def test_two_real_engines_two_processes_share_one_gpu(tmp_path):
     for gpus in (1, 2):
         best = str(tmp_path / ('best%d.npy' % gpus))
         cmd = [sys.executable, 'bench.py', '--gpus', str(gpus), '--scaling', 'strong', '--restarts', '8192', '--steps', '2', '--warmup', '1',
-               '--comm', 'file', '--device', '0', '--no-cpu-baseline', '--best-out', best]
+               '--n', '512', '--m-rows', '128', '--comm', 'file', '--device', '0', '--no-cpu-baseline', '--best-out', best]
         pr = subprocess.run(cmd, cwd=repo, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert pr.returncode == 0, pr.stderr.decode()[-3000:]
         lines = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
@@ -312,14 +312,92 @@ def test_two_real_engines_two_processes_share_one_gpu(tmp_path):
     (d1, x1), (d2, x2) = out[1], out[2]
     assert d1['n_gpus'] == 1 and d2['n_gpus'] == 2 and d1['scaling'] == d2['scaling'] == 'strong'
     assert d1['config']['restarts_per_gpu'] == 8192 and d2['config']['restarts_per_gpu'] == 4096      # each rank: its shard only
-    assert d1['roofline']['kernel'] == d2['roofline']['kernel']
+    # (the two runs may dispatch to different lifecycle kernels -- 8192 restarts per launch against 4096 --: same restarts either way)
     for key in ('objective', 'max_violation', 'global_restart_index', 'step'):
         assert d1['best'][key] == d2['best'][key], (key, d1['best'], d2['best'])
-    assert x1.shape == x2.shape == (2, 1024) and np.array_equal(x1, x2)                                # every step's winner, bit for bit
+    assert x1.shape == x2.shape == (2, 512) and np.array_equal(x1, x2)                                # every step's winner, bit for bit
     # the same restarts did the same sweeps wherever they ran: value x time = phase-2 sweeps of the job
     s1, s2 = d1['value'] * d1['timed_region_s'], d2['value'] * d2['timed_region_s']
     assert abs(s1 - s2) <= 1e-6 * s1, (s1, s2)
     assert d1['phase2_sweeps_per_restart'] == pytest.approx(d2['phase2_sweeps_per_restart'], rel=1e-12)
+
+
+FACTORED = [
+    # family, n, rows of A, R, K, num_iters, oracle restarts per population
+    ('bls', 128, 32, 4000, 2, 1000, 4),            # 8000 restarts on 8192 slots... and back: refills, episodes that begin and end mid-run
+    ('bls', 1000, 250, 150, 2, 1000, 2),           # n not a multiple of 16 (63 blocks), rank 250 (16 blocks of Y, the last one partly zero)
+    ('bls', 1024, 256, 4096, 2, 1000, 2),          # BASELINE.json configs[1]
+    ('box', 320, 96, 700, 2, 60, 2),               # the `gen` step kind (box |x_i| <= 1) on a rank-96 objective
+]
+
+
+@pytest.mark.parametrize('fam,n,rows,R,K,iters,norc', FACTORED, ids=['%s-%d-r%d' % (c[0], c[1], c[2]) for c in FACTORED])
+def test_factored_objective_kernel_vs_serial_oracle_and_itself(eng_mod, orc, fam, n, rows, R, K, iters, norc):
+    """qcqpmi_cd_set_objective_factor (round 6): with P0 = L L^T handed over (qcqp_amd.lowrank.objective_factor finds L from P0 alone
+    and verifies it entry by entry) the lifecycle kernel carries Y = L^T X per tile and never multiplies with P0.  What must hold:
+      * every restart is the serial path's restart (which multiplies with P0): all counters equal, points 1e-9 (the two sum (P0 x)_i
+        in different orders: measured 6e-14), objective 1e-9, the same best restart per population;
+      * sampled restarts follow the ORACLE's trajectory (1e-9, every counter);
+      * the reported objective and max violation are those of the final point (fresh evaluation by the evaluation kernel);
+      * results do not depend on the scheduling: one population of K R restarts and K populations of R restarts with matching
+        keys give the same bits, twice in a row (Y rests between episodes in exactly the state the first product of the next
+        episode wants; a restart's column is loaded by the products' own updates)."""
+    from qcqp_amd import lowrank, problems
+    if fam == 'bls':
+        funcs = problems.boolean_least_squares(n, rows, seed=1)[0]
+    else:
+        funcs = problems.box_least_squares(n, rows, bound=1.0, seed=1, ridge=0.0)[0]      # (no ridge: P0 = A^T A of rank rows)
+    P0 = funcs[0][0]
+    P0 = P0.toarray() if hasattr(P0, 'toarray') else np.asarray(P0)
+    L = lowrank.objective_factor(P0, max_rank=288)
+    assert L is not None and L.shape == (n, rows)
+    es, e = make(eng_mod, funcs), make(eng_mod, funcs)
+    es.cd_set_objective_factor(L)
+    seed0, first0, fstride = 700, 3, 50000
+    o = es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
+    assert 'factored' in es.last_cd_kernel(), es.last_cd_kernel()
+    X = es.download()
+    f0e, mve = es.eval()
+    # (the evaluation kernel multiplies with P0, the factored kernel's window sum uses L (L^T x): 1e-13 of the objective's TERMS apart --
+    #  the box family's optimum nearly cancels them, f0 ~ 1e-3 there)
+    assert rel(o['f0'], f0e) < 1e-9 and np.max(np.abs(o['maxviol'] - mve)) < 1e-12
+    prob = orc.Problem(funcs)
+    jobs = []
+    for p in range(K):
+        sd, fi = seed0 + p, first0 + p * fstride
+        e.randn(R, seed=sd, first_index=fi)
+        X0 = e.download()
+        outr = e.cd_run(phase1=True, num_iters=iters, seed=sd, first_index=fi)
+        assert 'factored' not in e.last_cd_kernel()
+        Xr = e.download()
+        sl = slice(p * R, (p + 1) * R)
+        assert rel(X[:, sl], Xr) < 1e-9, (p, np.max(np.abs(X[:, sl] - Xr)))
+        for key in ('sweeps1', 'sweeps2', 'visits2', 'accepted2', 'ran_phase2', 'status1', 'status2'):
+            assert np.array_equal(o[key][sl], outr[key]), (p, key)
+        assert rel(o['f0'][sl], outr['f0']) < 1e-9 and np.max(np.abs(o['maxviol'][sl] - outr['maxviol'])) < 1e-9
+        assert o['best_index'][p] == e.select_best(1e-4)[0]
+        jobs += [(p, r, sd, fi, X0[:, r].copy()) for r in list(range(R))[:norc]]
+
+    def oracle_restart(job):
+        p, r, sd, fi, x0 = job
+        rng = orc.Rng(orc.RNG_KEYED, sd)
+        rng.set_restart(fi + r)
+        return prob.improve_cd(x0, num_iters=iters, rng=rng)
+    for (p, r, sd, fi, x0), (x, s1, s2) in zip(jobs, oracle_map(oracle_restart, jobs)):
+        k = p * R + r
+        assert rel(X[:, k], x) < 1e-9, (p, r)
+        assert o['visits2'][k] == s2[1] and o['accepted2'][k] == s2[2]
+        assert abs(o['f0'][k] - prob.eval(0, x)) <= 1e-9 * (1 + abs(prob.eval(0, x)))
+    # scheduling invariance, bit for bit: the same restarts as ONE population (other slots, other episode boundaries), and again
+    o1 = es.cd_stream_run(1, K * R, num_iters=iters, seed=seed0, seed_stride=0, first_index=first0, first_stride=0)
+    X1 = es.download()
+    o2 = es.cd_stream_run(1, K * R, num_iters=iters, seed=seed0, seed_stride=0, first_index=first0, first_stride=0)
+    assert np.array_equal(X1, es.download()) and np.array_equal(o1['f0'], o2['f0'])
+    assert np.array_equal(X1[:, :R], X[:, :R]) and np.array_equal(o1['f0'][:R], o['f0'][:R])      # population 0 has the same keys in both runs
+    # without the factor the same call runs the kernel that multiplies with P0
+    es.cd_set_objective_factor(None)
+    es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
+    assert 'factored' not in es.last_cd_kernel()
 
 
 def _fuzz_shape(rs):

@@ -759,6 +759,28 @@ bench.emit_line(fd, '{"value": 1}')
     assert b'banner' in pr.stderr and b'chatter' in pr.stderr
 
 
+def test_objective_factor_found_verified_or_refused():
+    """qcqp_amd.lowrank.objective_factor (pivoted Cholesky, NumPy only): a least-squares objective gives a factor of rank rows(A) that
+    reproduces P0 entry by entry; an indefinite objective (MAXCUT), a rank above the limit, a matrix that is not PSD by a hair and a
+    non-square input are refused (None) -- the caller then multiplies with P0 as before."""
+    from qcqp_amd import lowrank, problems
+    funcs = problems.boolean_least_squares(96, 24, seed=3)[0]
+    P0 = funcs[0][0]
+    P0 = P0.toarray() if hasattr(P0, 'toarray') else np.asarray(P0)
+    L = lowrank.objective_factor(P0, max_rank=48)
+    assert L is not None and L.shape == (96, 24)
+    assert np.max(np.abs(L @ L.T - P0)) <= 1e-12 * np.max(np.abs(P0))
+    assert lowrank.objective_factor(P0, max_rank=23) is None                       # rank above the limit
+    assert lowrank.objective_factor(P0 - 1e-6 * np.eye(96), max_rank=96) is None   # indefinite by a hair (the factor would not verify)
+    Pm = problems.maxcut(40, 0.5, seed=1)[0][0][0]
+    Pm = Pm.toarray() if hasattr(Pm, 'toarray') else np.asarray(Pm)
+    assert lowrank.objective_factor(Pm) is None                                    # zero diagonal, indefinite
+    assert lowrank.objective_factor(np.zeros((8, 8))) is None and lowrank.objective_factor(np.ones((3, 4))) is None
+    full = np.eye(16) * 2.0
+    Lf = lowrank.objective_factor(full, max_rank=16)
+    assert Lf is not None and np.allclose(Lf @ Lf.T, full, atol=1e-14)
+
+
 def test_build_units_cover_every_source_file():
     """qcqp_amd/_build.py derives what a translation unit is built from by scanning its #include lines (round 4 kept the lists by
     hand and missed a header: an edit to cd_phase1_sep.h rebuilt nothing, and a GPU box could run yesterday's phase 1).  Every

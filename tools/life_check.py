@@ -39,6 +39,14 @@ def main():
     seed0, first0, fstride = 1000, 7, 100000
     es = Engine(form)
     es.cd_life_version(int(os.environ.get('LIFE_VER', '2')))
+    if os.environ.get('LIFE_FACTOR', '0') == '1':          # factored objective (qcqpmi_cd_set_objective_factor)
+        from qcqp_amd import lowrank
+        P0 = funcs[0][0]
+        P0 = P0.toarray() if hasattr(P0, 'toarray') else np.asarray(P0)
+        t0 = time.perf_counter()
+        Lf = lowrank.objective_factor(P0)
+        print('objective factor:', None if Lf is None else Lf.shape, '%.2f s' % (time.perf_counter() - t0), flush=True)
+        es.cd_set_objective_factor(Lf)
     dbg = int(os.environ.get('LIFE_DBG', '0'))
     if dbg:
         es.L.qcqpmi_debug_profile(es.h, dbg << 4, None)
@@ -74,6 +82,7 @@ def main():
         print('  per EPISODE (ticks): chain prologue %.0f, after the chain left its loop %.0f; per interval: requests %.1f' % (pr[18] / max(pr[2], 1), pr[20] / max(pr[2], 1), pr[19] / ni), flush=True)
         print('  chain per interval: sum + requests %.1f, 16 steps %.1f, block end + commit %.1f, fix-up + share + staging %.1f' % (
             pr[13] / ni, pr[14] / ni, pr[15] / ni, pr[7] / ni), flush=True)
+        print('  factored objective: Y of the starting columns %.1f %% of the workgroups\' time' % (100.0 * pr[21] / max(pr[1], 1)), flush=True)
     X = es.download()
     f0e, mve = es.eval()
     print('reported vs fresh evaluation: rel df0 %.2e, d maxviol %.2e' % (np.max(np.abs(o['f0'] - f0e) / (1 + np.abs(f0e))), np.max(np.abs(o['maxviol'] - mve))), flush=True)
