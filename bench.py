@@ -782,16 +782,22 @@ def main():
     def allreduce_sum(a):
         return eng.comm_allreduce(a, 'sum')
 
+    parts_ms = {}        # wall clock of the last run_stream call by part (host side)
+
     # ------------------------------------------------------------------ scheme `stream` (default): one launch for all steps
     def run_stream(count, base):
         """`count` steps -- step k = suggest(RANDOM) with seed + k, improve(COORD_DESCENT), best point -- through ONE launch of the
         lifecycle kernel on this rank's restarts, then ONE exchange over the ranks for the global best of every step (an all-gather
         of the 32-byte keys, an all-reduce of the winners' points)."""
+        ta = time.perf_counter()
         o = eng.cd_stream_run(count, R, generate=True, phase1=True, num_iters=1000, viol_tol=1e-2, tol=1e-4, seed=args.seed + base,
                               seed_stride=1, first_index=first, first_stride=0, select_tol=1e-4)
+        tb = time.perf_counter()
         ms = eng.kernel_ms(Engine.KERNEL_CD2)
         keys, X = dist.global_best_of_populations(allreduce_sum, rank, world, o['best_f0'], o['best_maxviol'], first + o['best_index'], o['best_x'],
                                                      allgather=getattr(eng, 'comm_allgather', None))
+        parts_ms.clear()
+        parts_ms.update(launch_and_fetch=1e3 * (tb - ta), exchange=1e3 * (time.perf_counter() - tb))
         return o, keys, X, ms
 
     # ------------------------------------------------------------------ scheme `two` (rounds 2 / 3): one phase-2 launch per step
@@ -925,6 +931,7 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / K,
             'timed_region_s': dt,
+            'timed_region_parts_ms': {k: round(v, 3) for k, v in parts_ms.items()} if scheme == 'stream' else None,
             'higher_is_better': True,
             'scaling': args.scaling,
             'vs_baseline': None,

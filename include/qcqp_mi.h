@@ -102,6 +102,14 @@ int qcqpmi_pop_sdr_sample(qcqpmi_ctx *ctx, const double *mu, const double *F, in
  *      (utilities.py:49-62, 133-134; callers qcqp.py:399-401, 415-417) -------------------- */
 /* on the resident population; f0/maxviol have R entries; F (optional) is (m+1) x R row-major */
 int qcqpmi_pop_eval(qcqpmi_ctx *ctx, double *f0, double *maxviol, double *F);
+/* suggest(SDR) for S samples in ONE call -- draw and evaluate (qcqp.py:396, 399, 401; SURVEY.md section 8b's
+ * qcqpmi_sdr_sample_eval): x_s = mu + F xi_s with device Philox normals keyed on (seed, first_index + s), f0[s] = f0(x_s),
+ * maxviol[s] = max_k violation_k(x_s).  Chunks of samples are drawn and evaluated back to back in two buffers that every chunk
+ * reuses (<= 32 MB each): no population of S points is laid out in HBM.  X_opt (n x S, column per sample, or NULL): the points;
+ * with NULL they are not kept -- re-draw the winner from its index (S = 1, first_index + s).  mu == F == NULL: the pair of the
+ * previous call.  Afterwards the resident population is the last chunk.  Synchronises before it returns. */
+int qcqpmi_sdr_sample_eval(qcqpmi_ctx *ctx, const double *mu, const double *F, int64_t S, uint64_t seed,
+                           uint64_t first_index, double *X_opt, double *f0, double *maxviol);
 /* host convenience: upload X, evaluate */
 int qcqpmi_eval_batch(qcqpmi_ctx *ctx, const double *X, int64_t S, double *f0, double *maxviol,
                       double *F);

@@ -37,6 +37,7 @@ PROTOTYPES = [
     ('qcqpmi_pop_randn', C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]),
     ('qcqpmi_pop_sdr_sample', C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int64, C.c_uint64, C.c_uint64, c_dp]),
     ('qcqpmi_pop_eval', C.c_int, [C.c_void_p, c_dp, c_dp, c_dp]),
+    ('qcqpmi_sdr_sample_eval', C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int64, C.c_uint64, C.c_uint64, c_dp, c_dp, c_dp]),
     ('qcqpmi_eval_batch', C.c_int, [C.c_void_p, c_dp, C.c_int64, c_dp, c_dp, c_dp]),
     ('qcqpmi_cd_run', C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_uint64,
                                 C.c_uint64, c_ip, c_ip, c_ip, c_ip, c_bp, c_dp, c_dp]),

@@ -166,6 +166,7 @@ class QCQP(object):
         # num_samples points at once -- batch b holds the global restart indices b R .. (b + 1) R - 1 of one keyed stream, i.e.
         # exactly the points K calls suggest(RANDOM, num_samples=R, first_index=b R) would draw; the improve() that follows
         # streams them through one persistent launch where the problem allows it (batch_results: the best point of each)
+        keep_population = bool(kwargs.pop('keep_population', True))     # SDR, num_samples > 1: False = draw + evaluate without laying out the population
         K = int(kwargs.pop('batches', 1))
         first_index = int(kwargs.pop('first_index', 0))
         self._batches = None
@@ -252,7 +253,19 @@ class QCQP(object):
                     # the factor NumPy's multivariate_normal uses: x = mu + (xi * sqrt(s)) @ v
                     (u, sv, v) = np.linalg.svd(self.Sigma)
                     self._sdr_factor = np.ascontiguousarray((np.sqrt(sv)[:, None] * v).T)
-                self.engine.sdr_sample(self.mu, self._sdr_factor, R, seed=0 if seed is None else seed)
+                if not keep_population:
+                    # draw + evaluate in one call, no population of R points (qcqpmi_sdr_sample_eval): the winner by the
+                    # reference's `better` rule is re-drawn from its index and becomes the resident point, as after qcqp.py:398
+                    sd = 0 if seed is None else seed
+                    f0, mv = self.engine.sdr_sample_eval(self.mu, self._sdr_factor, R, seed=sd, first_index=first_index)
+                    from .dist import select_best_host
+                    best = int(select_best_host(f0, mv, 1e-4)[2])
+                    self.engine.sdr_sample(None, None, 1, seed=sd, first_index=first_index + best)
+                    fb, vb = self.engine.eval()
+                    out = self._publish(fb, vb)
+                    self.population_f, self.population_v, self.best_index = self._sign(np.asarray(f0)), np.asarray(mv), best
+                    return out
+                self.engine.sdr_sample(self.mu, self._sdr_factor, R, seed=0 if seed is None else seed, first_index=first_index)
         f0, mv = self.engine.eval()
         return self._publish(f0, mv)
 

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/qcqp_mi.h"
@@ -86,6 +87,17 @@ RcclApi *rccl() {
 }
 
 }  // namespace
+
+// Busy-wait for the stream.  hipStreamSynchronize and the implicit wait of a pageable copy go to sleep in slices once a kernel
+// has run for a few milliseconds and wake up 10-30 ms late in about one call of four on this stack (measured round 6 with the 34 ms
+// lifecycle launch: tools/timed_region_probe.py, profiles/r06_timed_region.md); the long launches of the coordinate-descent paths
+// are therefore awaited by polling hipStreamQuery -- one host core spins for the length of the launch.
+hipError_t spin_sync(hipStream_t st) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
+}
 
 struct qcqpmi_ctx {
     int device = 0;
@@ -258,7 +270,7 @@ int pop_reserve(qcqpmi_ctx *c, int64_t R) {
     if (R <= 0) return fail(c, QCQPMI_EINVAL, "population size must be positive");
     int64_t Rpad = (R + 15) / 16 * 16;
     if (Rpad > c->Rcap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, spin_sync(c->stream));
         free_population(c);
         int rc = 0;
         size_t xe = (size_t)Rpad * (size_t)c->n16;
@@ -311,7 +323,7 @@ __global__ void pack_cd_outputs_kernel(char *out, int64_t R, const int64_t *s1, 
 // row by the runtime: 1025 rows of 47 doubles cost 15 ms)
 int pin_reserve(qcqpmi_ctx *c, size_t bytes) {
     if (bytes <= c->h_pin_cap) return 0;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     c->h_pin = nullptr; c->h_pin_cap = 0;
     HIPCHK(c, hipHostMalloc((void **)&c->h_pin, bytes, hipHostMallocDefault));
@@ -323,7 +335,7 @@ int pin_reserve(qcqpmi_ctx *c, size_t bytes) {
 int cd_outputs_reserve(qcqpmi_ctx *c, int64_t R) {
     const int64_t bytes = 57 * R;
     if (bytes > c->out_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, spin_sync(c->stream));
         if (c->d_out) (void)hipFree(c->d_out);
         if (c->h_out) (void)hipHostFree(c->h_out);
         c->d_out = c->h_out = nullptr;
@@ -360,7 +372,7 @@ int fetch_cd_outputs(qcqpmi_ctx *c, int64_t *sweeps1, int64_t *sweeps2, int64_t 
                        (const int *)c->d_status, (const int *)c->d_status1, (const uint8_t *)c->d_flag);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     const char *h = c->h_out;
     const size_t n8 = (size_t)R * 8;
     if (sweeps1) memcpy(sweeps1, h, n8);
@@ -398,7 +410,7 @@ int cd_apply_status(qcqpmi_ctx *c, const std::vector<int> &st, const std::vector
             HIPCHK(c, hipMemcpyAsync(c->d_f0 + r, &inf, sizeof(double), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->d_mv + r, &inf, sizeof(double), hipMemcpyHostToDevice, c->stream));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, spin_sync(c->stream));
         return 0;
     }
     const int64_t r = first;
@@ -414,7 +426,7 @@ int launch_eval(qcqpmi_ctx *c, bool want_F) {
     if (want_F) {
         int64_t need = (c->m + 1) * c->Rpad;
         if (need > c->F_cap) {
-            if (c->d_F) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_F); c->d_F = nullptr; }
+            if (c->d_F) { HIPCHK(c, spin_sync(c->stream)); (void)hipFree(c->d_F); c->d_F = nullptr; }
             int rc = dev_alloc(c, &c->d_F, need);
             if (rc) return rc;
             c->F_cap = need;
@@ -431,7 +443,7 @@ int launch_eval(qcqpmi_ctx *c, bool want_F) {
         // (the per-tile MFMA loop of eval_kernel re-reads all of P0 from L2 for every tile)
         const int groups = (NB + DP_FG - 1) / DP_FG, nplanes = 2 * groups;
         if ((int64_t)nplanes * c->Rpad > c->planes_cap) {
-            if (c->d_planes) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_planes); c->d_planes = nullptr; }
+            if (c->d_planes) { HIPCHK(c, spin_sync(c->stream)); (void)hipFree(c->d_planes); c->d_planes = nullptr; }
             int rc = dev_alloc(c, &c->d_planes, (size_t)nplanes * c->Rpad);
             if (rc) return rc;
             c->planes_cap = (int64_t)nplanes * c->Rpad;
@@ -729,7 +741,7 @@ int qcqpmi_ctx_create(qcqpmi_ctx **out, int64_t n, int64_t m, int device) {
 void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)spin_sync(c->stream);
     if (c->comm && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->comm);
     free_population(c);
     admm_free(c, false);
@@ -839,7 +851,7 @@ int qcqpmi_set_quad(qcqpmi_ctx *c, int64_t k, int format, const double *vals, co
         hipLaunchKernelGGL(dense_pack_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, c->stream, (const double *)nullptr,
                            (const double *)(c->dn_tmp - (k - 1) * n * n), c->dn_gp_pre, n, n16, (int)m1, (int)k);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging buffer and the caller's array are free again
+        HIPCHK(c, spin_sync(c->stream));      // the staging buffer and the caller's array are free again
         std::vector<int>().swap(h.ci); std::vector<int>().swap(h.cj); std::vector<double>().swap(h.cv);
         h.streamed = true;
     }
@@ -866,7 +878,7 @@ int qcqpmi_set_quad_generated(qcqpmi_ctx *c, int64_t k, uint64_t seed, double sc
     hipLaunchKernelGGL(dense_gen_q_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, dq, c->n, (int)k, seed, qscale);
     h.q.resize((size_t)c->n);
     hipError_t e = hipMemcpyAsync(h.q.data(), dq, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = spin_sync(c->stream);
     (void)hipFree(dq);
     if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "set_quad_generated: %s", hipGetErrorString(e));
     return 0;
@@ -894,7 +906,7 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
             hipLaunchKernelGGL(dense_gen_rowmajor_kernel, dim3((unsigned)((n16 * n16 + 255) / 256)), dim3(256), 0, c->stream,
                                tmp, n, n16, 0, h.gseed, h.gscale, h.gdiag);
             hipError_t e = hipMemcpyAsync(P.data(), tmp, P.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = spin_sync(c->stream);
             (void)hipFree(tmp);
             if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "finalize: generated objective: %s", hipGetErrorString(e));
         }
@@ -941,7 +953,7 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
         hipLaunchKernelGGL(pack_A2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                            dp.P0, ap2, n16, dp.KS);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // P, q vectors go out of scope
+        HIPCHK(c, spin_sync(c->stream));  // P, q vectors go out of scope
         dp.Apack = ap;
         dp.Apack2 = ap2;
         dp.r0 = h.r;
@@ -1059,7 +1071,7 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
             const double *tmp = nullptr;
             if ((rc = prob_upload(c, &tmp, gP))) return rc;
             c->d_gP = const_cast<double *>(tmp);
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, spin_sync(c->stream));
         }
         if ((rc = prob_upload(c, &dp.gptr, gptr))) return rc;
         if ((rc = prob_upload(c, &dp.gi, gi))) return rc;
@@ -1073,7 +1085,7 @@ int qcqpmi_finalize(qcqpmi_ctx *c) {
     }
     if ((rc = dev_alloc(c, &c->d_best_idx, 2))) return rc;
     if ((rc = dev_alloc(c, &c->d_best_key, 2))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     // host copies are no longer needed
     for (auto &h : c->quads) { std::vector<int>().swap(h.ci); std::vector<int>().swap(h.cj); std::vector<double>().swap(h.cv); }
     c->finalized = true;
@@ -1112,7 +1124,7 @@ int qcqpmi_sdr_solve_unitdiag(qcqpmi_ctx *c, const double *C, int64_t N, double 
         if (e == hipSuccess) e = hipMemcpyAsync(V, dV, (size_t)N * SDR_K * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(hist, dh, ((size_t)max_sweeps + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&sw, ds, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = spin_sync(c->stream);
     }
     void *ptrs[] = {dC, dV, dh, ds, dw};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1138,7 +1150,7 @@ int qcqpmi_pop_upload(qcqpmi_ctx *c, const double *X, int64_t R) {
     hipLaunchKernelGGL(to_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
                        c->d_stage, c->X, c->n, c->n16, R, c->Rpad);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     return 0;
 }
 
@@ -1152,7 +1164,7 @@ int qcqpmi_pop_download(qcqpmi_ctx *c, double *X, int64_t R) {
                        c->X, c->d_stage, c->n, c->n16, R);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(X, c->d_stage, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     return 0;
 }
 
@@ -1196,12 +1208,12 @@ int qcqpmi_pop_sdr_sample(qcqpmi_ctx *c, const double *mu, const double *F, int6
         c->sdr_factor_resident = true;
         // the 2D copy may pin the caller's pages and return with the DMA in flight; the caller (Engine.sdr_sample passes
         // temporaries) may free F / mu as soon as this call returns.  The reuse path (mu = F = NULL) stays asynchronous.
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, spin_sync(c->stream));
     }
     if ((rc = pop_reserve(c, S))) return rc;
     // the standard normals: caller-provided (host layout) or device Philox; the buffer is kept across calls
     if ((int64_t)c->Rpad * n16 > c->Xi_cap) {
-        if (c->Xi) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->Xi); c->Xi = nullptr; c->Xi_cap = 0; }
+        if (c->Xi) { HIPCHK(c, spin_sync(c->stream)); (void)hipFree(c->Xi); c->Xi = nullptr; c->Xi_cap = 0; }
         if ((rc = dev_alloc(c, &c->Xi, (size_t)c->Rpad * n16, false))) return rc;
         c->Xi_cap = (int64_t)c->Rpad * n16;
     }
@@ -1249,7 +1261,36 @@ int qcqpmi_pop_eval(qcqpmi_ctx *c, double *f0, double *maxviol, double *F) {
     if (F)
         HIPCHK(c, hipMemcpy2DAsync(F, (size_t)c->R * sizeof(double), c->d_F, (size_t)c->Rpad * sizeof(double),
                                    (size_t)c->R * sizeof(double), (size_t)(c->m + 1), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
+    return 0;
+}
+
+// ---- suggest(SDR) for S samples in one call (qcqp.py:396-401: x = multivariate_normal(mu, Sigma), f0.eval(x), max(violations(x));
+// SURVEY section 8b's qcqpmi_sdr_sample_eval).  The samples are drawn (x = mu + F xi, normals by keyed Philox: sample first_index + s
+// is the same point whatever S and the chunking) and evaluated chunk by chunk on the stream: the normals and the points of a chunk
+// live in two buffers every chunk reuses (<= 32 MB each: they stay in the Infinity Cache between the sampler's GEMM and the
+// evaluation's GEMM), a population of S points is never laid out in HBM.  X_opt == NULL: the points are not kept at all -- the caller
+// re-draws the winner from its index (S = 1, the same first_index + s).  Afterwards the resident population is the LAST chunk.
+int qcqpmi_sdr_sample_eval(qcqpmi_ctx *c, const double *mu, const double *F, int64_t S, uint64_t seed, uint64_t first_index,
+                           double *X_opt, double *f0, double *maxviol) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (S < 1 || !f0 || !maxviol) return fail(c, QCQPMI_EINVAL, "sdr_sample_eval: S < 1 or f0 / maxviol missing");
+    int64_t chunk = ((int64_t)32 << 20) / (c->n16 * (int64_t)sizeof(double));
+    chunk = chunk / 128 * 128;                       // whole groups of 8 tiles of 16 samples (the LDS-tiled GEMMs' unit)
+    if (chunk < 128) chunk = 128;
+    if (const char *ev = getenv("QCQPMI_SDR_CHUNK")) { const int64_t v = atoll(ev); if (v >= 16) chunk = v / 16 * 16; }     // tests: several chunks at small sizes
+    for (int64_t off = 0; off < S; off += chunk) {
+        const int64_t cnt = S - off < chunk ? S - off : chunk;
+        if ((rc = qcqpmi_pop_sdr_sample(c, off == 0 ? mu : nullptr, off == 0 ? F : nullptr, cnt, seed, first_index + (uint64_t)off, nullptr))) return rc;
+        if ((rc = launch_eval(c, false))) return rc;
+        HIPCHK(c, hipMemcpyAsync(f0 + off, c->d_f0, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(maxviol + off, c->d_mv, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (X_opt) {
+            if ((rc = qcqpmi_pop_download(c, X_opt + off * c->n, cnt))) return rc;
+        }
+    }
+    HIPCHK(c, spin_sync(c->stream));
     return 0;
 }
 
@@ -1271,7 +1312,7 @@ int qcqpmi_pop_weighted_product(qcqpmi_ctx *c, const double *w, double *Y) {
         if ((rc = dev_alloc(c, &c->d_wz, (size_t)n16))) return rc;   // zero offset vector of the affine map
     }
     if (c->Rpad * n16 > c->wY_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, spin_sync(c->stream));
         if (c->d_wY) (void)hipFree(c->d_wY);
         c->d_wY = nullptr;
         if ((rc = dev_alloc(c, &c->d_wY, (size_t)c->Rpad * n16, false))) return rc;
@@ -1302,7 +1343,7 @@ int qcqpmi_pop_weighted_product(qcqpmi_ctx *c, const double *w, double *Y) {
                 if (e == hipSuccess) e = hipMemcpyAsync(c->h_pin, c->d_stage, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
             }
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = spin_sync(c->stream);
         if (e == hipSuccess) memcpy(Y, c->h_pin, (size_t)(c->R * c->n) * sizeof(double));
     }
     if (rc) return rc;
@@ -1341,7 +1382,7 @@ int qcqpmi_weighted_matrix(qcqpmi_ctx *c, const double *w, double *S) {
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(S, dU, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = spin_sync(c->stream);
     }
     void *ptrs[] = {dw, dS, dU};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1364,7 +1405,7 @@ int qcqpmi_pop_eval_parts(qcqpmi_ctx *c, double *quad, double *lin) {
     if ((rc = pin_reserve(c, 2 * plane))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_F, plane, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_pin + plane, dlin, plane, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     const double *hq = (const double *)c->h_pin, *hl = (const double *)(c->h_pin + plane);
     for (int64_t k = 0; k < m1; k++) {
         memcpy(quad + k * c->R, hq + k * c->Rpad, (size_t)c->R * sizeof(double));
@@ -1484,7 +1525,7 @@ static int cd_life2_reserve(qcqpmi_ctx *c, int nmw, int cus) {
     int rc;
     const size_t need = (size_t)cd_life2_max_wgs(nmw, cus, 1) * (size_t)c->n16 * 16;      // (two tiles per workgroup: half the workgroups, the same tiles)
     if (need > c->l2_scratch_cap) {
-        if (c->l2_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0; }
+        if (c->l2_scratch) { HIPCHK(c, spin_sync(c->stream)); (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0; }
         if ((rc = dev_alloc(c, &c->l2_scratch, need))) return rc;
         c->l2_scratch_cap = need;
     }
@@ -1509,6 +1550,11 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     if (K < 1 || R < 1 || num_iters < 0 || !(tol > 0.0) || K * R >= (1LL << 30)) return fail(c, QCQPMI_EINVAL, "cd_stream_run: bad K / R / num_iters / tol");
     if (!generate && c->R != K * R) return fail(c, QCQPMI_EINVAL, "cd_stream_run: the resident population has %lld points, K R = %lld", (long long)c->R, (long long)(K * R));
     HIPCHK(c, hipSetDevice(c->device));
+    // QCQPMI_STREAM_TIMING=1: host-side wall clock of the call's stages on stderr (set-up, kernel, fetch, status, best)
+    const bool stt = getenv("QCQPMI_STREAM_TIMING") != nullptr;
+    double stm[6] = {0, 0, 0, 0, 0, 0};
+    auto stnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    stm[0] = stnow();
     // ---- which kernel (decided BEFORE the resident population is touched: a refused call leaves the context as it was)
     int nmw = 0, cs2 = 0, kind = 0;
     bool use2 = c->life_version != 1 && !c->force_generic && !(c->dbg & 64) && c->sep &&
@@ -1554,9 +1600,10 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         L.prof = c->d_life_prof;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_life, &L, sizeof(L), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));       // (L lives on this stack frame)
+    HIPCHK(c, spin_sync(c->stream));       // (L lives on this stack frame)
     int cus = 0;
     HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    stm[1] = stnow();
     if (use2) {
         if ((rc = cd_life2_reserve(c, nmw, cus))) return rc;
         if (!lr && (c->dbg & 128)) { const int k2 = (c->dbg >> 8) & 7; if (nmw == 3 && (k2 == 0 || k2 == 2 || k2 == 4) && k2 < (int)(c->n16 / 16)) cs2 = k2; }
@@ -1571,15 +1618,22 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         qa.b.R = K * R;
         qa.scratch = c->l2_scratch; qa.Dpack = c->l2_D; qa.Spack = c->l2_S; qa.abort = c->l2_abort; qa.fbound = c->fbound; qa.dbg = (c->dbg & 2048) ? 1 : 0;
         qa.Gpack = lr ? c->lr_G : nullptr; qa.Upack = lr ? c->lr_U : nullptr; qa.RB = lr ? c->lr_RB : 0;
+        const double l0 = stnow();
         (void)hipEventRecord(c->timers[2].beg, c->stream);
+        const double l1 = stnow();
         hipError_t qe = (hipError_t)cd_life2_launch(qa, nmw, cs2, kind, tiles, (int)wgs, c->stream);
+        const double l2 = stnow();
         (void)hipEventRecord(c->timers[2].end, c->stream);
         c->timers[2].valid = true;
         if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_stream_run: %s", hipGetErrorString(qe));
         c->last_cd2_kernel = cd_life2_name(nmw, kind, tiles, lr ? 1 : 0);
         int ab = 0;
+        HIPCHK(c, spin_sync(c->stream));
+        const double l3 = stnow();
         HIPCHK(c, hipMemcpyAsync(&ab, c->l2_abort, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const double l4 = stnow();
+        HIPCHK(c, spin_sync(c->stream));
+        if (stt) fprintf(stderr, "cd_stream_run launch (ms): reserve %.3f, event %.3f, launch call %.3f, event + spin wait %.3f, copy call %.3f, sync %.3f\n", l0 - stm[1], l1 - l0, l2 - l1, l3 - l2, l4 - l3, stnow() - l4);
         if (ab) {
             HIPCHK(c, hipMemsetAsync(c->l2_abort, 0, sizeof(int), c->stream));
             c->R = 0;
@@ -1596,13 +1650,17 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         (void)hipEventRecord(c->timers[2].end, c->stream);
         c->timers[2].valid = true;
         if (qe != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_stream_run: %s", hipGetErrorString(qe));
+        HIPCHK(c, spin_sync(c->stream));
         c->last_cd2_kernel = "cd_phase2_qs_kernel<lifecycle>";
     }
     c->cd_stage = 0;
     c->evaluated = true;                   // d_f0 / d_mv hold the values of the final points
+    if (stt) { (void)spin_sync(c->stream); stm[2] = stnow(); }
     std::vector<int> st, st1;
     if ((rc = fetch_cd_outputs(c, sweeps1, sweeps2, visits2, accepted2, ran_phase2, f0, maxviol, st, st1))) return rc;
+    stm[3] = stnow();
     if ((rc = cd_apply_status(c, st, st1, f0, maxviol, 0))) return rc;
+    stm[4] = stnow();
     if (best_index || best_f0 || best_maxviol || best_x) {
         // the best restart of every population (QCQPForm.better folded over it, ties -> lowest index)
         if ((rc = cd_bestK_reserve(c, K))) return rc;
@@ -1620,12 +1678,17 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         HIPCHK(c, hipMemcpyAsync(idx.data(), c->d_bestK_idx, idx.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(key.data(), c->d_bestK_key, key.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         if (best_x) HIPCHK(c, hipMemcpyAsync(best_x, c->d_bestK_x, (size_t)K * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, spin_sync(c->stream));
         for (int64_t p = 0; p < K; p++) {
             if (best_index) best_index[p] = idx[(size_t)2 * p];            // index WITHIN the population
             if (best_f0) best_f0[p] = key[(size_t)2 * p];
             if (best_maxviol) best_maxviol[p] = key[(size_t)2 * p + 1];
         }
+    }
+    if (stt) {
+        stm[5] = stnow();
+        fprintf(stderr, "cd_stream_run timing (ms): set-up %.3f, launch + kernel %.3f, fetch %.3f, status %.3f, best %.3f\n", stm[1] - stm[0], stm[2] - stm[1],
+                stm[3] - stm[2], stm[4] - stm[3], stm[5] - stm[4]);
     }
     return 0;
 }
@@ -1653,7 +1716,7 @@ int qcqpmi_debug_life_profile(qcqpmi_ctx *c, int64_t *out16) {
     for (int k = 0; k < 24; k++) out16[k] = 0;
     if (!c->d_life_prof) return 0;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     HIPCHK(c, hipMemcpy(out16, c->d_life_prof, 24 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1682,7 +1745,7 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
     double key[2];
     HIPCHK(c, hipMemcpyAsync(idx, c->d_best_idx, sizeof(idx), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(key, c->d_best_key, sizeof(key), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     if (best_index) *best_index = idx[0];
     if (best_f0) *best_f0 = key[0];
     if (best_maxviol) *best_maxviol = key[1];
@@ -1691,7 +1754,7 @@ int qcqpmi_select_best(qcqpmi_ctx *c, double tol, int64_t *best_index, double *b
         const double *src = c->X + (r >> 4) * c->n16 * 16 + (r & 15);
         HIPCHK(c, hipMemcpy2DAsync(best_x, sizeof(double), src, 16 * sizeof(double), sizeof(double), (size_t)c->n,
                                    hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, spin_sync(c->stream));
     }
     return 0;
 }
@@ -1702,7 +1765,7 @@ int qcqpmi_cd_set_objective_factor(qcqpmi_ctx *c, const double *L, int64_t r) {
     int rc = check_ready(c, false);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     for (double **p : {&c->lr_L, &c->lr_G, &c->lr_U}) if (*p) { (void)hipFree(*p); *p = nullptr; }
     c->lr_RB = 0;
     if (!L || r == 0) return 0;                       // cleared
@@ -1718,7 +1781,7 @@ int qcqpmi_cd_set_objective_factor(qcqpmi_ctx *c, const double *L, int64_t r) {
                                hipMemcpyHostToDevice, c->stream));
     hipError_t e = (hipError_t)cd_life2_pack_factor(c->lr_L, c->lr_G, c->lr_U, NB, RB, c->stream);
     if (e != hipSuccess) return fail(c, QCQPMI_EHIP, "cd_life2_pack_factor: %s", hipGetErrorString(e));
-    HIPCHK(c, hipStreamSynchronize(c->stream));      // (the 2-D copy may still be reading the caller's pages)
+    HIPCHK(c, spin_sync(c->stream));      // (the 2-D copy may still be reading the caller's pages)
     c->lr_RB = RB;
     return 0;
 }
@@ -1790,7 +1853,7 @@ int qcqpmi_debug_trace(qcqpmi_ctx *c, int64_t *out, int count) {
 int qcqpmi_sync(qcqpmi_ctx *c) {
     if (!c) return QCQPMI_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     return 0;
 }
 
@@ -1839,7 +1902,7 @@ int qcqpmi_comm_allreduce(qcqpmi_ctx *c, double *values, int64_t count, int op) 
     double *buf = c->d_comm;
     if (count > 4) {      // the exchange of a streamed run (keys of all populations, then the winners' points): a buffer of its own
         if (count > c->comm_big_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, spin_sync(c->stream));
             if (c->d_comm_big) (void)hipFree(c->d_comm_big);
             c->d_comm_big = nullptr; c->comm_big_cap = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_comm_big, (size_t)count * sizeof(double)));
@@ -1850,7 +1913,7 @@ int qcqpmi_comm_allreduce(qcqpmi_ctx *c, double *values, int64_t count, int op) 
     HIPCHK(c, hipMemcpyAsync(buf, values, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
     NCCLCHK(c, rccl()->AllReduce(buf, buf, (size_t)count, ncclDouble, op == 0 ? ncclMax : ncclSum, c->comm, c->stream));
     HIPCHK(c, hipMemcpyAsync(values, buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     return 0;
 }
 
@@ -1861,7 +1924,7 @@ int qcqpmi_comm_allgather(qcqpmi_ctx *c, const void *send, int64_t nbytes, void 
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t need = ((int64_t)(c->world + 1) * nbytes + 7) / 8;      // doubles: send area + receive area
     if (need > c->comm_big_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, spin_sync(c->stream));
         if (c->d_comm_big) (void)hipFree(c->d_comm_big);
         c->d_comm_big = nullptr; c->comm_big_cap = 0;
         HIPCHK(c, hipMalloc((void **)&c->d_comm_big, (size_t)need * sizeof(double)));
@@ -1871,7 +1934,7 @@ int qcqpmi_comm_allgather(qcqpmi_ctx *c, const void *send, int64_t nbytes, void 
     HIPCHK(c, hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
     NCCLCHK(c, rccl()->AllGather(d_send, d_recv, (size_t)nbytes, ncclInt8, c->comm, c->stream));
     HIPCHK(c, hipMemcpyAsync(recv, d_recv, (size_t)nbytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     return 0;
 }
 
@@ -1892,7 +1955,7 @@ int qcqpmi_comm_select_best(qcqpmi_ctx *c, double tol, int64_t index_offset, int
     NCCLCHK(c, rccl()->AllGather(d_send, d_recv, 4, ncclDouble, c->comm, c->stream));
     std::vector<double> all((size_t)4 * W);
     HIPCHK(c, hipMemcpyAsync(all.data(), d_recv, all.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     int win = 0;
     for (int w = 1; w < W; w++) {
         const double *a = &all[(size_t)4 * w], *b = &all[(size_t)4 * win];
@@ -1905,7 +1968,7 @@ int qcqpmi_comm_select_best(qcqpmi_ctx *c, double tol, int64_t index_offset, int
     }
     NCCLCHK(c, rccl()->Broadcast(d_x, d_x, (size_t)c->n, ncclDouble, win, c->comm, c->stream));
     if (best_x) HIPCHK(c, hipMemcpyAsync(best_x, d_x, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, spin_sync(c->stream));
     if (best_global_index) *best_global_index = (int64_t)all[(size_t)4 * win + 3];
     if (best_f0) *best_f0 = all[(size_t)4 * win + 1];
     if (best_maxviol) *best_maxviol = all[(size_t)4 * win + 2];

@@ -136,6 +136,23 @@ class Engine(object):
         self._chk(self.L.qcqpmi_pop_sdr_sample(self.h, _dp(mu_p), _dp(F_p), int(S), int(seed),
                                                int(first_index), _dp(Xc)))
 
+    def sdr_sample_eval(self, mu, F, S, seed=0, first_index=0, want_X=False):
+        """S samples x_s = mu + F xi_s drawn AND evaluated in one call (qcqpmi_sdr_sample_eval; qcqp.py:396-401 for S samples):
+        returns (f0, maxviol[, X (n, S)]).  No population of S points is laid out: chunks through two reused buffers; sample
+        first_index + s is the same point whatever S (keyed normals).  mu = F = None: the pair of the previous call."""
+        if mu is None and F is None:
+            mu_p = F_p = None
+        else:
+            mu_p = np.ascontiguousarray(mu, dtype=np.float64).ravel()
+            F_p = np.ascontiguousarray(F, dtype=np.float64)
+            assert F_p.shape == (self.n, self.n) and mu_p.size == self.n
+        S = int(S)
+        f0 = np.empty(S)
+        mv = np.empty(S)
+        Xc = np.empty((S, self.n)) if want_X else None
+        self._chk(self.L.qcqpmi_sdr_sample_eval(self.h, _dp(mu_p), _dp(F_p), S, int(seed), int(first_index), _dp(Xc), _dp(f0), _dp(mv)))
+        return (f0, mv, np.ascontiguousarray(Xc.T)) if want_X else (f0, mv)
+
     # ---------------------------------------------------------------- evaluation
     def eval(self, want_F=False):
         R = self.pop_size

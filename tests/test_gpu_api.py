@@ -126,6 +126,14 @@ def test_suggest_sdr_separable_families():
     q = handler(funcs)
     f, v = q.suggest(SDR, num_samples=64, seed=1)
     assert q.sdr_info['lambda_min'] > -1e-5 * (1 + abs(q.sdr_bound))
+    xs = np.array(q._assigned, copy=True)
+    pf, pv = np.array(q.population_f, copy=True), np.array(q.population_v, copy=True)
+    # the same 64 samples drawn + evaluated in ONE call without a resident population (qcqpmi_sdr_sample_eval): same values, same
+    # winner, the winner re-drawn from its index is the resident point the improve() below starts from
+    g, w = q.suggest(SDR, num_samples=64, seed=1, keep_population=False)
+    assert (g, w) == (f, v) and np.array_equal(q._assigned, xs)
+    assert np.array_equal(q.population_f, pf) and np.array_equal(q.population_v, pv)
+    assert q.engine.pop_size == 1
     f2, v2 = q.improve(COORD_DESCENT, seed=2)
     assert v2 < 1e-2 and q.sdr_bound <= f2 + 1e-6 * (1 + abs(f2))
 

@@ -91,6 +91,40 @@ def test_config3_maxcut_full_size(eng_mod, orc):
     assert np.array_equal(Xs, X[:, 1024:2048])
     f1, m1 = e.eval()
     assert np.array_equal(f1, f0[1024:2048]) and np.array_equal(m1, mv[1024:2048])
+    # the one-call entry (qcqpmi_sdr_sample_eval): 8192 samples in chunks of 2048 through two reused buffers, no
+    # population laid out -- the same values bit for bit; the winner re-drawn from its index is the same point
+    f2, m2 = e.sdr_sample_eval(mu, F, S, seed=2024, first_index=0)
+    assert np.array_equal(f2, f0) and np.array_equal(m2, mv)
+    assert e.pop_size == 2048
+    w = int(np.argmin(f0))
+    e.sdr_sample(None, None, 1, seed=2024, first_index=w)
+    assert np.array_equal(e.download()[:, 0], X[:, w])
+
+
+@pytest.mark.parametrize('n,S,chunk', [(200, 1000, 256), (10, 77, 16), (500, 384, 0)])
+def test_sdr_sample_eval_one_call(eng_mod, orc, n, S, chunk, monkeypatch):
+    """qcqpmi_sdr_sample_eval (qcqp.py:396-401 for S samples in one call): several chunks (a ragged last one), with and without
+    the points, against the oracle's keyed normals + NumPy's product + the oracle's evaluation, and bit-identical to
+    qcqpmi_pop_sdr_sample + qcqpmi_pop_eval on the whole population."""
+    from qcqp_amd import problems
+    funcs, _, _ = problems.boolean_least_squares(n, max(4, n // 4), seed=6)
+    e = make(eng_mod, funcs)
+    rs = np.random.RandomState(n + S)
+    F = rs.randn(n, n) / np.sqrt(n)
+    mu = rs.randn(n)
+    e.sdr_sample(mu, F, S, seed=5, first_index=300)
+    fa, ma = e.eval()
+    Xa = e.download()
+    if chunk:
+        monkeypatch.setenv('QCQPMI_SDR_CHUNK', str(chunk))
+    f0, mv, X = e.sdr_sample_eval(mu, F, S, seed=5, first_index=300, want_X=True)
+    assert np.array_equal(X, Xa) and np.array_equal(f0, fa) and np.array_equal(mv, ma)
+    f1, m1 = e.sdr_sample_eval(None, None, S, seed=5, first_index=300)          # the resident pair, the points not kept
+    assert np.array_equal(f1, fa) and np.array_equal(m1, ma)
+    ref = mu[:, None] + F.dot(orc.keyed_normal_matrix(5, n, S, first_index=300))
+    assert np.max(np.abs(X - ref)) < 1e-11 * (1 + np.max(np.abs(ref)))
+    g0, gv = orc.Problem(funcs).eval_batch(X)
+    assert rel(f0, g0) < 1e-12 and rel(mv, gv) < 1e-12
 
 
 # ------------------------------------------------------------------ dense path at dispatch-changing sizes
