@@ -36,10 +36,13 @@ import os
 import sys
 import time
 
-import numpy as np
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+from qcqp_amd import _threads  # noqa: E402
+
+_threads.set_blas_env()      # BEFORE NumPy: 256 visible CPUs, 16 cores of cgroup quota -- spinning BLAS workers get the whole container throttled
+
+import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (AMD datasheet); see DESIGN.md section 4
 
@@ -58,12 +61,16 @@ def profiled_counters(kernel_name):
                 d = json.load(open(os.path.join(pdir, name)))
             except Exception:
                 continue
-            if 'cd_phase2_hbm_bytes_per_launch' in d and (d.get('kernel') or '').split('<')[0] == (kernel_name or '').split('<')[0]:
-                best = dict(traffic=d['cd_phase2_hbm_bytes_per_launch'], mfma_busy=d.get('cd_phase2_mfma_busy_frac'),
+            exact = d.get('engine_kernel') == kernel_name
+            if best is not None and best['exact'] and not exact:
+                continue                 # a profile of exactly this instantiation beats a later one of the same kernel family
+            if 'cd_phase2_hbm_bytes_per_launch' in d and (exact or (d.get('kernel') or '').split('<')[0] == (kernel_name or '').split('<')[0]):
+                best = dict(exact=exact, traffic=d['cd_phase2_hbm_bytes_per_launch'], mfma_busy=d.get('cd_phase2_mfma_busy_frac'),
                             source='profiles/' + name, profile_commit=d.get('git_commit'), profile_date=d.get('date'),
                             kernel=d.get('kernel'), launch=d.get('launch'))
+    if best is not None:
+        best.pop('exact')
     return best
-
 
 
 # ------------------------------------------------------------------------------------- the one line

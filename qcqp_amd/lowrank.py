@@ -139,17 +139,19 @@ def objective_factor(P0, max_rank=288, tol=1e-12):
     L = np.zeros((n, rmax))
     r = 0
     stop = 64.0 * np.finfo(np.float64).eps * scale * max(1.0, np.sqrt(n))
-    while r < rmax:
-        i = int(np.argmax(d))
-        if d[i] <= stop:
-            break
-        col = P[:, i] - L[:, :r] @ L[i, :r]
-        L[:, r] = col / np.sqrt(d[i])
-        d -= L[:, r] ** 2
-        r += 1
-    if r == 0 or float(np.max(d)) > max(stop, tol * scale):
-        return None                                   # rank above max_rank (or P0 = 0)
-    L = np.ascontiguousarray(L[:, :r])
-    if float(np.max(np.abs(L @ L.T - P))) > tol * scale:
-        return None                                   # not PSD / not symmetric to that accuracy
+    from ._threads import blas_limit
+    with blas_limit():        # (a BLAS pool as wide as the visible CPUs gets a quota-limited container throttled: _threads.py)
+        while r < rmax:
+            i = int(np.argmax(d))
+            if d[i] <= stop:
+                break
+            col = P[:, i] - L[:, :r] @ L[i, :r]
+            L[:, r] = col / np.sqrt(d[i])
+            d -= L[:, r] ** 2
+            r += 1
+        if r == 0 or float(np.max(d)) > max(stop, tol * scale):
+            return None                                   # rank above max_rank (or P0 = 0)
+        L = np.ascontiguousarray(L[:, :r])
+        if float(np.max(np.abs(L @ L.T - P))) > tol * scale:
+            return None                                   # not PSD / not symmetric to that accuracy
     return L

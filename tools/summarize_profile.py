@@ -99,9 +99,10 @@ if mb:
 bj = os.path.join(src, 'bench_under_profiler.json')
 if os.path.exists(bj) and os.path.getsize(bj):
     out['bench_under_profiler'] = json.load(open(bj))
+    out['engine_kernel'] = (out['bench_under_profiler'].get('roofline') or {}).get('kernel')     # the name the engine reports (bench.py matches on it)
 hdr = ['# rocprofv3 summary %s' % tag, '',
        'Command: `python bench.py --scheme stream --steps 20 --warmup 20 --no-cpu-baseline --no-secondary` (tools/profile_round.sh):',
-       'two launches of the lifecycle kernel (round 5: `cd_life_kernel<3, 4, 0>`; round 4: `cd_phase2_qs_kernel<4, true>`), each = 20 steps of 4096 restarts --',
+       'two launches of the lifecycle kernel (round 6: `cd_life_kernel<3, 0, 0, 1, 1>` = three multiplying waves, no chain share, band kind, one tile per workgroup, FACTORED objective; round 5: `cd_life_kernel<3, 4, 0>`; round 4: `cd_phase2_qs_kernel<4, true>`), each = 20 steps of 4096 restarts --',
        'suggest, phase 1, gate, phase 2, objective of 81920 restarts inside the launch.',
        'Pass 1 `--kernel-trace --stats`; passes 2-4 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc TCC_HIT_sum TCC_MISS_sum`',
        '(separate runs, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled (gfx950 reports half the bytes of',
