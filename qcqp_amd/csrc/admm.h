@@ -263,24 +263,35 @@ __device__ __attribute__((always_inline)) inline void admm_small_solve(const Adm
                 fast = den != 0.0 && onel > 0.0 && nus - nus == 0.0 && dphi - dphi == 0.0;
             }
         }
-        auto psign = [&](double nu) {      // the sign of phi(nu) (its value when it has to be evaluated)
-            if (fast) {
-                const double d = nu - nus;
-                if (fabs(d) > 1e-8 * (1.0 + fabs(nus)) && fabs(dphi * d) > 1e-10 * scale) return d < 0.0 ? 1.0 : -1.0;
+        // The sign of phi at a trial value: by the SIDE of nu* unless the trial is too close to tell (then phi is evaluated).  Written
+        // straight-line -- `up` / `dn` are plain compares, phi sits behind ONE wave-uniform test (no lane of the wave near nu*: the common
+        // case has nothing to skip over), the bracket moves by selects: with an early return per case a step was ten exec-mask regions
+        // and 40 instructions, and the ~25 steps of a solve were what admm_unit_step_kernel spent its time ISSUING (a wave64 vector
+        // instruction occupies its SIMD for 4 cycles whatever it does; round 6, profiles/r06_admm_unit_bases.md).  Same decisions, same
+        // bits: |d| > c1 and |phi'(nu*) d| > c2  <=>  |d| > zone up to the rounding of c2 / |phi'| -- a trial THAT close to the zone's
+        // edge has the sign of its side either way (the zone is 1e6 roundings wide).
+        const double zone = fast ? fmax(1e-8 * (1.0 + fabs(nus)), 1e-10 * scale / fabs(dphi)) : QM_INF;
+        bool pnan = false;                                     // phi was evaluated and is not a number (ends the doubling loops like the reference's comparisons do)
+        auto psign = [&](double nu, bool &up, bool &dn) {
+            const double d = nu - nus;
+            const bool near = !(fabs(d) > zone);               // (also for a not-a-number trial)
+            up = d < 0.0; dn = !up;
+            if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
+                if (near) { const double p = phi(nu); up = p > 0.0; dn = p < 0.0; pnan = p != p; }
             }
-            return phi(nu);
         };
         double s = a.slo[k], e_ = a.ehi[k];
         int guard = 0;
-        if (s == -QM_INF) { s = -1.0; while (psign(s) <= 0.0 && guard++ < 2000) s *= 2.0; }
-        if (e_ == QM_INF) { e_ = 1.0; while (psign(e_) >= 0.0 && guard++ < 4000) e_ *= 2.0; }
+        bool up, dn;
+        if (s == -QM_INF) { s = -1.0; for (;;) { psign(s, up, dn); if (up || pnan || guard++ >= 2000) break; s *= 2.0; } }          // while phi(s) <= 0
+        if (e_ == QM_INF) { e_ = 1.0; for (;;) { psign(e_, up, dn); if (dn || pnan || guard++ >= 4000) break; e_ *= 2.0; } }        // while phi(e) >= 0
         int steps = 0;
         while (e_ - s > a.sec_tol && steps++ < 100000) {
             const double mid = (s + e_) / 2.0;
-            const double p = psign(mid);
-            if (p > 0.0) s = mid;
-            else if (p < 0.0) e_ = mid;
-            else { s = e_ = mid; break; }
+            psign(mid, up, dn);
+            // phi > 0: s = mid; phi < 0: e = mid; otherwise (zero, or not a number) both, which ends the loop (utilities.py:189-194)
+            s = (up || !dn) ? mid : s;
+            e_ = (dn || !up) ? mid : e_;
         }
         (void)phi((s + e_) / 2.0);
     }

@@ -1564,20 +1564,19 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     c->cd_queue = 2;                                   // (qcqpmi_cd_queue chooses the phase-2 kernel of qcqpmi_cd_run; it does not apply here)
     const bool eligible = cd_queue_eligible(c, false) && (int)(c->n16 / 16) - 4 <= RQ_NSIMD * RQ_MAXU && c->n16 >= 48;
     c->cd_queue = queue_switch;
-    // life_version 0 (default): the faster kernel for the shape.  Measured on one MI355X, 20 steps of 4096 restarts, Boolean family
-    // (tools/life_vs_r4.py, profiles/r05_life_vs_round4.md): cd_life_kernel takes 0.59 of the round-4 kernel's time at n = 64, 0.75 at 256,
-    // 0.82 at 512, 0.92 at 768, 1.01 at 896, 1.12 at 1024 -- at full width its multiplying waves (20 blocks of the contraction each,
-    // two streams per SIMD) are the bound while the round-4 kernel's eight waves split one tile's product six ways.  So: the round-4
-    // kernel from n = 960 on when the run has more restarts than both kernels have slots, cd_life_kernel everywhere else.
+    // ONE lifecycle kernel (round 6): cd_life_kernel takes every shape the round-4 kernel (cd_phase2_qs_kernel<CS, lifecycle>, cd_queue.hip)
+    // takes and more; the shape rule of round 5 (the round-4 kernel from n = 960 on for runs beyond 8192 restarts, where it is 12 % faster
+    // on a FULL-rank objective: profiles/r05_life_vs_round4.md) is gone -- the headline family has a low-rank objective and runs the
+    // factored instantiation, 1.3 x faster than either (profiles/r06_summary.md).  qcqpmi_cd_life_version(1) still launches the round-4
+    // kernel: a debug switch, kept as the independent implementation the tests compare against.
     // factored objective (qcqpmi_cd_set_objective_factor): cd_life_kernel's products through Y = L^T X -- half the matrix work and less
     // per block interval, a positive diagonal (band / gen kinds), three multiplying waves per tile
     const bool lr = use2 && c->lr_RB > 0 && nmw == 3 && kind != L2_KIND_LIN && c->life_version != 3 && cd_life2_factor_ok(c->dp, 16 * (int64_t)c->lr_RB);
     if (lr) cs2 = 0;
-    if (use2 && !lr && c->life_version == 0 && eligible && c->n16 >= 960 && K * R > 8192) use2 = false;
     if (!use2) {
-        if (!eligible)
-            return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernels need separable constraints of ONE class with one constraint per "
-                        "coordinate, a diagonal of P0 that is positive everywhere or zero everywhere, and 48 <= n <= 2048: use qcqpmi_cd_run per population");
+        if (!eligible || c->life_version != 1)
+            return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernel needs separable constraints of ONE class with one constraint per "
+                        "coordinate, a diagonal of P0 that is positive everywhere or zero everywhere, and 48 <= n <= 2304: use qcqpmi_cd_run per population");
         const int NBq = (int)(c->n16 / 16);
         cs = (c->dbg & 128) ? ((c->dbg >> 8) & 7) : 4;
         cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;

@@ -63,8 +63,10 @@ def oracle_restarts(orc, funcs, eng_mod, seed, first, R, picks, iters):
 CASES = [
     # family, n, R, K, num_iters, oracle restarts per population, kernel name
     ('bls', 128, 100, 3, 1000, 8, 'cd_life_kernel<3,band>'),
-    ('bls', 1000, 200, 2, 1000, 4, 'cd_life_kernel<3,band>'),          # n not a multiple of 16; 8 oracle trajectories in all
-    ('bls', 1024, 4096, 2, 1000, 4, 'cd_life_kernel<3,band>'),         # BASELINE.json configs[1]: 8 oracle trajectories in all
+    ('bls', 1000, 200, 2, 3, 4, 'cd_life_kernel<3,band>'),             # n not a multiple of 16; 8 oracle trajectories of three sweeps + the frozen one
+                                                                       # (to convergence at this size: the factored case bls-1000-r250 below, ~35 s of oracle per trajectory)
+    ('bls', 1024, 4096, 2, 4, 4, 'cd_life_kernel<3,band>'),            # BASELINE.json configs[1]'s size: 8 oracle trajectories of four sweeps (to convergence:
+                                                                       # test_gpu_stream.py's 1024 case with this kernel, bls-1024-r256 below with the factored one)
     ('bls', 50, 40, 2, 1000, 8, 'cd_life_kernel<3,band>'),             # NB = 4: no chain share
     ('bls', 1040, 32, 1, 3, 8, 'cd_life_kernel<7,band>'),              # just past 1024: eight waves, seven multiplying (three sweeps:
                                                                         # the serial path's kernel for n > 1024 takes minutes to converge)
@@ -460,24 +462,28 @@ def test_life_kernel_fuzz_shapes(eng_mod, orc, seed):
         e.close()
 
 
-def test_lifecycle_dispatch_by_shape(eng_mod):
-    """qcqpmi_cd_life_version 0 (the default): qcqpmi_cd_stream_run launches the faster kernel for the shape -- the round-4 kernel for the
-    Boolean family at n >= 960 when the run has more restarts than the kernels have slots (BASELINE.json configs[1] streamed: 12 %
-    faster there, profiles/r05_life_vs_round4.md), cd_life_kernel everywhere else; the restarts are the same either way."""
+def test_lifecycle_dispatch_is_one_kernel(eng_mod):
+    """Round 6: qcqpmi_cd_stream_run launches cd_life_kernel for every shape it takes (the round-5 rule that sent the Boolean family at
+    n >= 960 with more than 8192 restarts to the round-4 kernel is gone); qcqpmi_cd_life_version(1) -- a debug switch -- still reaches
+    the round-4 kernel, and the restarts are the same either way."""
     from qcqp_amd import problems
     funcs, _, _ = problems.boolean_least_squares(1024, 256, seed=1)
     e = make(eng_mod, funcs)
     o3 = e.cd_stream_run(3, 4096, seed=7, seed_stride=1)
-    assert e.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
-    X3 = e.download()
-    e.cd_life_version(2)
-    o3b = e.cd_stream_run(3, 4096, seed=7, seed_stride=1)
     assert e.last_cd_kernel() == 'cd_life_kernel<3,band>'
+    X3 = e.download()
+    e.cd_life_version(1)
+    o3b = e.cd_stream_run(3, 4096, seed=7, seed_stride=1)
+    assert e.last_cd_kernel() == 'cd_phase2_qs_kernel<lifecycle>'
     assert np.max(np.abs(e.download() - X3)) < 1e-12 and np.array_equal(o3['visits2'], o3b['visits2']) and np.array_equal(o3['best_index'], o3b['best_index'])
     e.cd_life_version(0)
     e.cd_stream_run(1, 4096, seed=7)
-    assert e.last_cd_kernel() == 'cd_life_kernel<3,band>'              # one population: nothing to stream, the newer kernel's latency is lower
-    funcs, _, _ = problems.boolean_least_squares(512, 128, seed=1)
-    e = make(eng_mod, funcs)
-    e.cd_stream_run(3, 4096, seed=7, seed_stride=1)
     assert e.last_cd_kernel() == 'cd_life_kernel<3,band>'
+    # a problem the round-4 kernel never took (n not a multiple of 16) is refused under the debug switch instead of silently rerouted
+    funcs, _, _ = problems.boolean_least_squares(100, 25, seed=1)
+    e = make(eng_mod, funcs)
+    e.cd_stream_run(2, 64, seed=7, seed_stride=1)
+    assert e.last_cd_kernel() == 'cd_life_kernel<3,band>'
+    e.cd_life_version(1)
+    with pytest.raises(eng_mod.EngineError):
+        e.cd_stream_run(2, 64, seed=7, seed_stride=1)

@@ -1,5 +1,5 @@
-"""GPU parity tests of the lifecycle launch (qcqpmi_cd_stream_run) -- every test with BOTH kernels: cd_life_kernel (csrc/cd_life.hip,
-round 5, the default) and the lifecycle mode of the slot-queue kernel it replaced (csrc/cd_queue.hip, round 4) --: K populations of R
+"""GPU parity tests of the lifecycle launch (qcqpmi_cd_stream_run: cd_life_kernel, csrc/cd_life.hip -- since round 6 the ONE
+lifecycle kernel; the round-4 kernel it replaced is a debug switch with one regression test in test_gpu_life.py): K populations of R
 restarts -- suggest(RANDOM) + improve(COORD_DESCENT) + best point each, the reference's user loop (README.md:51-57, qcqp.py:381-382,
 181-192) -- inside ONE persistent launch, against the serial path (one qcqpmi_pop_randn + qcqpmi_cd_run per population) and against
 the oracle.  Run with `-m gpu` on an MI355X."""
@@ -18,15 +18,15 @@ def eng_mod():
     return engine
 
 
-LIFE = {'version': 2}
-KNAME = {2: 'cd_life_kernel<3,band>', 1: 'cd_phase2_qs_kernel<lifecycle>'}
+LIFE = {'version': 0}
+KNAME = {0: 'cd_life_kernel<3,band>', 2: 'cd_life_kernel<3,band>', 1: 'cd_phase2_qs_kernel<lifecycle>'}
 
 
-@pytest.fixture(autouse=True, params=[2, 1], ids=['cd_life_kernel', 'round4_lifecycle_kernel'])
+@pytest.fixture(autouse=True, params=[0], ids=['cd_life_kernel'])      # (0 = the default dispatch: one kernel)
 def life_version(request):
     LIFE['version'] = request.param
     yield request.param
-    LIFE['version'] = 2
+    LIFE['version'] = 0
 
 
 def make(eng_mod, funcs):
