@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QCQPMI_ABI_VERSION 5
+#define QCQPMI_ABI_VERSION 6
 
 enum {
     QCQPMI_OK = 0,

@@ -203,6 +203,7 @@ struct qcqpmi_ctx {
     double *l2_scratch = nullptr; size_t l2_scratch_cap = 0;
     double *l2_D = nullptr, *l2_S = nullptr;
     int *l2_abort = nullptr;
+    int *l2_cuslot = nullptr;    // [4096] arrival counters per compute unit of cd_life_kernel (zeroed before every launch)
     // factored objective P0 = L L^T (qcqpmi_cd_set_objective_factor): L (n16 x 16 lr_RB, zero-padded) and its fragment packs
     double *lr_L = nullptr, *lr_G = nullptr, *lr_U = nullptr; int lr_RB = 0;
     int life_version = 0;        // qcqpmi_cd_life_version: 0 = the faster one for the shape, 2 = cd_life_kernel wherever it applies, 1 = cd_phase2_qs_kernel<lifecycle> only
@@ -747,7 +748,7 @@ void qcqpmi_ctx_destroy(qcqpmi_ctx *c) {
     admm_free(c, false);
     for (void *p : c->prob_allocs) (void)hipFree(p);
     void *ptrs[] = {c->d_Fpack, c->d_Frow, c->d_mu, c->d_best_idx, c->d_best_key, c->d_comm, c->d_comm_big,   // d_gP is in prob_allocs
-                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key, c->d_bestK_x, c->l2_scratch, c->l2_D, c->l2_S, c->l2_abort, c->lr_L, c->lr_G, c->lr_U};
+                    c->dn_G, c->dn_Dg, c->dn_Ft, c->dn_prof, c->dn_state, c->d_planes, c->d_out, c->d_wS, c->d_wY, c->d_ww, c->d_wz, c->af_work, c->d_qnext, c->d_life, c->d_life_prof, c->d_bestK_idx, c->d_bestK_key, c->d_bestK_x, c->l2_scratch, c->l2_D, c->l2_S, c->l2_abort, c->l2_cuslot, c->lr_L, c->lr_G, c->lr_U};
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1530,6 +1531,7 @@ static int cd_life2_reserve(qcqpmi_ctx *c, int nmw, int cus) {
         c->l2_scratch_cap = need;
     }
     if (!c->l2_abort && (rc = dev_alloc(c, &c->l2_abort, 4))) return rc;
+    if (!c->l2_cuslot && (rc = dev_alloc(c, &c->l2_cuslot, 4096))) return rc;
     if (!c->l2_D) {
         const size_t NB = (size_t)(c->n16 / 16);
         if ((rc = dev_alloc(c, &c->l2_D, NB * 256))) return rc;
@@ -1615,7 +1617,13 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         qa.P = c->dp; qa.num_iters = num_iters; qa.tol = tol; qa.life = c->d_life;
         cd_queue_fill_batch(c, qa.b, seed, first_index);
         qa.b.R = K * R;
-        qa.scratch = c->l2_scratch; qa.Dpack = c->l2_D; qa.Spack = c->l2_S; qa.abort = c->l2_abort; qa.fbound = c->fbound; qa.dbg = (c->dbg & 2048) ? 1 : 0;
+        qa.scratch = c->l2_scratch; qa.Dpack = c->l2_D; qa.Spack = c->l2_S; qa.abort = c->l2_abort; qa.fbound = c->fbound;
+        // the two chains of a CU on different SIMDs (QCQPMI_L2_ROT=1): an experiment of round 6, OFF -- measured at n = 1024, 20 x 4096 restarts,
+        // factored: 33.2 -> 35.7 ms (a chain beside a product stream: its fix-up + staging 1.26 k -> 2.21 k cycles per block interval behind
+        // the stream's queued matrix instructions; two chains on one SIMD interleave); without the factor 48.4 -> 48.7 ms (profiles/r06_summary.md)
+        { const char *ev = getenv("QCQPMI_L2_ROT"); const bool rot = ev ? atoi(ev) != 0 : false; qa.cuslot = rot ? c->l2_cuslot : nullptr; }
+        if (qa.cuslot) HIPCHK(c, hipMemsetAsync(c->l2_cuslot, 0, 4096 * sizeof(int), c->stream));
+        qa.dbg = (c->dbg & 2048) ? 1 : 0;
         qa.Gpack = lr ? c->lr_G : nullptr; qa.Upack = lr ? c->lr_U : nullptr; qa.RB = lr ? c->lr_RB : 0;
         const double l0 = stnow();
         (void)hipEventRecord(c->timers[2].beg, c->stream);

@@ -43,6 +43,8 @@ struct CdLife2Args {
     const double *Dpack;         // [NB][256]: strictly upper triangle of the diagonal blocks of P0 (zeros elsewhere)
     const double *Spack;         // [NB][48]: q0 / 2, 1 / P0[i,i] (0 where the diagonal is 0), P0[i,i] of the block's coordinates
     int *abort;                  // [0] set by a wave whose wait ran into the watchdog (a bug, never the data): the launch unwinds
+    int *cuslot;                 // [4096] zeroed before the launch, or NULL: arrival counter per compute unit (key: XCC, SE, CU of HW_ID) -- the
+                                 // second four-wave workgroup of a CU turns its roles by two SIMDs, so that the two chains of a CU do not share a SIMD
     double fbound;               // sum |P0| + sum |q0| + |r0|: scale of the objective for the near-tie test of the linear kind
     // factored objective (P0 = L L^T, L n x r; cd_life2_pack_factor): fragments of L for the products / the updates of Y = L^T X;
     // RB = blocks of 16 rows of Y (0: not factored)

@@ -1043,6 +1043,17 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
     // Both chains of a CU go to SIMD 0 (two latency-bound waves interleave well), the product streams to SIMDs 1-3.
     // If the waves do not cover the SIMDs evenly the roles fall back to the wave index (slower, equally correct).
     if ((tid0 & 63) == 0) simdof[wave] = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)));       // HW_ID[5:4]
+    if (NMW == 3 && TILES == 1 && tid0 == 0) {
+        // which of its CU's workgroups is this one?  (round 6 experiment, off by default -- capi.hip: with the factored objective a
+        // multiplying wave has 48 matrix instructions per block interval and the SIMD that carries BOTH chains of the CU sets the pace;
+        // a chain beside a product stream turned out slower still)
+        int arrival = 0;
+        if (a0.cuslot) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+            arrival = l2_add(l2_g(a0.cuslot) + (((xcc & 15) << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15)), 1);
+        }
+        simdof[8] = (arrival & 1) ? 2 : 0;
+    }
     if (tid0 < 64 * TILES) {
         long long *cs_ = l2_tl(cst, tid0 >> 6, TD);
 #pragma unroll
@@ -1065,7 +1076,7 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
             rank += (s == mys && w < wave) ? 1 : 0;
         }
         const bool even = cnt[0] == NW / 4 && cnt[1] == NW / 4 && cnt[2] == NW / 4 && cnt[3] == NW / 4;
-        if (NMW == 3 && TILES == 1) role = even ? mys : wave;
+        if (NMW == 3 && TILES == 1) role = even ? ((mys + simdof[8]) & 3) : wave;
         else if (TILES == 2) { role = even ? mys : (wave & 3); rtile = even ? rank : (wave >> 2); }      // SIMD s: the waves of role s of both tiles
         else if (even) role = (mys == 0) ? (rank == 0 ? 0 : 7) : mys + 3 * rank;      // SIMD s: waves s (, s + 3); SIMD 0: the chain and wave 7
         else role = wave;

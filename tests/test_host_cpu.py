@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     L = _ffi.lib()
-    assert L.qcqpmi_abi_version() == 5
+    assert L.qcqpmi_abi_version() == 6
     assert L.qcqpmi_device_count() >= 0
 
 

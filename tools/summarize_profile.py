@@ -108,7 +108,9 @@ hdr = ['# rocprofv3 summary %s' % tag, '',
        '(separate runs, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is doubled (gfx950 reports half the bytes of',
        'wide coalesced reads); WRITE_SIZE is taken as is (uncalibrated).  Pass 5 `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`:',
        'fraction of the SIMD-cycles of the launch during which the matrix pipe is busy (all MFMAs issued, useful or not).', '']
-open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(hdr + lines) + '\n')
+notes = os.path.join(dst, tag + '_notes.md')          # hand-written findings of the round (resource usage, stage split, experiments): appended
+tail = ['', open(notes).read().rstrip()] if os.path.exists(notes) else []
+open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(hdr + lines + tail) + '\n')
 json.dump(out, open(os.path.join(dst, tag + '_summary.json'), 'w'), indent=1, sort_keys=True)
 print('\n'.join(lines))
 print(json.dumps(out)[:600])
