@@ -197,6 +197,14 @@ def secondary_records(device, sdr_full=False):
         n = 1024
         funcs, _, _ = problems.boolean_least_squares(n, 256, seed=1)
         e = Engine(QCQPForm.from_arrays(funcs), device=device)
+        try:        # the headline's objective factor (P0 = L L^T of rank 256: the lifecycle kernel carries L^T X), as in main()
+            from qcqp_amd import lowrank
+            P0s = funcs[0][0]
+            Lf = lowrank.objective_factor(P0s.toarray() if hasattr(P0s, 'toarray') else np.asarray(P0s), max_rank=288)
+            if Lf is not None:
+                e.cd_set_objective_factor(Lf)
+        except Exception:
+            pass
         pts = []
         stream_kernel = None
         for R, K in ((4096, 40), (512, 160)):
