@@ -1573,12 +1573,12 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     // kernel: a debug switch, kept as the independent implementation the tests compare against.
     // factored objective (qcqpmi_cd_set_objective_factor): cd_life_kernel's products through Y = L^T X -- half the matrix work and less
     // per block interval, a positive diagonal (band / gen kinds), three multiplying waves per tile
-    const bool lr = use2 && c->lr_RB > 0 && nmw == 3 && kind != L2_KIND_LIN && c->life_version != 3 && cd_life2_factor_ok(c->dp, 16 * (int64_t)c->lr_RB);
+    const bool lr = use2 && c->lr_RB > 0 && nmw == 3 && (kind == L2_KIND_BAND || kind == L2_KIND_GEN) && c->life_version != 3 && cd_life2_factor_ok(c->dp, 16 * (int64_t)c->lr_RB);
     if (lr) cs2 = 0;
     if (!use2) {
         if (!eligible || c->life_version != 1)
-            return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernel needs separable constraints of ONE class with one constraint per "
-                        "coordinate, a diagonal of P0 that is positive everywhere or zero everywhere, and 48 <= n <= 2304: use qcqpmi_cd_run per population");
+            return fail(c, QCQPMI_EUNSUPPORTED, "cd_stream_run: the lifecycle kernel needs separable constraints -- at most four classes of coordinates, at most two constraints "
+                        "per coordinate --, a diagonal of P0 that is positive everywhere or zero everywhere, and 48 <= n <= 2304: use qcqpmi_cd_run per population");
         const int NBq = (int)(c->n16 / 16);
         cs = (c->dbg & 128) ? ((c->dbg >> 8) & 7) : 4;
         cs = cs > RQ_CSMAX ? RQ_CSMAX : cs;
@@ -1625,6 +1625,7 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         if (qa.cuslot) HIPCHK(c, hipMemsetAsync(c->l2_cuslot, 0, 4096 * sizeof(int), c->stream));
         qa.dbg = (c->dbg & 2048) ? 1 : 0;
         qa.Gpack = lr ? c->lr_G : nullptr; qa.Upack = lr ? c->lr_U : nullptr; qa.RB = lr ? c->lr_RB : 0;
+        qa.nclass = c->Kreal;
         const double l0 = stnow();
         (void)hipEventRecord(c->timers[2].beg, c->stream);
         const double l1 = stnow();

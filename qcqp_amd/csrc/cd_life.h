@@ -31,7 +31,10 @@
 
 namespace qcqpmi {
 
-enum { L2_KIND_BAND = 0, L2_KIND_GEN = 1, L2_KIND_LIN = 2 };
+// step kinds.  GENK / LINK (round 6): GEN / LIN for problems with SEVERAL constraint classes (coordinates with different
+// constraint lists: up to four classes) and up to two constraints per coordinate -- the slots keep a feasible set per class, the
+// chain looks its columns' classes up per block
+enum { L2_KIND_BAND = 0, L2_KIND_GEN = 1, L2_KIND_LIN = 2, L2_KIND_GENK = 3, L2_KIND_LINK = 4 };
 
 struct CdLife2Args {
     DevProblem P;
@@ -50,12 +53,13 @@ struct CdLife2Args {
     // RB = blocks of 16 rows of Y (0: not factored)
     const double *Gpack, *Upack;
     int RB;
+    int nclass;                  // multi-class kinds: classes among the real coordinates (<= 4; class k = DevProblem::krep[k])
     int dbg;                     // timing experiments (results INVALID when != 0): 1 = every block row reads the fragments of rows 0..7 (an L2-resident stream)
 };
 
 // does the kernel take this problem?  nmw / cs / kind: the instantiation (multiplying waves 3 | 7, chain share, step kind)
 bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, int *nmw, int *cs, int *kind);
-size_t cd_life2_lds_bytes(int nmw, int cs, int tiles, int lr);
+size_t cd_life2_lds_bytes(int nmw, int cs, int tiles, int lr, int kind);
 bool cd_life2_factor_ok(const DevProblem &P, int64_t r);
 int cd_life2_pack_factor(const double *Lrow, double *Gpack, double *Upack, int NB, int RB, hipStream_t st);
 int cd_life2_max_wgs(int nmw, int cus, int tiles);

@@ -137,12 +137,16 @@ __device__ __attribute__((always_inline)) inline v4d_ l2_product(v2d_ (&ar)[2 * 
 //   cst: the chain wave's per-lane state between episodes [field][lane], phase-1 words, par
 //   LR (factored objective, see l2_mfma_lr_role): ytile L2_YBMAX x 256 -- Y = L^T X of the tile's 16 slots between episodes, [row][slot];
 //   pend 2 x 256 -- the moves of the two blocks a sweep rewrites last, [j][r], until the next episode has applied them
+//   TC: the slots' feasible sets [interval][class][slot] (one class; L2_KCL classes of up to three intervals for the multi-class
+//   kinds), clsb 2 x 16 ints: the classes of the staged block's coordinates
 constexpr int L2_SHARED_DOUBLES = 8 + 8 + 16 + 8;
 constexpr int L2_YBMAX = 18;          // blocks of 16 rows of Y a tile can hold: factor rank <= 288
 constexpr int L2_YU = 6;              // ... per multiplying wave (three per tile)
-constexpr int l2_tile_doubles(int nmw, int csu, int lr) {
-    return 2 * nmw * 256 + 256 + 256 + 2 * 256 + 2 * 48 + 4 * 256 + csu * 256 + 16 + 4 * 16 + 8 + 8 + 8 + 16 * 4 + 8 * 5 + 64 * 10 + 16 * 3 + 8 * 5 + 32 +
-           (lr ? L2_YBMAX * 256 + 2 * 256 : 0);
+constexpr int L2_KCL = 4;            // constraint classes of the multi-class kinds (GENK / LINK); up to two constraints per coordinate
+constexpr int l2_tile_doubles(int nmw, int csu, int lr, int kcl = 1, int maxc = 1) {
+    return 2 * nmw * 256 + 256 + 256 + 2 * 256 + 2 * 48 + 4 * 256 + csu * 256 + 16 + 8 + 16 * 4 + 8 * 5 + 64 * 10 + 16 * 3 + 8 * 5 + 32 +
+           (lr ? L2_YBMAX * 256 + 2 * 256 : 0) +
+           2 * (maxc + 1) * 16 * kcl + 2 * 8 * kcl + (kcl > 1 ? 16 : 0);      // the feasible-set table (per class), the staged class ids
 }
 #define L2_LDS_VIEW(tile_) \
     extern __shared__ double smem[]; \
@@ -150,7 +154,7 @@ constexpr int l2_tile_doubles(int nmw, int csu, int lr) {
     int *simdof = (int *)(smem + 8); \
     int *p1cols = (int *)(smem + 16); \
     int *jn = (int *)(smem + 32); \
-    double *sp = smem + L2_SHARED_DOUBLES + (tile_) * l2_tile_doubles(NMW, CSU, LRV); \
+    double *sp = smem + L2_SHARED_DOUBLES + (tile_) * l2_tile_doubles(NMW, CSU, LRV, KCLV, MAXC); \
     double *part2 = sp; sp += 2 * NMW * 256; \
     double *fixp = sp; sp += 256; \
     double *gtile = sp; sp += 256; \
@@ -159,12 +163,6 @@ constexpr int l2_tile_doubles(int nmw, int csu, int lr) {
     double *ring = sp; sp += 4 * 256; \
     double *cshare = sp; sp += CSU * 256; \
     double *slk = sp; sp += 16; \
-    SetTable<MAXC> TC; \
-    TC.slots = 16; \
-    TC.lo = sp; sp += 2 * 16; \
-    TC.hi = sp; sp += 2 * 16; \
-    TC.n = (int *)sp; sp += 8; \
-    TC.slow = (int *)sp; sp += 8; \
     rq_lds_int *sy = (rq_lds_int *)(int *)sp; sp += 8; \
     double *of0 = sp; sp += 16; \
     long long *ovis = (long long *)sp; sp += 16; \
@@ -183,9 +181,16 @@ constexpr int l2_tile_doubles(int nmw, int csu, int lr) {
     int *p1fin = (int *)sp; sp += 8; \
     int *p1sw = (int *)sp; sp += 8; \
     int *p1st = (int *)sp; sp += 8; \
-    L2Par *par = (L2Par *)sp; sp += 32; \
+    L2Par *par = (L2Par *)sp; sp += 32;      /* (sizeof(L2Par) <= 256 bytes: static_assert below) */ \
     double *ytile = sp; sp += LRV ? L2_YBMAX * 256 : 0; \
-    double *pend = sp; sp += LRV ? 2 * 256 : 0;
+    double *pend = sp; sp += LRV ? 2 * 256 : 0; \
+    SetTable<MAXC> TC;       /* last: the roles that never look at it (MAXC = KCLV = 1 there) see every other offset unchanged */ \
+    TC.slots = 16 * KCLV; \
+    TC.lo = sp; sp += (MAXC + 1) * 16 * KCLV; \
+    TC.hi = sp; sp += (MAXC + 1) * 16 * KCLV; \
+    TC.n = (int *)sp; sp += 8 * KCLV; \
+    TC.slow = (int *)sp; sp += 8 * KCLV; \
+    int *clsb = (int *)sp;   /* [2][16] class of the coordinates of the staged block, by interval parity (multi-class kinds) */
 // the same per-slot array of the other tile (every tile block has the same layout)
 template <class T>
 __device__ __attribute__((always_inline)) inline T *l2_tl(T *p, int t, int tile_doubles) { return (T *)((double *)p + t * tile_doubles); }
@@ -203,7 +208,9 @@ struct L2Par {
     long long num_iters, n16;
     double tol, r0, fbound;
     int NB, KS, n, nlast, Rtotal, dbg;
+    const int *cls;                       // [n16] class of each coordinate (multi-class kinds)
 };
+static_assert(sizeof(L2Par) <= 32 * sizeof(double), "L2Par outgrew its LDS slot");
 __device__ __attribute__((always_inline)) inline int l2_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __attribute__((always_inline)) inline long long l2_uni(long long v) {
     const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
@@ -220,11 +227,12 @@ __device__ __attribute__((always_inline)) inline T *l2_uni(T *p) { return (T *)(
 template <int NMW, int CS>
 __device__ __attribute__((noinline)) void l2_mfma_role(int m_in, int t_in) {
     constexpr int MAXC = 1;
+    constexpr int KCLV = 1;
     constexpr int CSU = CS > 0 ? CS : 1;
     constexpr int LRV = 0;
     const int tile = l2_uni(t_in);                 // the tile of the workgroup this wave multiplies for
     L2_LDS_VIEW(tile)
-    (void)ytile; (void)pend;
+    (void)ytile; (void)pend; (void)clsb;
     (void)fixp; (void)gtile; (void)DU2; (void)sc2; (void)cshare; (void)slk; (void)TC; (void)of0; (void)ovis; (void)oacc; (void)oswp; (void)sid; (void)snew;
     (void)sfin; (void)ost; (void)ctl; (void)cst; (void)sseed; (void)sfirst; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols; (void)jn;
     const int lane = threadIdx.x & 63;
@@ -383,11 +391,13 @@ __device__ __attribute__((noinline)) void l2_mfma_role(int m_in, int t_in) {
 template <int NMW>
 __device__ __attribute__((noinline)) void l2_mfma_lr_role(int m_in, int t_in) {
     constexpr int MAXC = 1;
+    constexpr int KCLV = 1;
     constexpr int CSU = 1;
     constexpr int LRV = 1;
     constexpr int YU = L2_YU;
     const int tile = l2_uni(t_in);
     L2_LDS_VIEW(tile)
+    (void)clsb;
     (void)fixp; (void)gtile; (void)DU2; (void)sc2; (void)cshare; (void)slk; (void)TC; (void)of0; (void)ovis; (void)oacc; (void)oswp; (void)sid; (void)snew;
     (void)sfin; (void)ost; (void)ctl; (void)cst; (void)sseed; (void)sfirst; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols; (void)jn;
     const int lane = threadIdx.x & 63;
@@ -518,14 +528,18 @@ __device__ __attribute__((noinline)) void l2_mfma_lr_role(int m_in, int t_in) {
 // ========================================================================== chain role (a real function as well)
 template <int NMW, int CS, int KIND, int TILES, int LR>
 __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
-    constexpr int MAXC = 1;
+    constexpr bool MULTI = KIND == L2_KIND_GENK || KIND == L2_KIND_LINK;       // several classes / two constraints per coordinate
+    constexpr int BK = KIND == L2_KIND_GENK ? L2_KIND_GEN : KIND == L2_KIND_LINK ? L2_KIND_LIN : KIND;      // the arithmetic of a step
+    constexpr int MAXC = MULTI ? 2 : 1;
+    constexpr int KCLV = MULTI ? L2_KCL : 1;
     constexpr int CSU = CS > 0 ? CS : 1;
     constexpr int LRV = LR;                        // factored objective (l2_mfma_lr_role): the ring carries the block's MOVES, no share
     static_assert(!LR || CS == 0, "factored objective: the chain has no share of the contraction");
-    constexpr bool PRE = KIND == L2_KIND_LIN;      // a restart's phase 2 starts with a frozen sweep that evaluates f0
+    static_assert(!MULTI || (TILES == 1 && !LR), "multi-class kinds: one tile per workgroup, no objective factor");
+    constexpr bool PRE = BK == L2_KIND_LIN;        // a restart's phase 2 starts with a frozen sweep that evaluates f0
     const int tile = TILES > 1 ? l2_uni(t_in) : 0; // the tile whose 16 slots this chain steps
     L2_LDS_VIEW(tile)
-    (void)ytile; (void)pend;
+    (void)ytile; (void)pend; (void)clsb;
     (void)slk; (void)snew; (void)p1key; (void)p1upd; (void)p1fin; (void)p1sw; (void)p1st; (void)gatep; (void)simdof; (void)p1cols; (void)jn;
     const int lane = threadIdx.x & 63, r = lane >> 2, gq = lane & 3;
     LG const double *Apk = l2_g(l2_uni(par->Apack));
@@ -534,6 +548,7 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
     LG const double *Spk = l2_g(l2_uni(par->Spack));
     LG double *Xg = l2_g(l2_uni(par->Xg));
     LG const int *pnext = l2_g(l2_uni(par->next));
+    LG const int *clsg = l2_g(l2_uni(par->cls));
     unsigned long long *pprof = l2_uni(par->prof);
     const int pRtotal = l2_uni(par->Rtotal);
     const int NB = l2_uni(par->NB), KS = l2_uni(par->KS), nlast = l2_uni(par->nlast);
@@ -553,16 +568,18 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
     const double syma = two ? Ul1 : 0.0, symb = two ? Uh1 : Uh0;
     const double gmid = two ? 0.5 * (Uh0 + Ul1) : QM_INF;
     const double linL = Ul0, linH = two ? Uh1 : Uh0;
-    double tl = 0.0;
-    if (KIND == L2_KIND_LIN) {
-        // candidates of the reference's end-point comparison (utilities.py:275-288) differ by slope x distance; they
-        // are told apart safely when that exceeds 1e-12 of the objective's scale (rounding: 1e-16 of it)
-        const double w0 = Uh0 - Ul0, w1 = two ? Uh1 - Ul1 : w0;
+    // candidates of the reference's end-point comparison (utilities.py:275-288) differ by slope x distance; they
+    // are told apart safely when that exceeds 1e-12 of the objective's scale (rounding: 1e-16 of it)
+    auto lin_tl = [&](double l0_, double h0_, double l1_, double h1_, bool two_) {
+        const double lL = l0_, lH = two_ ? h1_ : h0_;
+        const double w0 = h0_ - l0_, w1 = two_ ? h1_ - l1_ : w0;
         const double wmin = w0 < w1 ? w0 : w1;
-        const double hh = fabs(linL) > fabs(linH) ? fabs(linL) : fabs(linH);
+        const double hh = fabs(lL) > fabs(lH) ? fabs(lL) : fabs(lH);
         const double scale = a.fbound * (hh * hh > 1.0 ? hh * hh : 1.0);
-        tl = (wmin > 0.0) ? 0.5e-12 * scale / wmin : QM_INF;
-    }
+        return (wmin > 0.0) ? 0.5e-12 * scale / wmin : QM_INF;
+    };
+    double tl = 0.0;
+    if (BK == L2_KIND_LIN && !MULTI) tl = lin_tl(Ul0, Uh0, Ul1, Uh1, two);
     struct { int upd_counter, visits, accepted, sweeps, status; bool conv; } S;      // (32-bit in the loop: < 2^31 visits per restart)
     S.upd_counter = (int)cst[0 * 64 + lane]; S.visits = (int)cst[1 * 64 + lane]; S.accepted = (int)cst[2 * 64 + lane];
     S.sweeps = (int)cst[3 * 64 + lane]; S.conv = cst[4 * 64 + lane] != 0; S.status = (int)cst[5 * 64 + lane];
@@ -597,6 +614,7 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
     #pragma unroll
         for (int e = 0; e < 4; e++) DU2[lane + 64 * e] = d4[e];
         if (lane < 48) sc2[lane] = s3;
+        if (MULTI && lane < 16) clsb[lane] = (lane < l2_uni(par->n)) ? clsg[lane] : 0;      // (a padded coordinate: class 0, see the column build)
         // virtual interval before the episode: the two blocks that a sweep rewrites last (NB - 2, NB - 1) times the
         // fragments of block rows 0 and 1, exactly as the end of a sweep leaves them (carry: NB - 1 x row 1; the
         // chain's plane: NB - 2 and NB - 1 x row 0 + the chain's share of row 0 without those two)
@@ -665,6 +683,8 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
     #pragma unroll
         for (int e = 0; e < 4; e++) d4[e] = Dpk[(int64_t)bn * 256 + lane + 64 * e];
         if (lane < 48) s3 = Spk[(int64_t)bn * 48 + lane];
+        int c3 = 0;
+        if (MULTI && lane < 16) c3 = (16 * bn + lane < (int)P.n) ? clsg[16 * bn + lane] : 0;
     #pragma unroll
         for (int v = 0; v < 4; v++) xon[v] = Xg[(16 * (int64_t)bn + 4 * v + gq) * 16 + r];
         {   // A fragments of this block's k-steps in the next two block rows (the chain's contribution to both)
@@ -714,9 +734,28 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
         }
         if (b == 0 && !S.conv) S.sweeps++;
         const bool act = !S.conv;
-        const bool actn = act && Un > 0;
-        const double tole = actn ? tolv : QM_INF;     // a restart that is not sweeping never moves (the padded coordinates of
-                                                      // the last block hold a fixed point of the step: see the column build)
+        // the feasible set of the lane's restart for each of its four columns: ONE set for the single-class kinds (registers of the
+        // episode), the set of the column's class from the slots' table for the multi-class kinds
+        int nv[4], slv[4];
+        double l0v[4], h0v[4], l1v[4], h1v[4], midv[4], thrv[4], tlv[4], tolev[4];
+    #pragma unroll
+        for (int v = 0; v < 4; v++) {
+            if (MULTI) {
+                const int s_ = clsb[cur * 16 + 4 * v + gq] * 16 + r;
+                nv[v] = TC.n[s_]; slv[v] = TC.slow[s_];
+                l0v[v] = TC.lo[s_]; h0v[v] = TC.hi[s_]; l1v[v] = TC.lo[16 * KCLV + s_]; h1v[v] = TC.hi[16 * KCLV + s_];
+                const bool two_ = nv[v] >= 2;
+                midv[v] = two_ ? 0.5 * (h0v[v] + l1v[v]) : QM_INF;
+                thrv[v] = two_ ? 1e-7 * (l1v[v] - h0v[v]) : 0.0;
+                tlv[v] = (BK == L2_KIND_LIN) ? lin_tl(l0v[v], h0v[v], l1v[v], h1v[v], two_) : 0.0;
+                if (BK == L2_KIND_LIN) h1v[v] = two_ ? h1v[v] : h0v[v];          // (linear kind: h1v = the highest end point)
+            } else {
+                nv[v] = Un; slv[v] = Uslow; l0v[v] = Ul0; h0v[v] = Uh0; l1v[v] = Ul1; h1v[v] = (BK == L2_KIND_LIN) ? linH : Uh1;
+                midv[v] = gmid; thrv[v] = thr; tlv[v] = tl;
+            }
+            tolev[v] = (act && nv[v] > 0) ? tolv : QM_INF;     // a restart that is not sweeping never moves (the padded coordinates of
+                                                               // the last block hold a fixed point of the step: see the column build)
+        }
         L2_TICK(pt_sum)
         // ---- the 16 steps: only what the next step waits for
     #pragma unroll
@@ -724,18 +763,18 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
             const int v = c >> 2, go = c & 3;
             // every lane works on its own column 4 v + gq; only the owner quad-lane (gq == go) is at step c
             double pick;
-            if (KIND == L2_KIND_BAND) {
+            if (BK == L2_KIND_BAND) {
                 const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);          // vertex of the scalar objective
                 pick = __builtin_copysign(fmin(fmax(fabs(xv), syma), symb), xv);
-            } else if (KIND == L2_KIND_GEN) {
+            } else if (BK == L2_KIND_GEN) {
                 const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);
-                const double p0 = fmin(fmax(xv, Ul0), Uh0), p1 = fmin(fmax(xv, Ul1), Uh1);
-                pick = (xv > gmid) ? p1 : p0;
+                const double p0 = fmin(fmax(xv, l0v[v]), h0v[v]), p1 = fmin(fmax(xv, l1v[v]), h1v[v]);
+                pick = (xv > midv[v]) ? p1 : p0;
             } else {
-                pick = (gb[v] > 0.0) ? linL : linH;                               // linear: the end point against the slope
+                pick = (gb[v] > 0.0) ? l0v[v] : h1v[v];                           // linear: the end point against the slope
             }
             const double dlt = pick - xo[v];
-            const double dl = (fabs(dlt) > tole) ? dlt : 0.0;
+            const double dl = (fabs(dlt) > tolev[v]) ? dlt : 0.0;
             double delta;
             if (go == 0) delta = rq_quad_bcast<0x00>(dl);
             else if (go == 1) delta = rq_quad_bcast<0x55>(dl);
@@ -747,38 +786,38 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
         L2_TICK(pt_steps)
         // ---- once per block, per own column: the decision again from the frozen G (bit-identical to what the step
         // computed when the lane was the owner), new x, near-tie test, move mask, objective tracking
-        bool allfar = true;
+        bool needgen = false;      // a real column of this lane whose decision is near a tie or whose set has an infinite end / a third interval
         unsigned mv = 0;
         double fadd = 0.0;
     #pragma unroll
         for (int v = 0; v < 4; v++) {
             double pick;
             bool far;
-            if (KIND == L2_KIND_BAND) {
+            if (BK == L2_KIND_BAND) {
                 const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);
                 pick = __builtin_copysign(fmin(fmax(fabs(xv), syma), symb), xv);
                 far = fabs(xv) > thr;                                             // false for NaN as well
-            } else if (KIND == L2_KIND_GEN) {
+            } else if (BK == L2_KIND_GEN) {
                 const double xv = __builtin_fma(-gb[v], rto[v], xo[v]);
-                const double p0 = fmin(fmax(xv, Ul0), Uh0), p1 = fmin(fmax(xv, Ul1), Uh1);
-                pick = (xv > gmid) ? p1 : p0;
-                far = fabs(xv - gmid) > thr;
+                const double p0 = fmin(fmax(xv, l0v[v]), h0v[v]), p1 = fmin(fmax(xv, l1v[v]), h1v[v]);
+                pick = (xv > midv[v]) ? p1 : p0;
+                far = fabs(xv - midv[v]) > thrv[v];
             } else {
-                pick = (gb[v] > 0.0) ? linL : linH;
-                far = fabs(gb[v]) > tl;
+                pick = (gb[v] > 0.0) ? l0v[v] : h1v[v];
+                far = fabs(gb[v]) > tlv[v];
             }
             const double dlt = pick - xo[v];
-            const bool mvd = fabs(dlt) > tole;
+            const bool mvd = fabs(dlt) > tolev[v];
             const double d = mvd ? dlt : 0.0;
             xn[v] = mvd ? pick : xo[v];
-            allfar = allfar && (far || 4 * v + gq >= ncol);
+            needgen = needgen || (nv[v] > 0 && (4 * v + gq < ncol ? (!far || slv[v] != 0) : (!MULTI && slv[v] != 0)));
             mv |= mvd ? (1u << (4 * v + gq)) : 0u;
             // f(x + d e_i) - f(x) = d (2 (P x)_i + q_i + P_ii d) = d (t2 d + 2 g):  g = G_i + q_i / 2 contains P_ii x_i
             fadd = __builtin_fma(d, __builtin_fma(t2o[v], d, gb[v] + gb[v]), fadd);
         }
         mv = rq_quad_or(mv);                                                       // bit c = coordinate c moved
         // per RESTART: does the block need the reference's arithmetic?  Only those restarts walk the generic loop
-        const bool redo = rq_quad_or((act && Un > 0 && (!allfar || Uslow != 0)) ? 1u : 0u) != 0u;
+        const bool redo = rq_quad_or((act && needgen) ? 1u : 0u) != 0u;
         auto fast_commit = [&]() {
             if (act) {
                 fpart += fadd;
@@ -824,10 +863,25 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
                 double fa = rq_quad_sum(facc);
                 const uint64_t dseed = sseed[r], dfirst = sfirst[r];
                 FeasSet<MAXC> C;
-                C.n = Un; C.lo[0] = TC.lo[r]; C.hi[0] = TC.hi[r]; C.lo[1] = TC.lo[16 + r]; C.hi[1] = TC.hi[16 + r];
+                C.n = Un;
+#pragma unroll
+                for (int j = 0; j <= MAXC; j++) { C.lo[j] = TC.lo[j * 16 * KCLV + r]; C.hi[j] = TC.hi[j * 16 * KCLV + r]; }
+                int cslow = Uslow;
+                double ctl_ = tl, clinL = linL, clinH = linH;
 #pragma unroll
                 for (int v = 0; v < 4; v++) rb[(4 * v + gq) * 16 + r] = xo[v];
                 for (int c = 0; c < ncol; c++) {
+                    if (MULTI) {       // the set of the coordinate's class
+                        const int s_ = clsb[cur * 16 + c] * 16 + r;
+                        C.n = TC.n[s_]; cslow = TC.slow[s_];
+#pragma unroll
+                        for (int j = 0; j <= MAXC; j++) { C.lo[j] = TC.lo[j * 16 * KCLV + s_]; C.hi[j] = TC.hi[j * 16 * KCLV + s_]; }
+                        if (BK == L2_KIND_LIN) {
+                            const bool two_ = C.n >= 2;
+                            clinL = C.lo[0]; clinH = two_ ? C.hi[1] : C.hi[0];
+                            ctl_ = lin_tl(C.lo[0], C.hi[0], C.lo[1], C.hi[1], two_);
+                        }
+                    }
                     const int64_t i = 16 * (int64_t)b + c;
                     const double t2g = dgb[c];
                     const double xi = rb[c * 16 + r];
@@ -838,11 +892,11 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
                     DrawKey dk{dseed, dfirst + (uint64_t)sid[r], (uint32_t)i, (uint32_t)(G.sweeps - 1) | 0x80000000u, 0u};
                     double xnew = xi;
                     int got;
-                    if (KIND == L2_KIND_LIN && Uslow == 0 && fabs(gc) > tl) {
+                    if (BK == L2_KIND_LIN && cslow == 0 && C.n > 0 && fabs(gc) > ctl_) {
                         // linear kind, the slope is far from a tie: the end point against the slope IS what the reference's end-point
                         // comparison returns (utilities.py:275-288 picks among the table's own values: nothing to round) -- only the
                         // coordinates that are near a tie pay for the replay.  (Unweighted MAXCUT has a tie in almost every block.)
-                        xnew = (gc > 0.0) ? linL : linH;
+                        xnew = (gc > 0.0) ? clinL : clinH;
                         got = G.conv ? 0 : 1;
                     } else {
                         got = G.conv ? 0 : onevar_minimise<MAXC>(t2g, t1, t0, C, dk, &xnew);
@@ -963,6 +1017,7 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
     #pragma unroll
             for (int e = 0; e < 4; e++) DU2[nx * 256 + lane + 64 * e] = d4[e];
             if (lane < 48) sc2[nx * 48 + lane] = s3;
+            if (MULTI && lane < 16) clsb[nx * 16 + lane] = c3;
         }
         L2_TICK(pt_fix)
         b = bn;
@@ -1019,15 +1074,19 @@ __device__ __attribute__((noinline)) void l2_chain_role(int t_in) {
 template <int NMW, int CS, int KIND, int TILES, int LR>
 __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_life_kernel(CdLife2Args a0) {
     const CdLife2Args &a = a0;
-    constexpr int MAXC = 1;
+    constexpr bool MULTI = KIND == L2_KIND_GENK || KIND == L2_KIND_LINK;       // several constraint classes / two constraints per coordinate
+    constexpr int BK = KIND == L2_KIND_GENK ? L2_KIND_GEN : KIND == L2_KIND_LINK ? L2_KIND_LIN : KIND;
+    constexpr int MAXC = MULTI ? 2 : 1;
+    constexpr int KCLV = MULTI ? L2_KCL : 1;
     constexpr int CSU = CS > 0 ? CS : 1;
     constexpr int LRV = LR;                        // factored objective P0 = L L^T (l2_mfma_lr_role)
+    static_assert(!MULTI || (TILES == 1 && !LR), "multi-class kinds: one tile per workgroup, no objective factor");
     constexpr int NT = (NMW == 3 && TILES == 1) ? 256 : 512;
     constexpr int NW = NT / 64;
     constexpr int NS = 16 * TILES;                 // slots of the workgroup
     constexpr int TD = l2_tile_doubles(NMW, CSU, LR);  // doubles of one tile's LDS block
-    static_assert(!LR || (NMW == 3 && CS == 0 && KIND != L2_KIND_LIN), "factored objective: three multiplying waves per tile, no chain share, a positive diagonal");
-    constexpr bool PRE = KIND == L2_KIND_LIN;      // a restart's phase 2 starts with a frozen sweep that evaluates f0 (see the chain role)
+    static_assert(!LR || (NMW == 3 && CS == 0 && BK != L2_KIND_LIN), "factored objective: three multiplying waves per tile, no chain share, a positive diagonal");
+    constexpr bool PRE = BK == L2_KIND_LIN;        // a restart's phase 2 starts with a frozen sweep that evaluates f0 (see the chain role)
     static_assert(TILES == 1 || NMW == 3, "two tiles per workgroup: eight waves = two chains + two x three multiplying waves");
     const DevProblem &P = a.P;
     const int tid0 = threadIdx.x;
@@ -1035,7 +1094,21 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
     const int64_t n16 = P.n16;
     const int NB = (int)P.NB, KS = (int)P.KS;
     L2_LDS_VIEW(0)                                  // tile 0's block; tile t: l2_tl(array, t, TD)
-    (void)fixp; (void)gtile; (void)DU2; (void)sc2; (void)ring; (void)cshare; (void)of0; (void)ovis; (void)oacc; (void)oswp; (void)ost; (void)ytile; (void)pend;
+    (void)fixp; (void)gtile; (void)DU2; (void)sc2; (void)ring; (void)cshare; (void)of0; (void)ovis; (void)oacc; (void)oswp; (void)ost; (void)ytile; (void)pend; (void)clsb;
+    // the feasible sets of slot `sc_` of tile `st_` at slack `slack_`: one per class (the single class of the other kinds); a set with a
+    // third interval (two constraints per coordinate can leave one) takes the generic path like one with an infinite end.
+    // (a macro, not a lambda: with the sets computed inside a closure the backend stopped at "illegal VGPR to SGPR copy")
+#define L2_STORE_SETS(st_, sc_, slack_) {                                                                                              \
+        SetTable<MAXC> T2 = TC;                                                                                                          \
+        T2.lo = l2_tl(TC.lo, st_, TD); T2.hi = l2_tl(TC.hi, st_, TD); T2.n = l2_tl(TC.n, st_, TD); T2.slow = l2_tl(TC.slow, st_, TD);    \
+        const int nk_ = MULTI ? a0.nclass : 1;                                                                                           \
+        for (int k_ = 0; k_ < nk_; k_++) {                                                                                               \
+            FeasSet<MAXC> C_;                                                                                                            \
+            compute_set<MAXC>(P, P.krep[k_], slack_, C_);                                                                                \
+            store_set<MAXC>(T2, 16 * k_ + (sc_), C_);                                                                                    \
+            if (MULTI && C_.n > 2) T2.slow[16 * k_ + (sc_)] = 1;                                                                         \
+        }                                                                                                                                \
+    }
     LG double *Xg0 = l2_g(a0.scratch) + (int64_t)blockIdx.x * TILES * n16 * 16;       // this workgroup's X tiles [tile][j][16]
 
     // ---- roles by hardware SIMD.  The dispatcher deals the waves of a workgroup round robin over the four SIMDs starting
@@ -1096,6 +1169,7 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
         pr->Xg = a0.scratch + ((int64_t)blockIdx.x * TILES + tid0) * n16 * 16; pr->next = a0.b.next; pr->prof = (unsigned long long *)lf0->prof;
         pr->num_iters = a.num_iters; pr->n16 = n16; pr->tol = a.tol; pr->r0 = P.r0; pr->fbound = a.fbound;
         pr->NB = NB; pr->KS = KS; pr->n = (int)P.n; pr->nlast = nlast; pr->Rtotal = (int)lf0->Rtotal; pr->dbg = a0.dbg;
+        pr->cls = P.cls;
     }
     __syncthreads();
 
@@ -1128,11 +1202,7 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
             if (id < 0) {
                 // an empty slot: a zero column that never moves (feasible set of slack 0, restart marked converged)
                 l2_tl(slk, st, TD)[sc] = 0.0;
-                FeasSet<MAXC> C;
-                compute_set<MAXC>(P, P.krep[0], 0.0, C);
-                SetTable<MAXC> T2 = TC;
-                T2.lo = l2_tl(TC.lo, st, TD); T2.hi = l2_tl(TC.hi, st, TD); T2.n = l2_tl(TC.n, st, TD); T2.slow = l2_tl(TC.slow, st, TD);
-                store_set<MAXC>(T2, sc, C);
+                L2_STORE_SETS(st, sc, 0.0)
             }
             if (id >= 0) atomicAdd(&ctl[0], 1);
             *(volatile rq_lds_int *)(l2_tl((int *)sy, st, TD) + sc) = (sc >= RQ_PARTS + NMW) ? 0x7fffffff : 0;
@@ -1209,7 +1279,7 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
                 // matrix work) runs several times faster -- and an even split made the build as slow as its slowest wave.  A visit's
                 // result depends on (restart, coordinate, sweep) only: who computes it is immaterial.
                 // (the Boolean family's class runs TWO visits per lane at once -- p1_band_visit_n: their dependency chains interleave)
-                const bool band2 = cq == 0.0 && rel == RELOP_EQ && cp > 1e-4 && cr < -1e-3;      // workgroup-uniform
+                const bool band2 = !MULTI && cq == 0.0 && rel == RELOP_EQ && cp > 1e-4 && cr < -1e-3;      // workgroup-uniform
                 const int cw = band2 ? 128 : 64;
                 const int nch = (int)((P.n + cw - 1) / cw);
                 for (int64_t t = 0; t < a.num_iters; t++) {
@@ -1248,8 +1318,17 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
                         } else {
                             const int64_t i = (int64_t)(ch % nch) * 64 + lane;
                             if (i < P.n) {
-                                const double xi = l2_p1_visit(cp, cq, cr, rel, i, Xg[i * 16 + cc], a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
-                                if (fl & 1) Xg[i * 16 + cc] = xi;
+                                if (MULTI) {          // the coordinate's own list of constraints (cd_phase1_sep.h, the serial path's visit)
+                                    double xi = Xg[i * 16 + cc];
+                                    P1Visit V;
+                                    p1_sep_visit<MAXC>(P, i, xi, a.tol, lf_viol_tol, sd, gidx, t, V);
+                                    fl = (V.moved ? 1 : 0) | ((-V.status) << 8);
+                                    va = V.vafter;
+                                    if (V.moved) Xg[i * 16 + cc] = xi;
+                                } else {
+                                    const double xi = l2_p1_visit(cp, cq, cr, rel, i, Xg[i * 16 + cc], a.tol, lf_viol_tol, sd, gidx, t, &fl, &va);
+                                    if (fl & 1) Xg[i * 16 + cc] = xi;
+                                }
                             }
                         }
                         const double vmax = l2_wave_max(va);
@@ -1278,9 +1357,17 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
                 double v = -QM_INF;
                 for (int64_t i = tid; i < P.n; i += NT) {
                     const double x = Xg[i * 16 + cc];
-                    const double f = (cp * x + cq) * x + cr;
-                    const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
-                    v = w > v ? w : v;
+                    if (MULTI) {
+                        for (int e = P.cptr[i]; e < P.cptr[i + 1]; e++) {
+                            const double f = (P.cp[e] * x + P.cq[e]) * x + P.cr[e];
+                            const double w = viol_of(f, P.crel[e]);
+                            v = w > v ? w : v;
+                        }
+                    } else {
+                        const double f = (cp * x + cq) * x + cr;
+                        const double w = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+                        v = w > v ? w : v;
+                    }
                 }
                 v = l2_wave_max(v);
                 if (lane == 0) atomicMax(&l2_tl(p1key, ct, TD)[cc], l2_key(v));
@@ -1291,11 +1378,7 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
                 const double mvx = l2_unkey(l2_tl(p1key, st, TD)[sc]);
                 l2_tl(slk, st, TD)[sc] = mvx;
                 l2_tl(gatep, st, TD)[sc] = (mvx < lf_viol_tol && l2_tl(p1st, st, TD)[sc] == 0) ? 1 : 0;
-                FeasSet<MAXC> C;
-                compute_set<MAXC>(P, P.krep[0], mvx, C);
-                SetTable<MAXC> T2 = TC;
-                T2.lo = l2_tl(TC.lo, st, TD); T2.hi = l2_tl(TC.hi, st, TD); T2.n = l2_tl(TC.n, st, TD); T2.slow = l2_tl(TC.slow, st, TD);
-                store_set<MAXC>(T2, sc, C);
+                L2_STORE_SETS(st, sc, mvx)
             }
             __syncthreads();
             if (nlast < 16) {
@@ -1307,9 +1390,10 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
                     if (l2_tl(snew, ct, TD)[cc] || l2_tl(sid, ct, TD)[cc] < 0) {
                         const int nn = l2_tl(TC.n, ct, TD)[cc];
                         double xp = 0.0;
-                        if (KIND == L2_KIND_BAND) xp = nn >= 2 ? l2_tl(TC.lo, ct, TD)[16 + cc] : 0.0;
-                        else if (KIND == L2_KIND_GEN) xp = nn >= 1 ? l2_tl(TC.hi, ct, TD)[cc] : 0.0;
-                        else xp = nn >= 2 ? l2_tl(TC.hi, ct, TD)[16 + cc] : l2_tl(TC.hi, ct, TD)[cc];
+                        // (multi-class kinds: the padded coordinates count as class 0 -- the chain stages class 0 for them)
+                        if (BK == L2_KIND_BAND) xp = nn >= 2 ? l2_tl(TC.lo, ct, TD)[16 * KCLV + cc] : 0.0;
+                        else if (BK == L2_KIND_GEN) xp = nn >= 1 ? l2_tl(TC.hi, ct, TD)[cc] : 0.0;
+                        else xp = nn >= 2 ? l2_tl(TC.hi, ct, TD)[16 * KCLV + cc] : l2_tl(TC.hi, ct, TD)[cc];
                         if (!(xp == xp) || __builtin_isinf(xp)) xp = 0.0;
                         (Xg0 + (int64_t)ct * n16 * 16)[(P.n + row) * 16 + cc] = xp;
                     }
@@ -1407,9 +1491,18 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
                         const int64_t i = w % n16;
                         l2_g(a0.b.X)[((int64_t)(id >> 4) * n16 + i) * 16 + (id & 15)] = xv8[u];
                         if (i < P.n) {
-                            const double f = (cp * xv8[u] + cq) * xv8[u] + cr;
-                            const double vv = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
-                            atomicMax(&l2_tl(p1key, col >> 4, TD)[col & 15], l2_key(vv));
+                            if (MULTI) {
+                                double vv = -QM_INF;
+                                for (int e = P.cptr[i]; e < P.cptr[i + 1]; e++) {
+                                    const double w_ = viol_of((P.cp[e] * xv8[u] + P.cq[e]) * xv8[u] + P.cr[e], P.crel[e]);
+                                    vv = w_ > vv ? w_ : vv;
+                                }
+                                atomicMax(&l2_tl(p1key, col >> 4, TD)[col & 15], l2_key(vv));
+                            } else {
+                                const double f = (cp * xv8[u] + cq) * xv8[u] + cr;
+                                const double vv = (rel == RELOP_EQ) ? fabs(f) : (f > 0.0 ? f : 0.0);
+                                atomicMax(&l2_tl(p1key, col >> 4, TD)[col & 15], l2_key(vv));
+                            }
                         }
                     }
                 }
@@ -1437,6 +1530,8 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
         atomicMax((unsigned long long *)lf0->prof + 16, dtl);
     }
 }
+
+#undef L2_STORE_SETS
 
 // strictly upper triangle of the diagonal blocks (zeros elsewhere) and the per-block scalars the chain stages
 __global__ void l2_pack_kernel(DevProblem P, double *Dpack, double *Spack) {
@@ -1467,8 +1562,12 @@ __global__ void l2_pack_factor_kernel(const double *__restrict__ L, double *__re
 
 template <int NMW, int CS, int TILES, int LR>
 int l2_launch_kind(const CdLife2Args &a, int kind, int wgs, size_t lds, hipStream_t st) {
+    constexpr bool MK = TILES == 1 && !LR;        // the multi-class kinds exist for one tile per workgroup, without an objective factor
+    if (!MK && (kind == L2_KIND_GENK || kind == L2_KIND_LINK)) return (int)hipErrorInvalidValue;
     auto k = kind == L2_KIND_BAND ? cd_life_kernel<NMW, CS, L2_KIND_BAND, TILES, LR> : (kind == L2_KIND_GEN || LR) ? cd_life_kernel<NMW, CS, L2_KIND_GEN, TILES, LR>
-                                                                                                                   : cd_life_kernel<NMW, CS, LR ? L2_KIND_GEN : L2_KIND_LIN, TILES, LR>;
+             : kind == L2_KIND_GENK ? cd_life_kernel<NMW, CS, MK ? L2_KIND_GENK : L2_KIND_GEN, TILES, LR>
+             : kind == L2_KIND_LINK ? cd_life_kernel<NMW, CS, MK ? L2_KIND_LINK : L2_KIND_GEN, TILES, LR>
+                                    : cd_life_kernel<NMW, CS, LR ? L2_KIND_GEN : L2_KIND_LIN, TILES, LR>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3((NMW == 3 && TILES == 1) ? 256 : 512), lds, st, a);
@@ -1477,8 +1576,9 @@ int l2_launch_kind(const CdLife2Args &a, int kind, int wgs, size_t lds, hipStrea
 
 }  // namespace
 
-size_t cd_life2_lds_bytes(int nmw, int cs, int tiles, int lr) {
-    return ((size_t)L2_SHARED_DOUBLES + (size_t)tiles * (size_t)l2_tile_doubles(nmw, cs > 0 ? cs : 1, lr)) * sizeof(double) + 256;
+size_t cd_life2_lds_bytes(int nmw, int cs, int tiles, int lr, int kind) {
+    const bool multi = kind == L2_KIND_GENK || kind == L2_KIND_LINK;
+    return ((size_t)L2_SHARED_DOUBLES + (size_t)tiles * (size_t)l2_tile_doubles(nmw, cs > 0 ? cs : 1, lr, multi ? L2_KCL : 1, multi ? 2 : 1)) * sizeof(double) + 256;
 }
 
 // can the factored-objective kernel take a factor of r columns for this problem?  (rank, the scratch of the column build)
@@ -1497,7 +1597,10 @@ int cd_life2_pack_factor(const double *Lrow, double *Gpack, double *Upack, int N
 int cd_life2_max_wgs(int nmw, int cus, int tiles) { return (nmw == 3 && tiles == 1) ? 2 * cus : cus; }
 
 bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, int *nmw, int *cs, int *kind) {
-    if (!P.sep || P.maxc != 1 || Kreal != 1) return false;
+    // one class with one constraint per coordinate: the BAND / GEN / LIN kinds; up to L2_KCL classes with up to two constraints per
+    // coordinate (every real coordinate constrained): GENK / LINK
+    if (!P.sep || P.maxc < 1 || P.maxc > 2 || Kreal < 1 || Kreal > L2_KCL) return false;
+    const bool multi = P.maxc > 1 || Kreal > 1;
     if (objclass != 1 && objclass != 2) return false;
     const int NB = (int)P.NB;
     if (NB < 3) return false;
@@ -1507,7 +1610,7 @@ bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, 
     else if (NB - 4 <= 7 * RQ_MAXU) { w = 7; c = 4; }
     else return false;
     *nmw = w; *cs = c;
-    *kind = objclass == 2 ? L2_KIND_LIN : (symcls ? L2_KIND_BAND : L2_KIND_GEN);
+    *kind = multi ? (objclass == 2 ? L2_KIND_LINK : L2_KIND_GENK) : objclass == 2 ? L2_KIND_LIN : (symcls ? L2_KIND_BAND : L2_KIND_GEN);
     return true;
 }
 
@@ -1535,7 +1638,7 @@ int cd_life2_launch(const CdLife2Args &a, int nmw, int cs, int kind, int tiles, 
         const int k2 = atoi(ev);
         if (!lr && nmw == 3 && tiles == 1 && (k2 == 0 || k2 == 2 || k2 == 4) && k2 + 3 <= (int)a.P.NB && (int)a.P.NB - k2 <= 3 * RQ_MAXU) cs = k2;
     }
-    const size_t lds = cd_life2_lds_bytes(nmw, cs, tiles, lr);
+    const size_t lds = cd_life2_lds_bytes(nmw, cs, tiles, lr, kind);
     if (getenv("QCQPMI_L2_DEBUG")) {
         int occ = -1;
         hipError_t e = lr ? (tiles == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cd_life_kernel<3, 0, L2_KIND_BAND, 2, 1>, 512, lds)
@@ -1561,6 +1664,8 @@ int cd_life2_launch(const CdLife2Args &a, int nmw, int cs, int kind, int tiles, 
 }
 
 const char *cd_life2_name(int nmw, int kind, int tiles, int lr) {
+    if (kind == L2_KIND_GENK) return nmw == 3 ? "cd_life_kernel<3,gen,classes>" : "cd_life_kernel<7,gen,classes>";
+    if (kind == L2_KIND_LINK) return nmw == 3 ? "cd_life_kernel<3,lin,classes>" : "cd_life_kernel<7,lin,classes>";
     if (lr) return tiles == 2 ? (kind == L2_KIND_BAND ? "cd_life_kernel<3,band,2 tiles,factored>" : "cd_life_kernel<3,gen,2 tiles,factored>")
                               : (kind == L2_KIND_BAND ? "cd_life_kernel<3,band,factored>" : "cd_life_kernel<3,gen,factored>");
     if (tiles == 2) return kind == L2_KIND_BAND ? "cd_life_kernel<3,band,2 tiles>" : kind == L2_KIND_GEN ? "cd_life_kernel<3,gen,2 tiles>" : "cd_life_kernel<3,lin,2 tiles>";

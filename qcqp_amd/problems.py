@@ -59,6 +59,56 @@ def box_least_squares(n, m_rows, bound=1.0, seed=1, ridge=0.1):
     return funcs, False, dict(A=A, b=b)
 
 
+def multi_class(name, n, seed=1):
+    """Separable problems with SEVERAL constraint classes and up to two constraints per coordinate (what cd_life_kernel's GENK / LINK
+    kinds take; the reference treats every coordinate's list on its own, qcqp.py:113-141, 160-176).  Returns funcs (objective first).
+      box3   least squares + ridge; coordinate i carries x^2 <= 1 | x^2 <= 0.49 | x^2 - x/2 - 1/2 <= 0 (= [-1/2, 1]) by i mod 3
+      ann2   least squares + ridge; even i: x^2 <= 1 AND -x^2 <= -1/4 (two intervals [-1, -1/2] u [1/2, 1]); odd i: x^2 == 1
+      lin2   least squares + ridge; TWO LINEAR constraints per coordinate, x <= u_c and -x <= -l_c, bounds by i mod 2
+      cut2   weighted MAXCUT objective (zero diagonal); even i: x^2 == 1, odd i: x^2 <= 1 (a relaxed vertex)"""
+    rs = np.random.RandomState(seed)
+    funcs = []
+    if name == 'cut2':
+        U = np.triu((rs.uniform(size=(n, n)) < 0.5).astype(float), 1) * np.triu(rs.uniform(0.5, 1.5, size=(n, n)), 1)
+        W = U + U.T
+        funcs.append((0.25 * W, np.zeros(n), -0.25 * float(W.sum()), None))
+    else:
+        m_rows = max(4, n // 2)
+        A = rs.randn(m_rows, n)
+        b = rs.randn(m_rows, 1) * np.sqrt(n)
+        P0 = A.T.dot(A) + 0.1 * np.eye(n)
+        funcs.append(((P0 + P0.T) / 2., (-2. * A.T.dot(b)).ravel(), float(b.T.dot(b)[0, 0]), None))
+
+    def quad(i, p, q, r, relop):
+        P = sp.csr_matrix(([float(p)], ([i], [i])), shape=(n, n))
+        qv = np.zeros(n)
+        qv[i] = float(q)
+        funcs.append((P, qv, float(r), relop))
+    for i in range(n):
+        if name == 'box3':
+            if i % 3 == 0:
+                quad(i, 1.0, 0.0, -1.0, '<=')
+            elif i % 3 == 1:
+                quad(i, 1.0, 0.0, -0.49, '<=')
+            else:
+                quad(i, 1.0, -0.5, -0.5, '<=')
+        elif name == 'ann2':
+            if i % 2 == 0:
+                quad(i, 1.0, 0.0, -1.0, '<=')
+                quad(i, -1.0, 0.0, 0.25, '<=')
+            else:
+                quad(i, 1.0, 0.0, -1.0, '==')
+        elif name == 'lin2':
+            lo, hi = ((-0.75, 1.25), (-1.5, 0.5))[i % 2]
+            quad(i, 0.0, 1.0, -hi, '<=')
+            quad(i, 0.0, -1.0, lo, '<=')
+        elif name == 'cut2':
+            quad(i, 1.0, 0.0, -1.0, '==' if i % 2 == 0 else '<=')
+        else:
+            raise KeyError(name)
+    return funcs
+
+
 def maxcut(n, p=0.5, seed=1, weighted=False):
     """maximize 0.25 (sum(W) - x^T W x)  s.t. x_i^2 == 1   (minimise form returned).
     weighted=True draws edge weights from U(0.5, 1.5): no exact ties between cuts."""

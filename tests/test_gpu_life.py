@@ -402,6 +402,74 @@ def test_factored_objective_kernel_vs_serial_oracle_and_itself(eng_mod, orc, fam
     assert 'factored' not in es.last_cd_kernel()
 
 
+MULTI = [
+    # family, n, R, K, num_iters, oracle restarts per population, kernel name
+    ('box3', 100, 70, 2, 1000, 4, 'cd_life_kernel<3,gen,classes>'),      # three classes, n not a multiple of 16
+    ('box3', 256, 40, 2, 30, 4, 'cd_life_kernel<3,gen,classes>'),
+    ('ann2', 96, 70, 2, 1000, 4, 'cd_life_kernel<3,gen,classes>'),       # two constraints per coordinate (two intervals) beside an equality class
+    ('lin2', 130, 50, 2, 60, 4, 'cd_life_kernel<3,gen,classes>'),        # two LINEAR constraints per coordinate, bounds by class
+    ('cut2', 100, 70, 2, 1000, 4, 'cd_life_kernel<3,lin,classes>'),      # zero diagonal (linear scalar objective), two classes
+    ('box3', 1100, 32, 1, 3, 2, 'cd_life_kernel<7,gen,classes>'),        # past 1024: eight waves
+]
+
+
+@pytest.mark.parametrize('fam,n,R,K,iters,norc,kname', MULTI)
+def test_life_kernel_several_classes_vs_oracle_and_serial(eng_mod, orc, fam, n, R, K, iters, norc, kname):
+    """Round 6: the lifecycle launch for separable problems with SEVERAL constraint classes and up to two constraints per coordinate
+    (kinds GENK / LINK: a feasible set per (class, slot), the chain looks its columns' classes up per block; qcqp.py:113-141, 160-176
+    treat every coordinate's list on its own).  `norc` restarts per population through the oracle (points 1e-9, every counter,
+    objective, max violation), ALL restarts against the serial path -- qcqpmi_cd_run: the general phase-2 kernel, which follows the
+    reference's one-variable arithmetic visit by visit where this kernel projects the vertex (1e-9, counters equal) --, the
+    reported values against a fresh evaluation, the per-population winner against select_best."""
+    from qcqp_amd import problems
+    funcs = problems.multi_class(fam, n)
+    es = make(eng_mod, funcs)
+    seed0, sstride, first0, fstride = 900, 2, 5, 30000
+    o = es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=sstride, first_index=first0, first_stride=fstride)
+    assert es.last_cd_kernel() == kname
+    X = es.download()
+    f0e, mve = es.eval()
+    assert rel(o['f0'], f0e) < 1e-10 and np.max(np.abs(o['maxviol'] - mve)) < 1e-12
+    e = make(eng_mod, funcs)
+    for p in range(K):
+        sd, fi = seed0 + p * sstride, first0 + p * fstride
+        sl = slice(p * R, (p + 1) * R)
+        picks = sorted(set(np.linspace(0, R - 1, norc).astype(int).tolist()))
+        for r, x, s1, s2, f_or, v_or in oracle_restarts(orc, funcs, eng_mod, sd, fi, R, picks, iters):
+            k = p * R + r
+            assert rel(X[:, k], x) < 1e-9, (fam, n, p, r, np.max(np.abs(X[:, k] - x)))
+            assert o['sweeps1'][k] == s1[0] or (s1[0] == iters and not o['ran_phase2'][k])
+            assert o['visits2'][k] == s2[1] and o['accepted2'][k] == s2[2], (fam, n, p, r)
+            assert abs(o['f0'][k] - f_or) <= 1e-9 * (1 + abs(f_or)) and abs(o['maxviol'][k] - v_or) <= 1e-12
+        e.randn(R, seed=sd, first_index=fi)
+        outr = e.cd_run(phase1=True, num_iters=iters, seed=sd, first_index=fi)
+        Xr = e.download()
+        assert rel(X[:, sl], Xr) < 1e-9, (fam, n, p, np.max(np.abs(X[:, sl] - Xr)))
+        for key in COUNTERS:
+            assert np.array_equal(o[key][sl], outr[key]), (fam, n, p, key)
+        assert rel(o['f0'][sl], outr['f0']) < 1e-9
+        idx = e.select_best(1e-4)[0]
+        assert o['best_index'][p] == idx and np.array_equal(o['best_x'][p], X[:, p * R + idx])
+    # scheduling invariance, bit for bit: the same restarts as ONE population
+    o1 = es.cd_stream_run(1, R, num_iters=iters, seed=seed0, seed_stride=0, first_index=first0, first_stride=0)
+    assert np.array_equal(es.download(), X[:, :R]) and np.array_equal(o1['f0'], o['f0'][:R])
+
+
+def test_stream_run_refuses_what_the_kinds_do_not_cover(eng_mod):
+    """More than four classes (every coordinate its own bounds) is refused with E_UNSUPPORTED, not misrouted."""
+    from qcqp_amd import problems
+    n = 64
+    funcs = [problems.multi_class('box3', n)[0]]
+    rs = np.random.RandomState(1)
+    import scipy.sparse as sp
+    for i in range(n):
+        funcs.append((sp.csr_matrix(([1.0], ([i], [i])), shape=(n, n)), np.zeros(n), -1.0 - rs.rand(), '<='))
+    e = make(eng_mod, funcs)
+    with pytest.raises(eng_mod.EngineError) as ei:
+        e.cd_stream_run(2, 32, seed=1)
+    assert ei.value.code == eng_mod.E_UNSUPPORTED
+
+
 def _fuzz_shape(rs):
     fam = str(rs.choice(['bls', 'bls', 'box', 'maxcutw']))
     n = int(rs.choice([48, 50, 64, 77, 96, 100, 128, 130, 176, 200, 256, 300, 320]))
