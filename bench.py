@@ -316,6 +316,44 @@ def secondary_records(device, sdr_full=False):
                                   'algorithmic_flops_per_restart_sweep': 2.0 * n * n}})
     except Exception as ex:
         recs.append({'config': 'MAXCUT G(2000, 0.5) through improve(COORD_DESCENT)', 'error': repr(ex)})
+    # separable problems with SEVERAL constraint classes / two constraints per coordinate through the lifecycle launch (round 6: kinds
+    # GENK / LINK of cd_life_kernel; rounds 1-5 ran them one population at a time through the general phase-2 kernel), beside the serial path
+    try:
+        n, R, K = 1024, 2048, 2
+        pts = []
+        for fam, iters in (('ann2', 1000), ('box3', 40), ('cut2', 1000)):
+            funcs = problems.multi_class(fam, n)
+            e = Engine(QCQPForm.from_arrays(funcs), device=device)
+            e.cd_stream_run(1, 512, seed=5, num_iters=iters)
+            e.sync()
+            t0 = time.perf_counter()
+            o = e.cd_stream_run(K, R, seed=6, seed_stride=1, num_iters=iters)
+            e.sync()
+            dt = time.perf_counter() - t0
+            ms = e.kernel_ms(Engine.KERNEL_CD2)
+            kname = e.last_cd_kernel()
+            sw = float(o['visits2'].sum()) / n
+            # the same restarts one population at a time through qcqpmi_pop_randn + qcqpmi_cd_run (what the API did before)
+            t0 = time.perf_counter()
+            for p in range(K):
+                e.randn(R, seed=6 + p)
+                e.cd_run(phase1=True, num_iters=iters, seed=6 + p)
+            e.sync()
+            dts = time.perf_counter() - t0
+            pts.append({'family': fam, 'kernel': kname, 'value': sw / dt, 'kernel_ms_per_launch': ms, 'sweeps_per_restart': sw / (K * R),
+                        'num_iters': iters, 'achieved': sw * 2.0 * n * n / 1e12 / (ms / 1e3), 'frac': sw * 2.0 * n * n / 1e12 / (ms / 1e3) / FP64_PEAK_TFLOPS,
+                        'serial_path_s': dts, 'serial_path_kernel': e.last_cd_kernel(), 'streamed_s': dt, 'speedup_over_serial_path': dts / dt})
+            del e
+        recs.append({'config': 'separable problems with several constraint classes / two constraints per coordinate (problems.multi_class: an annulus class '
+                               'beside an equality class; three box classes; MAXCUT with a relaxed class), n = 1024, 2 populations of 2048 random restarts '
+                               'in one launch of the lifecycle kernel',
+                     'metric': 'restarts x coord-sweeps / s (phase 2)', 'value': pts[0]['value'], 'unit': 'restart-sweeps/s',
+                     'kernel': pts[0]['kernel'], 'by_family': pts,
+                     'roofline': {'bound': 'mfma', 'kernel': pts[0]['kernel'], 'achieved': pts[0]['achieved'], 'peak': FP64_PEAK_TFLOPS,
+                                  'unit': 'TFLOP/s', 'frac': pts[0]['frac'], 'kernel_ms_per_launch': pts[0]['kernel_ms_per_launch'],
+                                  'algorithmic_flops_per_restart_sweep': 2.0 * n * n}})
+    except Exception as ex:
+        recs.append({'config': 'several constraint classes through the lifecycle launch', 'error': repr(ex)})
     # configs[1]'s problem through improve(ADMM): separable constraints x_i^2 = 1 -> bases of unit vectors (round 5)
     try:
         n, R, iters = 1024, 4096, 100

@@ -313,10 +313,14 @@ int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out24);
  * Round 5 (ABI 5): the launch is cd_life_kernel (csrc/cd_life.hip) -- four-wave workgroups, two per CU, the X tile in a private
  * global tile instead of LDS -- and takes every problem with separable constraints of ONE class, one constraint per coordinate
  * (Boolean / MAXCUT x_i^2 == 1, box and disc x_i^2 <= c, one-sided and linear single-coordinate constraints), a diagonal of P0
- * that is positive everywhere or ZERO everywhere (MAXCUT: qcqp.py:152-178 with a linear scalar objective), any 48 <= n <= 2048
- * (n need not be a multiple of 16; 1024 < n <= 2048 runs eight-wave workgroups).  QCQPMI_EUNSUPPORTED otherwise (several
- * classes, several constraints per coordinate, mixed diagonal signs, coupled constraints): use qcqpmi_cd_run per population;
- * a refused call leaves the resident population untouched.  K R < 2^30 (restart tickets are 32-bit; QCQPMI_EINVAL beyond).
+ * that is positive everywhere or ZERO everywhere (MAXCUT: qcqp.py:152-178 with a linear scalar objective), any 48 <= n <= 2304
+ * (n need not be a multiple of 16; 1024 < n <= 2304 runs eight-wave workgroups).  Round 6 (ABI 6): ALSO problems with up to four
+ * classes of coordinates (coordinates whose constraint lists are bit-identical share a class) and up to two constraints per
+ * coordinate -- boxes with different bounds, an annulus beside an equality, two linear bounds, MAXCUT with relaxed vertices
+ * (qcqp.py:113-141, 160-176 treat every coordinate's list on its own); ONE lifecycle kernel for every shape; with
+ * qcqpmi_cd_set_objective_factor the kernel carries L^T X instead of multiplying with P0.  QCQPMI_EUNSUPPORTED otherwise (more
+ * than four classes, three or four constraints per coordinate, mixed diagonal signs, coupled constraints, n > 2304): use
+ * qcqpmi_cd_run per population; a refused call leaves the resident population untouched.  K R < 2^30 (restart tickets are 32-bit; QCQPMI_EINVAL beyond).
  * Near-ties: a restart whose decision is within rounding of a tie is replayed in the reference's arithmetic like in
  * qcqpmi_cd_run; for a positive diagonal the replay sees the objective RELATIVE to the start of phase 2 (the constant of its
  * scalar objective differs from the reference's by f0 at that start: candidates closer than one ulp of f0 may resolve

@@ -215,11 +215,11 @@ def test_maxcut_unweighted_ties_are_the_references(eng_mod, orc):
 
 
 def test_stream_run_refusal_leaves_population(eng_mod):
-    """A problem the lifecycle kernels do not take (two constraint classes) is refused BEFORE the resident population is touched
-    (ADVICE round 4): the points uploaded before the call are still there and still evaluate."""
+    """A problem the lifecycle kernel does not take (six constraint classes: since round 6 it takes up to four) is refused BEFORE the
+    resident population is touched: the points uploaded before the call are still there and still evaluate."""
     from qcqp_amd import problems
     funcs, _, _ = problems.boolean_least_squares(64, 16, seed=1)
-    funcs = [funcs[0]] + [(P * (1.0 + (i % 2)), q, r * (1.0 + (i % 2)), rel_) for i, (P, q, r, rel_) in enumerate(funcs[1:])]
+    funcs = [funcs[0]] + [(P * (1.0 + (i % 6)), q, r * (1.0 + (i % 6)), rel_) for i, (P, q, r, rel_) in enumerate(funcs[1:])]
     e = make(eng_mod, funcs)
     X0 = np.random.RandomState(0).randn(64, 24)
     e.upload(X0)
@@ -518,6 +518,62 @@ def test_life_kernel_fuzz_shapes(eng_mod, orc, seed):
             for key in COUNTERS:
                 assert np.array_equal(o[key][sl], outr[key]), (tag, p, key)
             assert rel(o['f0'][sl], outr['f0']) < 1e-10 and np.max(np.abs(o['maxviol'][sl] - outr['maxviol'])) < 1e-12, (tag, p)
+            assert o['best_index'][p] == e.select_best(1e-4)[0], (tag, p)
+            if p == 0:
+                for r in sorted({0, R - 1}):
+                    rng = orc.Rng(orc.RNG_KEYED, sd)
+                    rng.set_restart(fi + r)
+                    x, s1, s2 = prob.improve_cd(Xs[:, r], num_iters=iters, phase1=phase1, rng=rng)
+                    assert rel(X[:, r], x) < 1e-9, (tag, r)
+                    assert o['visits2'][r] == s2[1] and o['accepted2'][r] == s2[2], (tag, r)
+        es.close()
+        e.close()
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_life_kernel_fuzz_several_classes(eng_mod, orc, seed):
+    """Eight random shapes per seed of the multi-class kinds (problems.multi_class: three classes of boxes, an annulus class beside an
+    equality class, two linear constraints per coordinate, MAXCUT with a relaxed class): n = 48 .. 300 incl. sizes that are not
+    multiples of 16, 1 .. 300 restarts, 1 .. 3 populations, sweep limits 0 .. 1000, with and without phase 1, generated and uploaded
+    starts.  Every population against the serial path (points 1e-9, all counters, objective, winner), two restarts per shape
+    against the oracle."""
+    from qcqp_amd import problems
+    rs = np.random.RandomState(2000 + seed)
+    for case in range(8):
+        fam = str(rs.choice(['box3', 'ann2', 'lin2', 'cut2']))
+        n = int(rs.choice([48, 50, 64, 77, 100, 128, 130, 200, 256, 300]))
+        R = int(rs.choice([1, 15, 16, 17, 100, 300]))
+        K = int(rs.choice([1, 2, 3]))
+        iters = int(rs.choice([0, 1, 2, 5, 40, 1000])) if fam in ('ann2', 'cut2') else int(rs.choice([0, 1, 3, 25]))
+        phase1, generate = bool(rs.rand() < 0.7), bool(rs.rand() < 0.6)
+        funcs = problems.multi_class(fam, n, seed=int(rs.randint(1, 50)))
+        es, e = make(eng_mod, funcs), make(eng_mod, funcs)
+        seed0, sstride, first0, fstride = int(rs.randint(1 << 20)), int(rs.randint(0, 4)), int(rs.randint(100)), int(rs.choice([0, R, 100000]))
+        tag = (seed, case, fam, n, R, K, iters, phase1, generate)
+        X0 = None
+        if generate:
+            o = es.cd_stream_run(K, R, generate=True, phase1=phase1, num_iters=iters, seed=seed0, seed_stride=sstride, first_index=first0, first_stride=fstride)
+        else:
+            X0 = np.sign(rs.randn(n, K * R)) * (0.6 + 0.4 * rs.rand(n, K * R))       # inside some classes' sets, outside others'
+            es.upload(X0)
+            o = es.cd_stream_run(K, R, generate=False, phase1=phase1, num_iters=iters, seed=seed0, seed_stride=sstride, first_index=first0, first_stride=fstride)
+        assert 'classes' in es.last_cd_kernel(), tag
+        X = es.download()
+        prob = orc.Problem(funcs)
+        for p in range(K):
+            sd, fi = seed0 + p * sstride, first0 + p * fstride
+            sl = slice(p * R, (p + 1) * R)
+            if generate:
+                e.randn(R, seed=sd, first_index=fi)
+            else:
+                e.upload(X0[:, sl])
+            Xs = e.download()
+            outr = e.cd_run(phase1=phase1, num_iters=iters, seed=sd, first_index=fi)
+            Xr = e.download()
+            assert rel(X[:, sl], Xr) < 1e-9, (tag, p)
+            for key in COUNTERS:
+                assert np.array_equal(o[key][sl], outr[key]), (tag, p, key)
+            assert rel(o['f0'][sl], outr['f0']) < 1e-9 and np.max(np.abs(o['maxviol'][sl] - outr['maxviol'])) < 1e-12, (tag, p)
             assert o['best_index'][p] == e.select_best(1e-4)[0], (tag, p)
             if p == 0:
                 for r in sorted({0, R - 1}):

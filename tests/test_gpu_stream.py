@@ -181,8 +181,9 @@ def test_cd_stream_run_exact_ties_take_the_reference_path(eng_mod, orc):
 
 def test_cd_stream_run_refuses_other_families(eng_mod):
     """No silent fallback: a family the kernel does not take is refused with a message that names the serial entry point -- for the
-    round-4 kernel anything but the Boolean family with n a multiple of 16; for cd_life_kernel several constraint classes (a
-    different right-hand side on every other coordinate), which it refuses, while n = 40 runs."""
+    round-4 kernel anything but the Boolean family with n a multiple of 16; for cd_life_kernel more than FOUR constraint classes (a
+    different right-hand side on six kinds of coordinates), which it refuses, while n = 40 runs and two classes run (round 6:
+    the multi-class kind)."""
     from qcqp_amd import problems
     funcs, _, _ = problems.boolean_least_squares(40, 10, seed=1)       # n not a multiple of 16
     e = make(eng_mod, funcs)
@@ -194,8 +195,13 @@ def test_cd_stream_run_refuses_other_families(eng_mod):
         assert e.last_cd_kernel() == 'cd_life_kernel<3,band>'
     funcs2 = [funcs[0]] + [(P * (1.0 + (i % 2)), q, r * (1.0 + (i % 2)), rl) for i, (P, q, r, rl) in enumerate(funcs[1:])]
     e2 = make(eng_mod, funcs2)
-    with pytest.raises(eng_mod.EngineError, match='lifecycle') as ei:
+    if LIFE['version'] != 1:
         e2.cd_stream_run(2, 32)
+        assert e2.last_cd_kernel() == 'cd_life_kernel<3,gen,classes>'
+    funcs6 = [funcs[0]] + [(P * (1.0 + (i % 6)), q, r * (1.0 + (i % 6)), rl) for i, (P, q, r, rl) in enumerate(funcs[1:])]
+    e6 = make(eng_mod, funcs6)
+    with pytest.raises(eng_mod.EngineError, match='lifecycle') as ei:
+        e6.cd_stream_run(2, 32)
     assert ei.value.code == eng_mod.E_UNSUPPORTED
 
 

@@ -23,6 +23,8 @@ def build(fam, n):
         return problems.maxcut(n, 0.5, seed=1)[0]
     if fam == 'maxcutw':
         return problems.maxcut(n, 0.5, seed=1, weighted=True)[0]
+    if fam in ('box3', 'ann2', 'lin2', 'cut2'):
+        return problems.multi_class(fam, n)
     raise SystemExit('family?')
 
 
