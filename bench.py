@@ -40,6 +40,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 from qcqp_amd import _threads  # noqa: E402
 
+if '--gpus' in sys.argv[:-1]:          # the ranks of a multi-GPU run share the machine's CPU quota (this process may spawn them itself)
+    try:
+        os.environ.setdefault('QCQP_LOCAL_RANKS', str(max(1, int(sys.argv[sys.argv.index('--gpus') + 1]))))
+    except ValueError:
+        pass
 _threads.set_blas_env()      # BEFORE NumPy: 256 visible CPUs, 16 cores of cgroup quota -- spinning BLAS workers get the whole container throttled
 
 import numpy as np  # noqa: E402

@@ -33,10 +33,22 @@ def usable_cores():
     return max(1, cores)
 
 
+def local_ranks():
+    """Processes of this job that share the machine (and its CPU quota): the launcher's LOCAL_WORLD_SIZE / WORLD_SIZE, or what
+    bench.py announces for the ranks it spawns itself (QCQP_LOCAL_RANKS)."""
+    n = 1
+    for v in ('LOCAL_WORLD_SIZE', 'WORLD_SIZE', 'QCQP_LOCAL_RANKS'):
+        try:
+            n = max(n, int(os.environ.get(v, '1')))
+        except ValueError:
+            pass
+    return n
+
+
 def blas_threads():
-    """Threads for the BLAS pools: half of what the process may use (the rest is for the thread that drives the GPU and for
-    the CPU-baseline workers), at most 8."""
-    return max(1, min(8, usable_cores() // 2))
+    """Threads for the BLAS pools: half of this rank's share of what the job may use (the rest is for the thread that drives the
+    GPU -- it polls -- and for the CPU-baseline workers), at most 8."""
+    return max(1, min(8, usable_cores() // (2 * local_ranks())))
 
 
 def set_blas_env():

@@ -811,3 +811,32 @@ def test_build_units_cover_every_source_file():
             assert _build._stale(obj, _build._unit_deps('cd_life.hip'))
         finally:
             os.utime(hdr, (st.st_atime, st.st_mtime))
+
+
+def test_host_thread_budget_follows_the_cgroup_quota_and_the_ranks(monkeypatch):
+    """qcqp_amd/_threads.py (round 6: a 256-thread BLAS pool in a container with 16 cores of quota got the host thread that waits for
+    the GPU throttled -- profiles/r06_timed_region.md): usable cores = min(affinity, quota), the BLAS pools get half of a rank's share
+    (at most 8, at least 1), the environment is only filled where the user has not spoken."""
+    import os
+    from qcqp_amd import _threads
+    cores = _threads.usable_cores()
+    assert 1 <= cores <= (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            assert cores <= max(1, int(quota) // int(period))
+    except OSError:
+        pass
+    for v in ('LOCAL_WORLD_SIZE', 'WORLD_SIZE', 'QCQP_LOCAL_RANKS'):
+        monkeypatch.delenv(v, raising=False)
+    one = _threads.blas_threads()
+    assert one == max(1, min(8, cores // 2))
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    assert _threads.local_ranks() == 8 and _threads.blas_threads() == max(1, min(8, cores // 16))
+    monkeypatch.setenv('OPENBLAS_NUM_THREADS', '3')
+    monkeypatch.delenv('OMP_NUM_THREADS', raising=False)
+    _threads.set_blas_env()
+    assert os.environ['OPENBLAS_NUM_THREADS'] == '3' and os.environ['OMP_NUM_THREADS'] == str(_threads.blas_threads())
+    with _threads.blas_limit():         # usable with or without threadpoolctl
+        import numpy as np
+        assert float(np.ones((8, 8)).dot(np.ones(8)).sum()) == 64.0
