@@ -530,7 +530,7 @@ def test_life_kernel_fuzz_shapes(eng_mod, orc, seed):
         e.close()
 
 
-@pytest.mark.parametrize('seed', [0, 1])
+@pytest.mark.parametrize('seed', list(range(int(__import__('os').environ.get('QCQP_FUZZ_SEEDS', '2')))))     # (QCQP_FUZZ_SEEDS=N: a longer shake-out)
 def test_life_kernel_fuzz_several_classes(eng_mod, orc, seed):
     """Eight random shapes per seed of the multi-class kinds (problems.multi_class: three classes of boxes, an annulus class beside an
     equality class, two linear constraints per coordinate, MAXCUT with a relaxed class): n = 48 .. 300 incl. sizes that are not
