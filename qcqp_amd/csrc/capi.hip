@@ -1269,8 +1269,9 @@ int qcqpmi_pop_eval(qcqpmi_ctx *c, double *f0, double *maxviol, double *F) {
 // ---- suggest(SDR) for S samples in one call (qcqp.py:396-401: x = multivariate_normal(mu, Sigma), f0.eval(x), max(violations(x));
 // SURVEY section 8b's qcqpmi_sdr_sample_eval).  The samples are drawn (x = mu + F xi, normals by keyed Philox: sample first_index + s
 // is the same point whatever S and the chunking) and evaluated chunk by chunk on the stream: the normals and the points of a chunk
-// live in two buffers every chunk reuses (<= 32 MB each: they stay in the Infinity Cache between the sampler's GEMM and the
-// evaluation's GEMM), a population of S points is never laid out in HBM.  X_opt == NULL: the points are not kept at all -- the caller
+// live in two buffers every chunk reuses (<= 32 MB each, sized to fit the 256 MB Infinity Cache between the sampler's GEMM and the
+// evaluation's GEMM; not measured separately: at configs[2]'s size the round trip of X is 1 % of the two GEMMs either way); a
+// population of S points is never laid out in HBM.  X_opt == NULL: the points are not kept at all -- the caller
 // re-draws the winner from its index (S = 1, the same first_index + s).  Afterwards the resident population is the LAST chunk.
 int qcqpmi_sdr_sample_eval(qcqpmi_ctx *c, const double *mu, const double *F, int64_t S, uint64_t seed, uint64_t first_index,
                            double *X_opt, double *f0, double *maxviol) {
