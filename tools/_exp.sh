@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_dense_r06; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python $GRAFT_REPO_ROOT/tools/dense_rate.py 1024 256 512 > $OUT/stats.log 2>&1
-grep -v "^[WE]2026" $OUT/stats.log | tail -3
-head -12 $OUT/stats/stats_kernel_stats.csv | cut -c1-140
-python $GRAFT_REPO_ROOT/tools/dense_timeline.py $OUT/stats 40
-find $OUT -name "*kernel_trace.csv" -size +20M -delete
+LIFE_FACTOR=1 LIFE_PROF=1 LIFE_SERIAL=1 python tools/life_check.py bls 1024 4096 20 1000 0 2>&1 | grep -v "^population\|reported\|objective factor" | head -16
+for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(1e3*d['timed_region_s'],2), round(d['roofline']['kernel_ms_per_launch'],2), d['roofline']['frac'])"; done
+python -m pytest tests/test_gpu_life.py -m gpu -x -q -k "factored" 2>&1 | tail -2
