@@ -272,14 +272,14 @@ class QCQP(object):
     def _objective_factor(self, enable=True):
         """Once per problem: P0 = L L^T of low rank (a least-squares objective: rank = rows of A) -> the lifecycle kernel carries
         L^T X instead of multiplying with P0 (qcqp_amd.lowrank.objective_factor, qcqpmi_cd_set_objective_factor).  Tried for a
-        dense-enough P0 with a positive diagonal of 256 <= n <= 1088; `factor=False` in improve() switches it off."""
+        dense-enough P0 with a positive diagonal of 256 <= n <= 4096; `factor=False` in improve() switches it off."""
         want = bool(enable)
         state = getattr(self, '_factor_state', None)
         if state is None:
             L = None
             f0 = self.qcqp_form.f0
             n = self.n
-            if want and 256 <= n <= 1088:
+            if want and 256 <= n <= 4096:
                 from .lowrank import objective_factor
                 P0 = f0.P.toarray() if hasattr(f0.P, 'toarray') else np.asarray(f0.P)
                 if np.all(np.diag(P0) > 0.0):

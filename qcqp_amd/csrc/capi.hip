@@ -1560,8 +1560,9 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     stm[0] = stnow();
     // ---- which kernel (decided BEFORE the resident population is touched: a refused call leaves the context as it was)
     int nmw = 0, cs2 = 0, kind = 0;
+    const int factor_rb = (c->lr_RB > 0 && c->life_version != 3 && cd_life2_factor_ok(c->dp, 16 * (int64_t)c->lr_RB)) ? c->lr_RB : 0;
     bool use2 = c->life_version != 1 && !c->force_generic && !(c->dbg & 64) && c->sep &&
-                cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, &nmw, &cs2, &kind);
+                cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, factor_rb, &nmw, &cs2, &kind);
     int cs = 0;
     const int queue_switch = c->cd_queue;
     c->cd_queue = 2;                                   // (qcqpmi_cd_queue chooses the phase-2 kernel of qcqpmi_cd_run; it does not apply here)
@@ -1574,7 +1575,7 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
     // kernel: a debug switch, kept as the independent implementation the tests compare against.
     // factored objective (qcqpmi_cd_set_objective_factor): cd_life_kernel's products through Y = L^T X -- half the matrix work and less
     // per block interval, a positive diagonal (band / gen kinds), three multiplying waves per tile
-    const bool lr = use2 && c->lr_RB > 0 && nmw == 3 && (kind == L2_KIND_BAND || kind == L2_KIND_GEN) && c->life_version != 3 && cd_life2_factor_ok(c->dp, 16 * (int64_t)c->lr_RB);
+    const bool lr = use2 && factor_rb > 0 && nmw == 3 && (kind == L2_KIND_BAND || kind == L2_KIND_GEN);
     if (lr) cs2 = 0;
     if (!use2) {
         if (!eligible || c->life_version != 1)
@@ -1715,7 +1716,7 @@ int qcqpmi_cd_stream_reserve(qcqpmi_ctx *c, int64_t K, int64_t R) {
     {
         int nmw = 0, cs2 = 0, kind = 0, cus = 0;
         HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        if (c->life_version != 1 && c->sep && cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, &nmw, &cs2, &kind) && (rc = cd_life2_reserve(c, nmw, cus))) return rc;
+        if (c->life_version != 1 && c->sep && cd_life2_config(c->dp, c->Kreal, c->objclass, c->symcls, c->lr_RB, &nmw, &cs2, &kind) && (rc = cd_life2_reserve(c, nmw, cus))) return rc;
     }
     return 0;
 }

@@ -58,7 +58,9 @@ struct CdLife2Args {
 };
 
 // does the kernel take this problem?  nmw / cs / kind: the instantiation (multiplying waves 3 | 7, chain share, step kind)
-bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, int *nmw, int *cs, int *kind);
+// factor_rb: blocks of 16 rows of an objective factor the caller WILL hand over (0: none) -- the factored instantiation keeps Y, not X,
+// in registers, so with a factor the kernel also takes 2304 < n <= 4096 (and prefers three multiplying waves from n = 1040 on)
+bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, int factor_rb, int *nmw, int *cs, int *kind);
 size_t cd_life2_lds_bytes(int nmw, int cs, int tiles, int lr, int kind);
 bool cd_life2_factor_ok(const DevProblem &P, int64_t r);
 int cd_life2_pack_factor(const double *Lrow, double *Gpack, double *Upack, int NB, int RB, hipStream_t st);

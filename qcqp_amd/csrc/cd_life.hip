@@ -1596,7 +1596,7 @@ int cd_life2_pack_factor(const double *Lrow, double *Gpack, double *Upack, int N
 
 int cd_life2_max_wgs(int nmw, int cus, int tiles) { return (nmw == 3 && tiles == 1) ? 2 * cus : cus; }
 
-bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, int *nmw, int *cs, int *kind) {
+bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, int factor_rb, int *nmw, int *cs, int *kind) {
     // one class with one constraint per coordinate: the BAND / GEN / LIN kinds; up to L2_KCL classes with up to two constraints per
     // coordinate (every real coordinate constrained): GENK / LINK
     if (!P.sep || P.maxc < 1 || P.maxc > 2 || Kreal < 1 || Kreal > L2_KCL) return false;
@@ -1607,6 +1607,7 @@ bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, 
     int w, c;
     if (NB <= 4) { w = 3; c = 0; }
     else if (NB - 4 <= 3 * RQ_MAXU) { w = 3; c = (NB < 8) ? 2 : 4; }
+    else if (factor_rb > 0 && !multi && objclass == 1 && NB <= 256) { w = 3; c = 0; }      // factored: nothing in its registers grows with n
     else if (NB - 4 <= 7 * RQ_MAXU) { w = 7; c = 4; }
     else return false;
     *nmw = w; *cs = c;

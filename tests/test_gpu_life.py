@@ -330,6 +330,9 @@ FACTORED = [
     ('bls', 1000, 250, 150, 2, 1000, 2),           # n not a multiple of 16 (63 blocks), rank 250 (16 blocks of Y, the last one partly zero)
     ('bls', 1024, 256, 4096, 2, 1000, 2),          # BASELINE.json configs[1]
     ('box', 320, 96, 700, 2, 60, 2),               # the `gen` step kind (box |x_i| <= 1) on a rank-96 objective
+    ('bls', 2320, 200, 40, 1, 2, 0),               # past 2304: ONLY the factored instantiation goes there (Y, not X, lives in registers); the oracle
+                                                   # needs ~40 s per sweep at this size: the serial path (oracle-checked up to n = 1040) stands in
+    ('bls', 4096, 256, 32, 2, 2, 0),               # n = 4096 (256 blocks of 16 coordinates), two populations
 ]
 
 
@@ -396,10 +399,16 @@ def test_factored_objective_kernel_vs_serial_oracle_and_itself(eng_mod, orc, fam
     o2 = es.cd_stream_run(1, K * R, num_iters=iters, seed=seed0, seed_stride=0, first_index=first0, first_stride=0)
     assert np.array_equal(X1, es.download()) and np.array_equal(o1['f0'], o2['f0'])
     assert np.array_equal(X1[:, :R], X[:, :R]) and np.array_equal(o1['f0'][:R], o['f0'][:R])      # population 0 has the same keys in both runs
-    # without the factor the same call runs the kernel that multiplies with P0
+    # without the factor the same call runs the kernel that multiplies with P0 -- where that one exists (n <= 2304: its B operands are
+    # the X tile, register-resident); beyond, the call is refused
     es.cd_set_objective_factor(None)
-    es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
-    assert 'factored' not in es.last_cd_kernel()
+    if n <= 2304:
+        es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
+        assert 'factored' not in es.last_cd_kernel()
+    else:
+        with pytest.raises(eng_mod.EngineError) as ei:
+            es.cd_stream_run(K, R, num_iters=iters, seed=seed0, seed_stride=1, first_index=first0, first_stride=fstride)
+        assert ei.value.code == eng_mod.E_UNSUPPORTED
 
 
 MULTI = [
