@@ -318,8 +318,9 @@ int qcqpmi_debug_life_profile(qcqpmi_ctx *ctx, int64_t *out24);
  * classes of coordinates (coordinates whose constraint lists are bit-identical share a class) and up to two constraints per
  * coordinate -- boxes with different bounds, an annulus beside an equality, two linear bounds, MAXCUT with relaxed vertices
  * (qcqp.py:113-141, 160-176 treat every coordinate's list on its own); ONE lifecycle kernel for every shape; with
- * qcqpmi_cd_set_objective_factor the kernel carries L^T X instead of multiplying with P0.  QCQPMI_EUNSUPPORTED otherwise (more
- * than four classes, three or four constraints per coordinate, mixed diagonal signs, coupled constraints, n > 2304): use
+ * qcqpmi_cd_set_objective_factor the kernel carries L^T X instead of multiplying with P0 and takes n up to 4096.
+ * QCQPMI_EUNSUPPORTED otherwise (more than four classes, three or four constraints per coordinate, mixed diagonal signs, coupled
+ * constraints, n > 2304 without an objective factor): use
  * qcqpmi_cd_run per population; a refused call leaves the resident population untouched.  K R < 2^30 (restart tickets are 32-bit; QCQPMI_EINVAL beyond).
  * Near-ties: a restart whose decision is within rounding of a tie is replayed in the reference's arithmetic like in
  * qcqpmi_cd_run; for a positive diagonal the replay sees the objective RELATIVE to the start of phase 2 (the constant of its
@@ -345,7 +346,7 @@ int qcqpmi_cd_life_version(qcqpmi_ctx *ctx, int version);
  * kernel carries Y = L^T X per tile of restarts instead of multiplying with P0: (P0 X)[I_b, :] = L[I_b, :] Y and Y += L[I_b, :]^T (moves
  * of block b) -- 8 r / 16 matrix instructions per block of 16 coordinates instead of n / 4.  P0 itself stays uploaded (diagonal
  * blocks, the evaluation kernels, every other path); the caller vouches for L L^T = P0 (qcqp_amd.lowrank.objective_factor checks
- * it to 1e-12 of the largest entry).  Takes r <= 288 and 128 <= n <= 1024 + 64, single-class separable constraints on a positive
+ * it to 1e-12 of the largest entry).  Takes r <= 288 and 128 <= n <= 4096 (ABI 6), single-class separable constraints on a positive
  * diagonal (QCQPMI_EUNSUPPORTED otherwise; qcqpmi_cd_stream_run then runs as without a factor).  L == NULL or r == 0 removes it;
  * qcqpmi_cd_life_version(ctx, 3) = cd_life_kernel WITHOUT the factor (comparisons). */
 int qcqpmi_cd_set_objective_factor(qcqpmi_ctx *ctx, const double *L, int64_t r);

@@ -330,8 +330,8 @@ FACTORED = [
     ('bls', 1000, 250, 150, 2, 1000, 2),           # n not a multiple of 16 (63 blocks), rank 250 (16 blocks of Y, the last one partly zero)
     ('bls', 1024, 256, 4096, 2, 1000, 2),          # BASELINE.json configs[1]
     ('box', 320, 96, 700, 2, 60, 2),               # the `gen` step kind (box |x_i| <= 1) on a rank-96 objective
-    ('bls', 2320, 200, 40, 1, 2, 0),               # past 2304: ONLY the factored instantiation goes there (Y, not X, lives in registers); the oracle
-                                                   # needs ~40 s per sweep at this size: the serial path (oracle-checked up to n = 1040) stands in
+    ('bls', 2320, 200, 40, 1, 1, 1),               # past 2304: ONLY the factored instantiation goes there (Y, not X, lives in registers); ONE sweep,
+                                                   # one oracle trajectory (~30 s of oracle per sweep at this size), all restarts against the serial path
     ('bls', 4096, 256, 32, 2, 2, 0),               # n = 4096 (256 blocks of 16 coordinates), two populations
 ]
 
