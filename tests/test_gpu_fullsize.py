@@ -167,7 +167,8 @@ def test_config4_admm_fused_kernel_full_size_vs_oracle(eng_mod, orc):
     """The ADMM path bench.py times for BASELINE.json configs[3] -- reduced bases (rp = 3 instead of 1024 coordinates per
     constraint) inside the fused persistent kernel, 128 restarts = the share of one GPU of eight (clusters of 16 workgroups
     per tile) -- against the ORACLE directly (improve_admm, qcqp.py:254-285, in the full eigenbasis) at full size, n = 1024,
-    m = 80, rho = 1, 100 + 100 iterations: points, objective and max violation of two restarts within the north star's 1e-6.
+    m = 80, rho = 1, 60 + 60 iterations (0.17 s of oracle per iteration and restart): points, objective and max violation of two
+    restarts within the north star's 1e-6.
     The engine's bisections start from the bracket the reference derives from the eigenvalues the oracle is given
     (utilities.py:176-180; qcqpmi_admm_set_bracket), so both visit the same midpoints."""
     from conftest import oracle_map
@@ -176,7 +177,7 @@ def test_config4_admm_fused_kernel_full_size_vs_oracle(eng_mod, orc):
     funcs, _, _ = problems.beamforming(512, 16, 64, seed=1)
     form = QCQPForm.from_arrays(funcs)
     n, m = form.n, form.m
-    rho, iters, R = 1.0, 100, 128
+    rho, iters, R = 1.0, 60, 128
     lm, Q = _eig_lowrank(form)
     X0 = np.random.RandomState(11).randn(n, R)
     e = eng_mod.Engine(form)
