@@ -564,10 +564,11 @@ def test_life_kernel_fuzz_several_classes(eng_mod, orc, seed):
     rs = np.random.RandomState(2000 + seed)
     for case in range(8):
         fam = str(rs.choice(['box3', 'ann2', 'lin2', 'cut2']))
-        n = int(rs.choice([48, 50, 64, 77, 100, 128, 130, 200, 256, 300]))
+        big = __import__('os').environ.get('QCQP_FUZZ_BIG') == '1'        # a shake-out of the larger instantiations (no oracle there: ~30 s per sweep)
+        n = int(rs.choice([500, 777, 1024, 1040, 1100, 1500, 2000] if big else [48, 50, 64, 77, 100, 128, 130, 200, 256, 300]))
         R = int(rs.choice([1, 15, 16, 17, 100, 300]))
         K = int(rs.choice([1, 2, 3]))
-        iters = int(rs.choice([0, 1, 2, 5, 40, 1000])) if fam in ('ann2', 'cut2') else int(rs.choice([0, 1, 3, 25]))
+        iters = int(rs.choice([0, 1, 2, 3])) if big else (int(rs.choice([0, 1, 2, 5, 40, 1000])) if fam in ('ann2', 'cut2') else int(rs.choice([0, 1, 3, 25])))
         phase1, generate = bool(rs.rand() < 0.7), bool(rs.rand() < 0.6)
         funcs = problems.multi_class(fam, n, seed=int(rs.randint(1, 50)))
         es, e = make(eng_mod, funcs), make(eng_mod, funcs)
@@ -598,7 +599,7 @@ def test_life_kernel_fuzz_several_classes(eng_mod, orc, seed):
                 assert np.array_equal(o[key][sl], outr[key]), (tag, p, key)
             assert rel(o['f0'][sl], outr['f0']) < 1e-9 and np.max(np.abs(o['maxviol'][sl] - outr['maxviol'])) < 1e-12, (tag, p)
             assert o['best_index'][p] == e.select_best(1e-4)[0], (tag, p)
-            if p == 0:
+            if p == 0 and not big:
                 for r in sorted({0, R - 1}):
                     rng = orc.Rng(orc.RNG_KEYED, sd)
                     rng.set_restart(fi + r)
