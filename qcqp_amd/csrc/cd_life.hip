@@ -1618,7 +1618,7 @@ bool cd_life2_config(const DevProblem &P, int Kreal, int objclass, bool symcls, 
 // tiles per workgroup (0 = automatic; QCQPMI_L2_TILES overrides: experiments).  Two tiles per workgroup -- one eight-wave workgroup
 // per CU, joint episodes, the build by 512 threads -- exist for the factored objective only and are NOT the default: measured at
 // n = 1024 (20 x 4096 restarts) 33.7-35.4 ms against 32.6-34.4 ms for two four-wave workgroups per CU, whose column builds overlap
-// the neighbour's products (profiles/r06_factored_objective.md; without a factor: 52.0-53.5 against 49.5-51.0 ms,
+// the neighbour's products (profiles/r06_summary.md; without a factor: 52.0-53.5 against 49.5-51.0 ms,
 // profiles/r06_headline_experiments.md -- that instantiation was removed).
 int cd_life2_tiles(const DevProblem &P, int nmw, int cs, int64_t restarts, int cus, int requested, int lr) {
     (void)P; (void)restarts; (void)cus;
