@@ -1620,10 +1620,14 @@ int qcqpmi_cd_stream_run(qcqpmi_ctx *c, int64_t K, int64_t R, int generate, int 
         cd_queue_fill_batch(c, qa.b, seed, first_index);
         qa.b.R = K * R;
         qa.scratch = c->l2_scratch; qa.Dpack = c->l2_D; qa.Spack = c->l2_S; qa.abort = c->l2_abort; qa.fbound = c->fbound;
-        // the two chains of a CU on different SIMDs (QCQPMI_L2_ROT=1): an experiment of round 6, OFF -- measured at n = 1024, 20 x 4096 restarts,
-        // factored: 33.2 -> 35.7 ms (a chain beside a product stream: its fix-up + staging 1.26 k -> 2.21 k cycles per block interval behind
-        // the stream's queued matrix instructions; two chains on one SIMD interleave); without the factor 48.4 -> 48.7 ms (profiles/r06_summary.md)
-        { const char *ev = getenv("QCQPMI_L2_ROT"); const bool rot = ev ? atoi(ev) != 0 : false; qa.cuslot = rot ? c->l2_cuslot : nullptr; }
+        // which of its CU's two workgroups a workgroup is (arrival counter per CU, HW_ID), and what the second one does with it:
+        //   QCQPMI_L2_ROT=2 (the default with the factored objective): it turns its MULTIPLYING roles by one among SIMDs 1-3 -- 16 blocks of Y
+        //   are 6 + 5 + 5 over the three waves, and with both six-block waves on SIMD 1 that SIMD's matrix pipe was 83 % busy and late for
+        //   one product in ten: the chain's wait for partial tiles 0.76 k -> 0.57 k cycles per block interval, the interval 7.45 k -> 7.29 k
+        //   (A / B / A / B on one box: 32.93 / 32.57 / 32.80 / 32.45 ms per 20 x 4096 restarts; same bits);
+        //   QCQPMI_L2_ROT=1: it turns ALL roles by two SIMDs (the two chains on different SIMDs) -- measured SLOWER, 33.2 -> 35.7 ms: a chain
+        //   beside a product stream waits behind the stream's queued matrix instructions (profiles/r06_summary.md);  0: off
+        { const char *ev = getenv("QCQPMI_L2_ROT"); const int rot = ev ? atoi(ev) : (lr ? 2 : 0); qa.cuslot = rot ? c->l2_cuslot : nullptr; qa.rotmode = rot; }
         if (qa.cuslot) HIPCHK(c, hipMemsetAsync(c->l2_cuslot, 0, 4096 * sizeof(int), c->stream));
         qa.dbg = (c->dbg & 2048) ? 1 : 0;
         qa.Gpack = lr ? c->lr_G : nullptr; qa.Upack = lr ? c->lr_U : nullptr; qa.RB = lr ? c->lr_RB : 0;

@@ -53,6 +53,8 @@ struct CdLife2Args {
     // RB = blocks of 16 rows of Y (0: not factored)
     const double *Gpack, *Upack;
     int RB;
+    int rotmode;                 // with cuslot: 1 = the second workgroup of a CU turns ALL roles by two SIMDs (chains on different SIMDs: measured slower),
+                                 // 2 = it turns only its multiplying roles by one among SIMDs 1-3 (the wave with six blocks of Y of either workgroup on its own SIMD)
     int nclass;                  // multi-class kinds: classes among the real coordinates (<= 4; class k = DevProblem::krep[k])
     int dbg;                     // timing experiments (results INVALID when != 0): 1 = every block row reads the fragments of rows 0..7 (an L2-resident stream)
 };

@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
             const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
             arrival = l2_add(l2_g(a0.cuslot) + (((xcc & 15) << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15)), 1);
         }
-        simdof[8] = (arrival & 1) ? 2 : 0;
+        simdof[8] = (arrival & 1) ? (a0.rotmode == 2 ? 16 + 1 : 2) : 0;      // >= 16: a turn among the multiplying SIMDs only
     }
     if (tid0 < 64 * TILES) {
         long long *cs_ = l2_tl(cst, tid0 >> 6, TD);
@@ -1149,7 +1149,12 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
             rank += (s == mys && w < wave) ? 1 : 0;
         }
         const bool even = cnt[0] == NW / 4 && cnt[1] == NW / 4 && cnt[2] == NW / 4 && cnt[3] == NW / 4;
-        if (NMW == 3 && TILES == 1) role = even ? ((mys + simdof[8]) & 3) : wave;
+        if (NMW == 3 && TILES == 1) {
+            const int rot = simdof[8];
+            if (!even) role = wave;
+            else if (rot >= 16) role = mys == 0 ? 0 : 1 + ((mys - 1 + (rot - 16)) % 3);
+            else role = (mys + rot) & 3;
+        }
         else if (TILES == 2) { role = even ? mys : (wave & 3); rtile = even ? rank : (wave >> 2); }      // SIMD s: the waves of role s of both tiles
         else if (even) role = (mys == 0) ? (rank == 0 ? 0 : 7) : mys + 3 * rank;      // SIMD s: waves s (, s + 3); SIMD 0: the chain and wave 7
         else role = wave;
