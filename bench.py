@@ -1064,7 +1064,7 @@ def main():
             res['roofline']['executed_flops_per_restart_sweep'] = executed
             res['roofline']['frac_executed'] = res['roofline']['frac'] * executed / (2.0 * n * n)
             res['roofline']['note'] = ('frac counts the ALGORITHMIC 2 n^2 flops of a sweep (the unit of `value`); the kernel carries L^T X '
-                                       '(P0 = L L^T, rank %d) and executes %.2f of them; the sequential chain, not the matrix pipe, is the limit'
+                                       '(P0 = L L^T, rank %d) and executes %.2f of them; bound by the two sequential chains of a CU together with the three multiplying SIMDs'
                                        % (factor_rank, executed / (2.0 * n * n)))
         if pmc:
             side['traffic_provenance'] = {k: pmc[k] for k in ('source', 'profile_commit', 'profile_date', 'kernel', 'launch')}
