@@ -1123,7 +1123,8 @@ __global__ __launch_bounds__((NMW == 3 && TILES == 1) ? 256 : 512, 2) void cd_li
         int arrival = 0;
         if (a0.cuslot) {
             const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
-            arrival = l2_add(l2_g(a0.cuslot) + (((xcc & 15) << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15)), 1);
+            // key: XCC, then HW_ID's SE_ID[15:13] and SH_ID[12] (four bits), then CU_ID[11:8]: one counter per compute unit
+            arrival = l2_add(l2_g(a0.cuslot) + (((xcc & 15) << 8) | (((hw >> 12) & 15) << 4) | ((hw >> 8) & 15)), 1);
         }
         simdof[8] = (arrival & 1) ? (a0.rotmode == 2 ? 16 + 1 : 2) : 0;      // >= 16: a turn among the multiplying SIMDs only
     }
