@@ -840,3 +840,34 @@ def test_host_thread_budget_follows_the_cgroup_quota_and_the_ranks(monkeypatch):
     with _threads.blas_limit():         # usable with or without threadpoolctl
         import numpy as np
         assert float(np.ones((8, 8)).dot(np.ones(8)).sum()) == 64.0
+
+
+def test_multi_class_families_are_what_the_kinds_take_and_the_oracle_solves_them():
+    """problems.multi_class (round 6: the families of cd_life_kernel's GENK / LINK kinds): every coordinate is constrained, at most two
+    constraints per coordinate, at most four distinct constraint lists; the ORACLE's improve_coord_descent (qcqp.py:181-192) drives a
+    random start of each family to a point that is feasible within the phase-1 slack (viol_tol = 1e-2)."""
+    import numpy as np
+    from oracle import oracle as orc
+    from qcqp_amd import problems
+    from qcqp_amd.form import QCQPForm
+    n = 24
+    for fam in ('box3', 'ann2', 'lin2', 'cut2'):
+        funcs = problems.multi_class(fam, n)
+        form = QCQPForm.from_arrays(funcs)
+        lists = {}
+        for (P, q, r, relop) in funcs[1:]:
+            P = P.toarray() if hasattr(P, 'toarray') else np.asarray(P)
+            nz = np.flatnonzero(np.abs(P).sum(axis=0) + np.abs(np.asarray(q)))
+            assert nz.size == 1 and np.count_nonzero(P - np.diag(np.diag(P))) == 0, fam      # separable: one coordinate per constraint
+            i = int(nz[0])
+            lists.setdefault(i, []).append((float(P[i, i]), float(np.asarray(q)[i]), float(r), relop))
+        assert sorted(lists) == list(range(n)), fam                                      # every coordinate constrained
+        assert max(len(v) for v in lists.values()) <= 2
+        assert len({tuple(v) for v in lists.values()}) <= 4
+        assert form.m == sum(len(v) for v in lists.values())
+        prob = orc.Problem(funcs)
+        rng = orc.Rng(orc.RNG_KEYED, 7)
+        rng.set_restart(3)
+        x0 = orc.keyed_normal_matrix(7, n, 1, first_index=3)[:, 0]
+        x, s1, s2 = prob.improve_cd(x0, num_iters=200, rng=rng)
+        assert prob.max_violation(x) < 1e-2, (fam, prob.max_violation(x))
